@@ -1,0 +1,96 @@
+"""oracle/natives.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle_cint.so (the C restatement of the libcint /
+libcgto arithmetic the reference reaches through dqclibs:
+dqc/hamilton/intor/molintor.py:590-708, dqc/hamilton/intor/gtoeval.py:196-239).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle_cint.so")
+        src = os.path.join(_HERE, "cint_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            build()
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def _p(a, t=ctypes.c_double):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _tab(t):
+    return (_p(t.atm, ctypes.c_int), ctypes.c_int(t.natm), _p(t.bas, ctypes.c_int),
+            ctypes.c_int(t.nbas), _p(t.env))
+
+
+def int1e(which, t, zs=None):
+    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao)"""
+    code = {"ovlp": 0, "kin": 1, "nuc": 2}[which]
+    out = np.zeros((t.nao, t.nao))
+    zp = None
+    if zs is not None:
+        zs = np.ascontiguousarray(zs, dtype=np.float64)
+        zp = _p(zs)
+    lib().orc_int1e(ctypes.c_int(code), _p(out), *_tab(t), zp)
+    return out
+
+
+def int2e_s4(t):
+    """packed (npair, npair), pair index i(i+1)/2+j"""
+    npair = t.nao * (t.nao + 1) // 2
+    out = np.zeros((npair, npair))
+    lib().orc_int2e_s4(_p(out), *_tab(t))
+    return out
+
+
+def fills4(packed, nao):
+    out = np.empty((nao, nao, nao, nao))
+    lib().orc_fills4(_p(out), _p(np.ascontiguousarray(packed)), ctypes.c_int(nao))
+    return out
+
+
+def int2e(t):
+    """dense (nao,)*4 like molintor.elrep after S4Symmetry expansion"""
+    return fills4(int2e_s4(t), t.nao)
+
+
+def eval_gto(t, rgrid, deriv=0):
+    """deriv 0: (nao, ngrid); 1: (3, nao, ngrid); 2: laplacian (nao, ngrid)"""
+    rgrid = np.ascontiguousarray(rgrid, dtype=np.float64)
+    ng = rgrid.shape[0]
+    shape = (3, t.nao, ng) if deriv == 1 else (t.nao, ng)
+    out = np.zeros(shape)
+    lib().orc_eval_gto(ctypes.c_int(deriv), _p(out), _p(rgrid), ctypes.c_int(ng), *_tab(t))
+    return out
+
+
+def cart2sph(l):
+    nc = (l + 1) * (l + 2) // 2
+    out = np.zeros((2 * l + 1, nc))
+    lib().orc_cart2sph(ctypes.c_int(l), _p(out))
+    return out
+
+
+def boys(mmax, T):
+    out = np.zeros(mmax + 1)
+    lib().orc_boys(ctypes.c_int(mmax), ctypes.c_double(T), _p(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()
