@@ -1,0 +1,274 @@
+"""oracle/hamilton.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU (torch float64) restatement of the reference's Hamiltonian and SCF engines, with the
+reference's own algorithm shape -- dense (nao^4) el_mat, the two einsum strings, separate
+density / Vxc passes chunked at CHUNK_MEMORY -- used as the parity checker and as the
+`cpu_baseline` leg of bench.py ("restatement of DQC's CPU algorithm, not an executed DQC").
+
+  HamiltonCGTO.build / setup_grid          dqc/hamilton/hcgto.py:95-186
+  get_elrep / get_exchange (returns -K/2)  dqc/hamilton/hcgto.py:204-241
+  get_vxc, _dm2densinfo, _get_vxc_from_potinfo   hcgto.py:260-269, 371-495
+  energies                                  hcgto.py:302-328
+  OrbitalOrthogonalizer                     dqc/hamilton/orbconverter.py:67-116
+  chunkify                                  dqc/utils/mem.py:6-38, config.CHUNK_MEMORY dqc/utils/config.py:10
+  _HFEngine / _KSEngine dm2scp, scp2dm, dm2energy   dqc/qccalc/hf.py:93-247, ks.py:110-187
+  SCF_QCCalc.run ("1e" guess, fixed point on the Fock matrix)   dqc/qccalc/scf_qccalc.py:84-116
+  Mol.get_nuclei_energy, occupations        dqc/system/mol.py:252-260, 421-443
+"""
+import numpy as np
+import torch
+
+from . import natives, grid as ogrid, xc as oxc, basis as obasis
+
+CHUNK_MEMORY = 16 * 1024 ** 2  # dqc/utils/config.py:10
+
+
+def chunkify(a, dim, maxnumel):
+    """dqc/utils/mem.py:6-38"""
+    numel = a.numel()
+    dimnumel = a.shape[dim]
+    nondimnumel = numel // dimnumel
+    if maxnumel < nondimnumel:
+        raise RuntimeError("too small chunk")
+    csize = min(maxnumel // nondimnumel, dimnumel)
+    ioff = 0
+    while ioff < dimnumel:
+        iend = min(ioff + csize, dimnumel)
+        yield a.narrow(dim, ioff, iend - ioff), ioff, iend
+        ioff = iend
+
+
+class Hamilton:
+    """Restatement of HamiltonCGTO for isolated molecules (no DF, no efield/vext)."""
+
+    def __init__(self, tables, orthozer=True, eri_mode="dense"):
+        self.t = tables
+        self.eri_mode = eri_mode  # "dense": reference formulation; "s4": packed variant for big nao
+        ovlp = torch.as_tensor(natives.int1e("ovlp", tables))
+        if orthozer:
+            ev, evec = torch.linalg.eigh(ovlp)
+            acc = ev > 1e-6  # orbconverter.py:73
+            self.X = evec[:, acc] * ev[acc] ** -0.5
+        else:
+            self.X = torch.eye(tables.nao, dtype=torch.float64)
+        self.xc = None
+        self.xcfamily = 1
+
+    @property
+    def nao(self):
+        return self.X.shape[-1]
+
+    # ---- orbconverter ----
+    def convert2(self, m):
+        return self.X.T @ m @ self.X
+
+    def unconvert_dm(self, dm):
+        return torch.einsum("kl,ik,jl->ij", dm, self.X, self.X)
+
+    # ---- setups ----
+    def build(self):
+        t = self.t
+        olp = torch.as_tensor(natives.int1e("ovlp", t))
+        kin = torch.as_tensor(natives.int1e("kin", t))
+        nuc = torch.as_tensor(natives.int1e("nuc", t))
+        self.olp_mat = self.convert2(olp)
+        self.kinnucl_mat = self.convert2(kin + nuc)
+        self.nucl_mat = self.convert2(nuc)
+        if self.eri_mode == "dense":
+            el = torch.as_tensor(natives.int2e(t))
+            X = self.X
+            # orbconverter.convert4 (hcgto.py:132), done as four successive contractions
+            el = torch.einsum("ijkl,im->mjkl", el, X)
+            el = torch.einsum("mjkl,jn->mnkl", el, X)
+            el = torch.einsum("mnkl,kp->mnpl", el, X)
+            el = torch.einsum("mnpl,lq->mnpq", el, X)
+            self.el_mat = el.contiguous()
+        else:
+            self.el_s4 = torch.as_tensor(natives.int2e_s4(t))
+        return self
+
+    def setup_grid(self, rgrid, dvolume, xc):
+        self.xc = xc
+        self.xcfamily = 1 if xc is None else xc.family
+        self.rgrid = rgrid
+        self.dvolume = torch.as_tensor(dvolume)
+        self.basis = torch.as_tensor(natives.eval_gto(self.t, rgrid, 0)).T.contiguous()  # (ngrid, nao)
+        self.basis_dvolume = self.basis * self.dvolume.unsqueeze(-1)
+        if self.xcfamily >= 2:
+            self.grad_basis = torch.as_tensor(natives.eval_gto(self.t, rgrid, 1)).transpose(-2, -1).contiguous()
+
+    # ---- Fock components (all in the orthogonalised basis) ----
+    def _pack_dm(self, dm_ao):
+        n = dm_ao.shape[0]
+        iu = torch.tril_indices(n, n)
+        d = dm_ao + dm_ao.T
+        d = d[iu[0], iu[1]]
+        d[iu[0] == iu[1]] *= 0.5
+        return d, iu
+
+    def get_elrep(self, dm):
+        if self.eri_mode == "dense":
+            mat = torch.einsum("ij,ijkl->kl", dm, self.el_mat)
+        else:  # packed-s4 variant (same numbers, different storage)
+            dao = self.unconvert_dm(dm)
+            d, iu = self._pack_dm(dao)
+            jp = self.el_s4 @ d
+            n = dao.shape[0]
+            J = torch.zeros((n, n), dtype=dm.dtype)
+            J[iu[0], iu[1]] = jp
+            J = J + J.T - torch.diag(torch.diag(J))
+            mat = self.convert2(J)
+        return (mat + mat.T) * 0.5
+
+    def get_exchange(self, dm):
+        """returns -K/2 (hcgto.py:234)"""
+        assert self.eri_mode == "dense"
+        mat = -0.5 * torch.einsum("il,ijkl->ijk", dm, self.el_mat).sum(dim=-3)
+        return (mat + mat.T) * 0.5
+
+    def dm2densinfo(self, dm):
+        dmdmt = (dm + dm.T) * 0.5
+        dmdmt = self.unconvert_dm(dmdmt)
+        ngrid = self.basis.shape[0]
+        dens = torch.empty(ngrid, dtype=torch.float64)
+        gdens = torch.empty((3, ngrid), dtype=torch.float64) if self.xcfamily >= 2 else None
+        maxnumel = CHUNK_MEMORY // 8
+        for basis, ioff, iend in chunkify(self.basis, 0, maxnumel):
+            dmao = basis @ dmdmt
+            dens[ioff:iend] = torch.einsum("ri,ri->r", dmao, basis)
+            if gdens is not None:
+                for d in range(3):
+                    gdens[d, ioff:iend] = torch.einsum("ri,ri->r", dmao, self.grad_basis[d, ioff:iend]) * 2
+        return dens, gdens
+
+    def vxc_from_potinfo(self, vrho, vgrad):
+        nao = self.basis.shape[-1]
+        mat = torch.zeros((nao, nao), dtype=torch.float64)
+        maxnumel = CHUNK_MEMORY // 8
+        for basis, ioff, iend in chunkify(self.basis, 0, maxnumel):
+            vb = vrho[ioff:iend].unsqueeze(-1) * basis
+            if vgrad is not None:
+                vg = vgrad[:, ioff:iend] * 2
+                for d in range(3):
+                    vb += vg[d].unsqueeze(-1) * self.grad_basis[d, ioff:iend]
+            mat += self.basis_dvolume[ioff:iend].T @ vb
+        mat = self.convert2(mat)
+        return (mat + mat.T) * 0.5
+
+    def get_vxc(self, dm):
+        dens, gdens = self.dm2densinfo(dm)
+        vr, vg = self.xc.get_vxc(dens.numpy(), None if gdens is None else gdens.numpy())
+        return self.vxc_from_potinfo(torch.as_tensor(vr), None if vg is None else torch.as_tensor(vg))
+
+    # ---- energies ----
+    def get_e_hcore(self, dm):
+        return torch.einsum("ij,ji->", self.kinnucl_mat, dm)
+
+    def get_e_elrep(self, dm):
+        return 0.5 * torch.einsum("ij,ji->", self.get_elrep(dm), dm)
+
+    def get_e_exchange(self, dm):
+        return 0.5 * torch.einsum("ij,ji->", self.get_exchange(dm), dm)
+
+    def get_e_xc(self, dm):
+        dens, gdens = self.dm2densinfo(dm)
+        e = self.xc.get_edensityxc(dens.numpy(), None if gdens is None else gdens.numpy())
+        return torch.sum(self.dvolume * torch.as_tensor(e))
+
+    def ao_orb2dm(self, orb, orb_weight):
+        return orb @ (orb * orb_weight.unsqueeze(-2)).T
+
+
+def nuclei_energy(zs, pos):
+    """dqc/system/mol.py:252-260"""
+    e = 0.0
+    for i in range(len(zs)):
+        for j in range(i):
+            e += zs[i] * zs[j] / np.linalg.norm(pos[i] - pos[j])
+    return float(e)
+
+
+class Engine:
+    """RHF (xc=None) / RKS engine: dm2scp, scp2dm, dm2energy as in hf.py / ks.py."""
+
+    def __init__(self, tables, xc=None, grid="sg3", hf=None, eri_mode="dense"):
+        self.t = tables
+        self.is_hf = (xc is None) if hf is None else hf
+        self.xc = None if self.is_hf else (oxc.get_xc(xc) if isinstance(xc, str) else xc)
+        self.h = Hamilton(tables, eri_mode=eri_mode).build()
+        if not self.is_hf:
+            rgrid, dvol = ogrid.get_predefined_grid(grid, tables.atomzs, tables.atompos)
+            self.h.setup_grid(rgrid, dvol, self.xc)
+        nel = int(round(float(np.sum(tables.atomzs))))
+        assert nel % 2 == 0, "restricted closed-shell only"
+        self.norb = nel // 2
+        self.orb_weight = torch.full((self.norb,), 2.0, dtype=torch.float64)
+        self.enuc = nuclei_energy(tables.atomzs, tables.atompos)
+
+    def dm2scp(self, dm):
+        F = self.h.kinnucl_mat + self.h.get_elrep(dm)
+        if self.is_hf:
+            return F + self.h.get_exchange(dm)
+        return F + self.h.get_vxc(dm)
+
+    def scp2dm(self, scp):
+        fock = (scp + scp.T) * 0.5
+        e, C = torch.linalg.eigh(fock)  # overlap is the identity in the orthogonalised basis
+        return self.h.ao_orb2dm(C[:, :self.norb], self.orb_weight)
+
+    def dm2energy(self, dm):
+        e = self.h.get_e_hcore(dm) + self.h.get_e_elrep(dm)
+        e = e + (self.h.get_e_exchange(dm) if self.is_hf else self.h.get_e_xc(dm))
+        return float(e) + self.enuc
+
+    def energy_parts(self, dm):
+        p = {"e_core": float(self.h.get_e_hcore(dm)), "e_elrep": float(self.h.get_e_elrep(dm)),
+             "e_nuc": self.enuc}
+        if self.is_hf:
+            p["e_exch"] = float(self.h.get_e_exchange(dm))
+        else:
+            p["e_xc"] = float(self.h.get_e_xc(dm))
+        p["e_tot"] = sum(p.values())
+        return p
+
+    def run(self, maxiter=100, tol=1e-9, dm0=None):
+        """SCF_QCCalc.run data flow: '1e' guess, then the fixed point F = dm2scp(scp2dm(F)).
+        Mixer: Pulay DIIS on F_out - F_in (reference: Broyden-1; only the fixed point is compared)."""
+        if dm0 is None:
+            scp = self.dm2scp(torch.zeros((self.h.nao, self.h.nao), dtype=torch.float64))
+            dm = self.scp2dm(scp)
+        else:
+            dm = dm0
+        scp = self.dm2scp(dm)
+        ys, rs = [], []
+        self.niter = 0
+        for it in range(maxiter):
+            fy = self.dm2scp(self.scp2dm(scp))
+            self.niter = it + 1
+            r = fy - scp
+            if r.abs().max() < tol:
+                scp = fy
+                break
+            ys.append(fy.reshape(-1))
+            rs.append(r.reshape(-1))
+            if len(ys) > 10:
+                ys.pop(0)
+                rs.pop(0)
+            n = len(ys)
+            B = -torch.ones((n + 1, n + 1), dtype=torch.float64)
+            B[n, n] = 0
+            R = torch.stack(rs)
+            B[:n, :n] = R @ R.T
+            rhs = torch.zeros(n + 1, dtype=torch.float64)
+            rhs[n] = -1
+            c = torch.linalg.lstsq(B, rhs.unsqueeze(-1)).solution[:n, 0]
+            scp = (c.unsqueeze(0) @ torch.stack(ys)).reshape(fy.shape)
+        self.dm = self.scp2dm(scp)
+        return self.dm2energy(self.dm)
+
+
+def run_scf(moldesc, basis, xc=None, grid="sg3", **kw):
+    t = obasis.make_tables(moldesc, basis)
+    eng = Engine(t, xc=xc, grid=grid)
+    e = eng.run(**kw)
+    return e, eng

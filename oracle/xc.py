@@ -1,0 +1,173 @@
+"""oracle/xc.py -- TEST INFRASTRUCTURE ONLY.
+
+numpy restatement of the exchange-correlation functionals the reference obtains
+from the un-vendored dependency `pylibxc2>=6.0.0` (libxc; /root/reference/setup.py:58)
+through dqc/xc/libxc.py:19-115 and dqc/xc/libxc_wrapper.py:380-413:
+
+  * unpolarised inputs rho (n,), sigma = |grad rho|^2 (n,)   (libxc.py:124-186)
+  * deriv=0 returns zk*rho  = energy per unit volume          (libxc_wrapper.py:400-411)
+  * deriv=1 returns vrho, vsigma; the potential handed to the Hamiltonian is
+    ValGrad(value=vrho, grad=2*vsigma*grad rho)               (libxc.py:188-242)
+  * "a + b" / "c * a" combinators                             (dqc/xc/base_xc.py:197-268,
+                                                               dqc/api/getxc.py:38-59)
+
+Functional definitions:
+  lda_x     : closed form in dqc/test/test_xc.py:390-391, 416-417
+  lda_c_pw  : PW92, constants of dqc/test/test_xc.py:393-414 (unpolarised branch, xi = 0)
+  gga_x_pbe : closed form of dqc/test/test_xc.py:419-425 with libxc's kappa = 0.8040,
+              mu = 0.2195149727645171 (the test's mu = 0.21951 agrees to allclose)
+  gga_c_pbe : no formula in the reference; Perdew-Burke-Ernzerhof PRL 77, 3865 (1996)
+              with libxc's beta = 0.06672455060314922, gamma = (1-ln2)/pi^2 and the
+              "modified" PW92 constants (a = gamma) for its LDA part  -- PARITY UNPINNED
+              against an executed libxc.
+
+Densities at or below DENS_THRESHOLD contribute zero (libxc dens_threshold behaviour).
+"""
+import re
+
+import numpy as np
+
+DENS_THRESHOLD = 1e-15
+
+_PW_ALPHA1 = 0.21370
+_PW_BETA = (7.5957, 3.5876, 1.6382, 0.49294)
+_PW_A = 0.0310907
+_PW_A_MOD = 0.0310906908696548950  # (1 - ln 2)/pi^2, used by lda_c_pw_mod inside gga_c_pbe
+_PBE_KAPPA = 0.8040
+_PBE_MU = 0.2195149727645171
+_PBE_BETA = 0.06672455060314922
+_PBE_GAMMA = (1.0 - np.log(2.0)) / np.pi ** 2
+
+
+def _safe(rho):
+    mask = rho > DENS_THRESHOLD
+    return mask, np.where(mask, rho, 1.0)
+
+
+# ---- each functional returns (e, vrho, vsigma) ; e = energy per unit volume ----
+def lda_x(rho, sigma=None):
+    mask, r = _safe(rho)
+    c = (3.0 / np.pi) ** (1.0 / 3)
+    e = -0.75 * c * r ** (4.0 / 3)
+    v = -c * r ** (1.0 / 3)
+    z = np.zeros_like(rho)
+    return np.where(mask, e, 0.0), np.where(mask, v, 0.0), z
+
+
+def _pw92_eps(rs, a):
+    """eps_c(rs) (unpolarised) and d eps / d rs"""
+    b1, b2, b3, b4 = _PW_BETA
+    sq = np.sqrt(rs)
+    q0 = -2.0 * a * (1.0 + _PW_ALPHA1 * rs)
+    q1 = 2.0 * a * (b1 * sq + b2 * rs + b3 * rs * sq + b4 * rs * rs)
+    q1p = a * (b1 / sq + 2.0 * b2 + 3.0 * b3 * sq + 4.0 * b4 * rs)
+    lg = np.log1p(1.0 / q1)
+    eps = q0 * lg
+    deps = -2.0 * a * _PW_ALPHA1 * lg - q0 * q1p / (q1 * q1 + q1)
+    return eps, deps
+
+
+def lda_c_pw(rho, sigma=None, a=_PW_A):
+    mask, r = _safe(rho)
+    rs = (3.0 / (4.0 * np.pi * r)) ** (1.0 / 3)
+    eps, deps = _pw92_eps(rs, a)
+    e = r * eps
+    v = eps - rs / 3.0 * deps
+    z = np.zeros_like(rho)
+    return np.where(mask, e, 0.0), np.where(mask, v, 0.0), z
+
+
+def gga_x_pbe(rho, sigma):
+    mask, r = _safe(rho)
+    A = -0.75 * (3.0 / np.pi) ** (1.0 / 3)
+    c2 = 4.0 * (3.0 * np.pi ** 2) ** (2.0 / 3)
+    r13 = r ** (1.0 / 3)
+    r43 = r * r13
+    s2 = sigma / (c2 * r43 * r43)
+    den = 1.0 + _PBE_MU * s2 / _PBE_KAPPA
+    F = 1.0 + _PBE_KAPPA - _PBE_KAPPA / den
+    Fp = _PBE_MU / (den * den)  # dF/d(s2)
+    e = A * r43 * F
+    vrho = (4.0 / 3.0) * A * r13 * F + A * r43 * Fp * (-8.0 / 3.0) * s2 / r
+    vsigma = A * r43 * Fp / (c2 * r43 * r43)
+    return np.where(mask, e, 0.0), np.where(mask, vrho, 0.0), np.where(mask, vsigma, 0.0)
+
+
+def gga_c_pbe(rho, sigma):
+    mask, r = _safe(rho)
+    g, b = _PBE_GAMMA, _PBE_BETA
+    rs = (3.0 / (4.0 * np.pi * r)) ** (1.0 / 3)
+    eps, deps = _pw92_eps(rs, _PW_A_MOD)
+    deps_drho = deps * (-rs / (3.0 * r))
+    kf = (3.0 * np.pi ** 2 * r) ** (1.0 / 3)
+    ks2 = 4.0 * kf / np.pi
+    # t^2 = sigma / (4 ks^2 rho^2) ;  d t2/d rho = -(7/3) t2 / rho
+    t2 = sigma / (4.0 * ks2 * r * r)
+    dt2_drho = -(7.0 / 3.0) * t2 / r
+    dt2_dsig = 1.0 / (4.0 * ks2 * r * r)
+    ex = np.expm1(-eps / g)  # exp(-eps/gamma) - 1
+    Ac = (b / g) / ex
+    dA_deps = (b / g) * (ex + 1.0) / (g * ex * ex)
+    At2 = Ac * t2
+    num = 1.0 + At2
+    den = 1.0 + At2 + At2 * At2
+    X = (b / g) * t2 * num / den
+    H = g * np.log1p(X)
+    # partials of X wrt t2 and A
+    dX_dt2 = (b / g) * (num / den + t2 * (Ac * den - num * (Ac + 2.0 * Ac * At2)) / (den * den))
+    dX_dA = (b / g) * t2 * (t2 * den - num * (t2 + 2.0 * At2 * t2)) / (den * den)
+    dH_dX = g / (1.0 + X)
+    dH_drho = dH_dX * (dX_dt2 * dt2_drho + dX_dA * dA_deps * deps_drho)
+    dH_dsig = dH_dX * dX_dt2 * dt2_dsig
+    e = r * (eps + H)
+    vrho = (eps + H) + r * (deps_drho + dH_drho)
+    vsigma = r * dH_dsig
+    return np.where(mask, e, 0.0), np.where(mask, vrho, 0.0), np.where(mask, vsigma, 0.0)
+
+
+_FUNCS = {"lda_x": (1, lda_x), "lda_c_pw": (1, lda_c_pw),
+          "gga_x_pbe": (2, gga_x_pbe), "gga_c_pbe": (2, gga_c_pbe)}
+
+
+class XC:
+    """Linear combination of libxc-named functionals; family 1 (LDA) / 2 (GGA)
+    (dqc/xc/base_xc.py:13-18)."""
+
+    def __init__(self, terms):
+        self.terms = terms  # list of (coef, name)
+        self.family = max([1] + [_FUNCS[n][0] for _, n in terms])
+
+    def compute(self, rho, sigma):
+        e = np.zeros_like(rho)
+        vr = np.zeros_like(rho)
+        vs = np.zeros_like(rho)
+        for c, n in self.terms:
+            ee, vv, ss = _FUNCS[n][1](rho, sigma)
+            e += c * ee
+            vr += c * vv
+            vs += c * ss
+        return e, vr, vs
+
+    def get_edensityxc(self, rho, grad=None):
+        sigma = None if grad is None else np.einsum("dr,dr->r", grad, grad)
+        return self.compute(rho, sigma)[0]
+
+    def get_vxc(self, rho, grad=None):
+        """returns (vrho, vgrad) with vgrad = 2*vsigma*grad (libxc.py:239)"""
+        sigma = None if grad is None else np.einsum("dr,dr->r", grad, grad)
+        _, vr, vs = self.compute(rho, sigma)
+        if self.family == 1 or grad is None:
+            return vr, None
+        return vr, 2.0 * vs[None, :] * grad
+
+
+def get_xc(xcstr):
+    """'lda_x + gga_c_pbe', '0.5*lda_x' ... (dqc/api/getxc.py:38-59); None/'' -> zero functional"""
+    terms = []
+    if xcstr:
+        for tok in xcstr.replace(" ", "").split("+"):
+            m = re.fullmatch(r"(?:([0-9.eE+-]+)\*)?([a-z0-9_]+)", tok)
+            if m is None or m.group(2) not in _FUNCS:
+                raise ValueError("unsupported xc term: %s" % tok)
+            terms.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2)))
+    return XC(terms)

@@ -1,0 +1,157 @@
+"""tools/make_golden.py -- BUILD-CONTAINER ONLY.  Generates tests/golden/*.npz, *.json.
+
+Golden vectors are produced by the REFERENCE'S OWN Python (dqc.Mol, HamiltonCGTO, _HFEngine,
+_KSEngine, SCF_QCCalc, dqc.grid) imported from /root/reference through tools/ref_harness.py, with the
+oracle's C restatement of libcint/libcgto/libxc plugged in at the native seams.
+The fixtures are *data*: inputs and expected outputs.  All matrices are stored in the AO basis
+(libcint AO order), which is invariant to the eigenvector conventions of the orthogonaliser:
+    dm_orth = X^T S dm_ao S X ,   M_ao = S X M_orth X^T S .
+
+Usage:  python tools/make_golden.py [case ...]     (default: all small cases)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+import dqc  # noqa: E402
+from dqc.qccalc.hf import _HFEngine  # noqa: E402,F401
+from oracle import natives, basis as obasis  # noqa: E402
+
+GOLD = os.path.join(HERE, "..", "tests", "golden")
+ANG = 1.0 / 0.52917721092
+
+
+def benzene():
+    rcc, rch = 1.397 * ANG, 1.084 * ANG
+    zs, pos = [], []
+    for k in range(6):
+        a = np.pi / 3 * k
+        zs.append(6)
+        pos.append([rcc * np.cos(a), rcc * np.sin(a), 0.0])
+    for k in range(6):
+        a = np.pi / 3 * k
+        zs.append(1)
+        pos.append([(rcc + rch) * np.cos(a), (rcc + rch) * np.sin(a), 0.0])
+    return zs, pos
+
+
+H2O = ([8, 1, 1], [[0, 0, 0.2156], [0, 1.4749, -0.8625], [0, -1.4749, -0.8625]])  # test_properties.py:21-27
+
+CASES = {
+    # name: (moldesc, basis, xc (None = RHF), grid)
+    "h2o_sto3g_rhf": (H2O, "sto-3g", None, None),
+    "h2o_ccpvdz_rhf": (H2O, "cc-pvdz", None, None),
+    "h2o_ccpvdz_lda_sg3": (H2O, "cc-pvdz", "lda_x+lda_c_pw", "sg3"),
+    "h2o_ccpvdz_pbe_sg3": (H2O, "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg3"),
+    "ch4_ccpvtz_pbe_sg2": (([6, 1, 1, 1, 1], [[0, 0, 0], [1.186, 1.186, 1.186], [-1.186, -1.186, 1.186],
+                                               [-1.186, 1.186, -1.186], [1.186, -1.186, -1.186]]),
+                           "cc-pvtz", "gga_x_pbe+gga_c_pbe", "sg2"),
+    "benzene_ccpvdz_rhf": (benzene(), "cc-pvdz", None, None),
+    "benzene_ccpvdz_lda_sg3": (benzene(), "cc-pvdz", "lda_x+lda_c_pw", "sg3"),
+}
+SMALL = ["h2o_sto3g_rhf", "h2o_ccpvdz_rhf", "h2o_ccpvdz_lda_sg3", "h2o_ccpvdz_pbe_sg3", "ch4_ccpvtz_pbe_sg2"]
+
+
+def seeded_dm_ao(nao, nel, S, seed):
+    """symmetric PSD pseudo-density with tr(D S) = nel"""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((nao, max(nel // 2, 1)))
+    D = A @ A.T
+    D *= nel / np.trace(D @ S)
+    return D
+
+
+def run_case(name):
+    moldesc, basis, xc, grid = CASES[name]
+    t0 = time.time()
+    kw = {} if grid is None else {"grid": grid}
+    mol = rh.ref_mol(moldesc, basis, **kw)
+    qc = dqc.HF(mol) if xc is None else dqc.KS(mol, xc=xc)
+    qc.run()
+    eng = qc._engine if hasattr(qc, "_engine") else qc.get_system()  # SCF_QCCalc keeps ._engine
+    e_tot = float(qc.energy())
+    dm = qc.aodm()
+    hamilt = mol.get_hamiltonian()
+    X = hamilt._orthozer._orthozer.detach()
+    tabs = obasis.make_tables(moldesc, basis)
+    S = torch.as_tensor(natives.int1e("ovlp", tabs))
+    SX = S @ X
+    to_ao = lambda m: (SX @ m @ SX.T).numpy()  # noqa: E731
+    dm_to_ao = lambda d: (X @ d @ X.T).numpy()  # noqa: E731  (unconvert_dm)
+    out = {
+        "atomzs": np.array(moldesc[0]), "atompos": np.array(moldesc[1], dtype=float),
+        "e_tot": e_tot,
+        "e_core": float(hamilt.get_e_hcore(dm)), "e_elrep": float(hamilt.get_e_elrep(dm)),
+        "e_nuc": float(mol.get_nuclei_energy()),
+        "dm_conv_ao": dm_to_ao(dm),
+        "hcore_ao": to_ao(hamilt.get_kinnucl().fullmatrix()),
+        "fock_conv_ao": to_ao(eng.dm2scp(dm)),
+        "nao": X.shape[0],
+    }
+    if xc is None:
+        out["e_exch"] = float(hamilt.get_e_exchange(dm))
+    else:
+        out["e_xc"] = float(hamilt.get_e_xc(dm))
+        g = mol.get_grid()
+        rg, dv = g.get_rgrid().numpy(), g.get_dvolume().numpy()
+        out["ngrid"] = rg.shape[0]
+        out["grid_checksum"] = np.array([dv.sum(), (dv * rg[:, 0]).sum(), (dv * (rg ** 2).sum(-1)).sum()])
+    # probe set: seeded AO densities -> J, -K/2, Vxc, e_xc, rho samples (all AO basis)
+    nel = int(sum(moldesc[0]))
+    XtS = SX.T  # X^T S
+    for k in range(3):
+        Dao = seeded_dm_ao(tabs.nao, nel, S.numpy(), 1234 + k)
+        dmo = XtS @ torch.as_tensor(Dao) @ XtS.T
+        out["probe%d_dm_ao" % k] = Dao
+        out["probe%d_J_ao" % k] = to_ao(hamilt.get_elrep(dmo).fullmatrix())
+        if xc is None:
+            out["probe%d_Khalf_ao" % k] = to_ao(hamilt.get_exchange(dmo).fullmatrix())
+        else:
+            out["probe%d_vxc_ao" % k] = to_ao(hamilt.get_vxc(dmo).fullmatrix())
+            out["probe%d_exc" % k] = float(hamilt.get_e_xc(dmo))
+            dens = hamilt._dm2densinfo(dmo)
+            idx = np.linspace(0, out["ngrid"] - 1, 64).astype(int)
+            out["probe_idx"] = idx
+            out["probe%d_rho" % k] = dens.value.numpy()[idx]
+            if dens.grad is not None:
+                out["probe%d_grho" % k] = dens.grad.numpy()[:, idx]
+    np.savez_compressed(os.path.join(GOLD, "ref_%s.npz" % name), **out)
+    print("%-28s E = %.10f  (%.1f s)" % (name, e_tot, time.time() - t0), flush=True)
+
+
+def write_kats():
+    """literal known answers held by the reference's own tests"""
+    kat = {
+        "_source": "literals copied from the reference test-suite (values only)",
+        "rhf_321g": {"tol_rel": 1e-7, "src": "dqc/test/test_hf.py:18-32,47,51",
+                     "cases": [["H", 1.0, -1.07195346], ["Li", 5.0, -14.7683688], ["N", 2.0, -108.298897],
+                               ["F", 2.5, -197.636373], ["C O", 2.0, -112.078732]]},
+        "rks_6311ppgss": {"tol_abs": 1.3e-3, "src": "dqc/test/test_ks.py:40-63,89-111",
+                          "lda_x": [["H", 1.0, -0.979143262], ["Li", 5.0, -14.3927863482],
+                                    ["N", 2.0, -107.726124018], ["F", 2.5, -197.005308558],
+                                    ["C O", 2.0, -111.490687029]],
+                          "gga_x_pbe": [["H", 1.0, -1.0682173104], ["Li", 5.0, -14.8282511868],
+                                        ["N", 2.0, -108.980200151], ["F", 2.5, -198.772971537],
+                                        ["C O", 2.0, -112.754279785]]},
+        "h2_density": {"src": "dqc/test/test_hamilton.py:95-142", "atoms_z": 0.8, "basis": "3-21G",
+                       "z": [0.0, 0.4, 0.8], "rho": [0.18742819, 0.23469519, 0.30250292]},
+        "grid_gauss_integral": {"src": "dqc/test/test_grid.py:16-78", "value": 15.7496099457224,
+                                "sg3_points": {"1": 16710, "6": 17674, "7": 18286, "8": 18946}},
+        "nuclei_energy": {"src": "dqc/test/test_system.py:61-72", "z": [1, 4], "dist": 1.5, "value": 4 / 1.5},
+    }
+    with open(os.path.join(GOLD, "reference_literals.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    write_kats()
+    for c in (sys.argv[1:] or SMALL):
+        run_case(c)
