@@ -1,0 +1,185 @@
+// common.hpp -- shared host/device helpers of libdqc_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dqc_amd.h"
+
+#define DQC_LMAX 4          // highest shell angular momentum accepted (s,p,d,f,g)
+#define DQC_TILE_B 8        // AO block edge of the ERI tile storage
+#define DQC_TILE_SZ 4096    // B^4 doubles per tile
+
+namespace dqc {
+
+void set_error(const std::string &msg);
+
+#define DQC_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            dqc::set_error(std::string(#call) + ": " + hipGetErrorString(e_));             \
+            return DQC_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define DQC_CHECK_LAUNCH() DQC_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------
+// Host-side view of the libcint tables (reference: dqc/hamilton/intor/lcintwrap.py:37-86)
+// ---------------------------------------------------------------------------------------
+struct HostShell {
+    int l, nprim, atom, ao_off, prim_off;  // prim_off: offset into the flat exps/coefs arrays
+    double r[3];
+};
+
+struct Basis {
+    std::vector<HostShell> shells;
+    std::vector<double> exps, coefs;  // flat per-primitive arrays (coefs already radially normalised)
+    int nao = 0, natm = 0;
+    std::vector<double> atom_xyz, atom_z;
+};
+
+// returns 0 or DQC_EINVAL
+int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, const double *env,
+                int nenv, const double *zs);
+
+// device mirror of the shell table (SoA, uploaded once per call)
+struct DevShells {
+    int *l = nullptr, *nprim = nullptr, *ao_off = nullptr, *prim_off = nullptr;
+    double *xyz = nullptr;  // (nsh,3)
+    double *exps = nullptr, *coefs = nullptr;
+    int nsh = 0;
+};
+
+// simple RAII-less device allocation list freed at the end of a (synchronous) setup call
+struct DevPool {
+    std::vector<void *> ptrs;
+    template <typename T>
+    int upload(T **dst, const std::vector<T> &src, hipStream_t st) {
+        size_t bytes = src.size() * sizeof(T);
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return DQC_ENOMEM;
+        ptrs.push_back(p);
+        if (bytes && hipMemcpyAsync(p, src.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            return DQC_EHIP;
+        *dst = (T *)p;
+        return 0;
+    }
+    template <typename T>
+    int alloc(T **dst, size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, n * sizeof(T) + 8) != hipSuccess) return DQC_ENOMEM;
+        ptrs.push_back(p);
+        *dst = (T *)p;
+        return 0;
+    }
+    void release() {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+    ~DevPool() { release(); }
+};
+
+int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st);
+
+inline int ncart(int l) { return (l + 1) * (l + 2) / 2; }
+
+}  // namespace dqc
+
+// ---------------------------------------------------------------------------------------
+// device-side tables
+// ---------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+#define DQC_DEV __device__ __forceinline__
+
+// real solid harmonics (generated, libcint convention)
+#define C2S_QUAL __device__ const
+#include "cart2sph.inc"
+#undef C2S_QUAL
+
+#define RYS_QUAL __device__ const
+#include "rys_tables.inc"
+#undef RYS_QUAL
+
+namespace dqc {
+
+template <int L>
+struct Cart {
+    static constexpr int n = (L + 1) * (L + 2) / 2;
+};
+
+// powers (lx,ly,lz) of Cartesian component c of shell l (libcint order), computed arithmetically
+DQC_DEV void cart_pow(int l, int c, int &lx, int &ly, int &lz) {
+    // rows: lx = l, l-1, ... ; row with lx has (l-lx+1) entries
+    int row = 0, acc = 0;
+    while (acc + row + 1 <= c) { acc += row + 1; row++; }
+    lx = l - row;
+    int k = c - acc;
+    ly = row - k;
+    lz = k;
+}
+
+// Rys roots u[r] (= t^2) and weights w[r] for given X = rho*|PQ|^2
+template <int N>
+DQC_DEV void rys_roots(double X, double *u, double *w) {
+    constexpr double XMAX = 35.0 + 5.0 * N;
+    if (X >= XMAX) {
+        double ix = 1.0 / X, isx = sqrt(ix);
+#pragma unroll
+        for (int r = 0; r < N; r++) {
+            u[r] = RYS_HERM_X2[N][r] * ix;
+            w[r] = RYS_HERM_W[N][r] * isx;
+        }
+        return;
+    }
+    int it = (int)(X * (1.0 / 2.5));
+    double x = (X - (it * 2.5 + 1.25)) * (1.0 / 1.25);
+    const double *tab = RYS_TAB + RYS_OFF[N - 1] + (size_t)it * (2 * N) * (RYS_DEG + 1);
+    double x2 = 2.0 * x;
+#pragma unroll
+    for (int q = 0; q < 2 * N; q++) {
+        const double *c = tab + q * (RYS_DEG + 1);
+        // Clenshaw
+        double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int k = RYS_DEG; k >= 1; k--) {
+            double t = x2 * b1 - b2 + c[k];
+            b2 = b1;
+            b1 = t;
+        }
+        double v = x * b1 - b2 + c[0];
+        if (q < N) u[q] = v; else w[q - N] = v;
+    }
+}
+
+// single root/weight r (runtime) -- used when different lanes need different roots
+template <int N>
+DQC_DEV void rys_root1(double X, int r, double &u, double &w) {
+    constexpr double XMAX = 35.0 + 5.0 * N;
+    if (X >= XMAX) {
+        double ix = 1.0 / X;
+        u = RYS_HERM_X2[N][r] * ix;
+        w = RYS_HERM_W[N][r] * sqrt(ix);
+        return;
+    }
+    int it = (int)(X * (1.0 / 2.5));
+    double x = (X - (it * 2.5 + 1.25)) * (1.0 / 1.25);
+    const double *cu = RYS_TAB + RYS_OFF[N - 1] + ((size_t)it * (2 * N) + r) * (RYS_DEG + 1);
+    const double *cw = cu + N * (RYS_DEG + 1);
+    double x2 = 2.0 * x, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int k = RYS_DEG; k >= 1; k--) {
+        double t = x2 * a1 - a2 + cu[k]; a2 = a1; a1 = t;
+        double s = x2 * b1 - b2 + cw[k]; b2 = b1; b1 = s;
+    }
+    u = x * a1 - a2 + cu[0];
+    w = x * b1 - b2 + cw[0];
+}
+
+}  // namespace dqc
+#endif

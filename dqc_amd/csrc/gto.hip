@@ -1,0 +1,126 @@
+// gto.hip -- AO values (and gradients) on the grid.
+// Replaces GTOval_sph / GTOval_ip_sph (reference call site dqc/hamilton/intor/gtoeval.py:196-239)
+// with the (ngrid, nao) "to_transpose" layout HamiltonCGTO.setup_grid caches (hcgto.py:168, :179).
+// No screening, like the reference (non0tab all ones, gtoeval.py:211-212).
+//
+// Mapping: one wave per 64 points, one lane per grid point, shells looped uniformly (shell data
+// comes through scalar loads); a 64-point x 16-column LDS tile turns the per-lane row writes into 128-byte
+// row segments before they go to HBM.
+#include "common.hpp"
+
+namespace dqc {
+
+constexpr int GTO_CW = 16;  // columns staged per flush
+
+template <int DERIV>
+__global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, const double *__restrict__ coords,
+                                                       int ngrid, int nao, int ld, DevShells sh) {
+    constexpr int NC = DERIV ? 4 : 1;
+    __shared__ double tile[1][NC][64][GTO_CW + 1];
+    constexpr int wave = 0;
+    const int lane = threadIdx.x;
+    const int g0 = blockIdx.x * 64;
+    if (g0 >= ngrid) return;
+    const int g = min(g0 + lane, ngrid - 1);
+    const double px = coords[g * 3], py = coords[g * 3 + 1], pz = coords[g * 3 + 2];
+    const size_t cstride = (size_t)ngrid * ld;
+
+    int col0 = 0;     // first AO column held in the tile
+    int nfill = 0;    // columns filled
+    auto flush = [&](int ncols) {
+        // tile[wave][c][p][j] -> out[c][g0+p][col0+j]; lanes sweep (p, j) with j fastest
+        __syncthreads();
+        for (int c = 0; c < NC; c++)
+            for (int e = lane; e < 64 * GTO_CW; e += 64) {
+                int p = e / GTO_CW, j = e % GTO_CW;
+                if (j < ncols && g0 + p < ngrid)
+                    out[c * cstride + (size_t)(g0 + p) * ld + col0 + j] = tile[wave][c][p][j];
+            }
+        __syncthreads();
+    };
+
+    for (int is = 0; is < sh.nsh; is++) {
+        const int l = sh.l[is], np = sh.nprim[is], po = sh.prim_off[is];
+        const double x = px - sh.xyz[is * 3], y = py - sh.xyz[is * 3 + 1], z = pz - sh.xyz[is * 3 + 2];
+        const double r2 = x * x + y * y + z * z;
+        double e0 = 0, e1 = 0;
+        for (int ip = 0; ip < np; ip++) {
+            double a = sh.exps[po + ip];
+            double e = sh.coefs[po + ip] * exp(-a * r2);
+            e0 += e;
+            e1 -= 2.0 * a * e;
+        }
+        double xp[DQC_LMAX + 2], yp[DQC_LMAX + 2], zp[DQC_LMAX + 2];
+        xp[0] = yp[0] = zp[0] = 1.0;
+#pragma unroll
+        for (int k = 1; k <= DQC_LMAX + 1; k++) { xp[k] = xp[k - 1] * x; yp[k] = yp[k - 1] * y; zp[k] = zp[k - 1] * z; }
+        const int nc = (l + 1) * (l + 2) / 2, ns = 2 * l + 1;
+        const double *C = C2S + C2S_OFF[l];
+        for (int m = 0; m < ns; m++) {
+            double v = 0, vx = 0, vy = 0, vz = 0;
+            int c = 0;
+            for (int lx = l; lx >= 0; lx--)
+                for (int ly = l - lx; ly >= 0; ly--, c++) {
+                    double cf = C[m * nc + c];
+                    if (cf == 0.0) continue;  // uniform branch
+                    int lz = l - lx - ly;
+                    double mono = xp[lx] * yp[ly] * zp[lz];
+                    v += cf * mono * e0;
+                    if (DERIV) {
+                        vx += cf * ((lx ? lx * xp[lx - 1] : 0.0) * yp[ly] * zp[lz] * e0 + xp[lx + 1] * yp[ly] * zp[lz] * e1);
+                        vy += cf * ((ly ? ly * yp[ly - 1] : 0.0) * xp[lx] * zp[lz] * e0 + xp[lx] * yp[ly + 1] * zp[lz] * e1);
+                        vz += cf * ((lz ? lz * zp[lz - 1] : 0.0) * xp[lx] * yp[ly] * e0 + xp[lx] * yp[ly] * zp[lz + 1] * e1);
+                    }
+                }
+            tile[wave][0][lane][nfill] = v;
+            if (DERIV) {
+                tile[wave][1][lane][nfill] = vx;
+                tile[wave][2][lane][nfill] = vy;
+                tile[wave][3][lane][nfill] = vz;
+            }
+            nfill++;
+            if (nfill == GTO_CW) {
+                flush(GTO_CW);
+                col0 += GTO_CW;
+                nfill = 0;
+            }
+        }
+    }
+    // zero padding columns nao..ld-1 (ld - nao < 16)
+    while (col0 + nfill < ld) {
+        for (int c = 0; c < NC; c++) tile[wave][c][lane][nfill] = 0.0;
+        nfill++;
+        if (nfill == GTO_CW) {
+            flush(GTO_CW);
+            col0 += GTO_CW;
+            nfill = 0;
+        }
+    }
+    if (nfill) flush(nfill);
+}
+
+}  // namespace dqc
+
+extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
+                            int natm, const int *bas, int nbas, const double *env, int nenv, void *stream) {
+    using namespace dqc;
+    if (deriv != 0 && deriv != 1) { set_error("dqc_eval_gto: deriv must be 0 or 1"); return DQC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    Basis b;
+    int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    DevPool pool;
+    DevShells ds;
+    if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_eval_gto: device upload failed"); return rc; }
+    if (ngrid > 0) {
+        int nblk = (ngrid + 63) / 64;
+        int ld = dqc_padded_nao(b.nao);
+        if (deriv == 0)
+            hipLaunchKernelGGL(eval_gto_kernel<0>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+        else
+            hipLaunchKernelGGL(eval_gto_kernel<1>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+        DQC_CHECK_LAUNCH();
+    }
+    DQC_HIP(hipStreamSynchronize(st));  // the shell tables are freed on return
+    return DQC_OK;
+}

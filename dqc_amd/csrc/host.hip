@@ -1,0 +1,111 @@
+// host.hip -- error handling, table parsing and small utilities of libdqc_amd.so
+#include "common.hpp"
+
+namespace dqc {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, const double *env,
+                int nenv, const double *zs) {
+    // layout per dqc/hamilton/intor/lcintwrap.py:57, 81-83
+    b.shells.clear();
+    b.exps.clear();
+    b.coefs.clear();
+    b.natm = natm;
+    b.atom_xyz.resize((size_t)natm * 3);
+    b.atom_z.resize(natm);
+    for (int ia = 0; ia < natm; ia++) {
+        int p = atm[ia * 6 + 1];
+        if (p < 0 || p + 3 > nenv) { set_error("atm: coordinate pointer outside env"); return DQC_EINVAL; }
+        for (int d = 0; d < 3; d++) b.atom_xyz[ia * 3 + d] = env[p + d];
+        b.atom_z[ia] = zs ? zs[ia] : (double)atm[ia * 6 + 0];
+    }
+    int ao = 0;
+    for (int i = 0; i < nbas; i++) {
+        const int *s = bas + i * 8;
+        HostShell h;
+        h.atom = s[0]; h.l = s[1]; h.nprim = s[2];
+        if (s[3] != 1) { set_error("bas: nctr must be 1 (general contractions are split upstream)"); return DQC_EINVAL; }
+        if (h.l < 0 || h.l > DQC_LMAX) { set_error("bas: angular momentum above g is not supported"); return DQC_EINVAL; }
+        if (h.atom < 0 || h.atom >= natm) { set_error("bas: atom index out of range"); return DQC_EINVAL; }
+        if (s[5] < 0 || s[5] + h.nprim > nenv || s[6] < 0 || s[6] + h.nprim > nenv) {
+            set_error("bas: exponent/coefficient pointer outside env"); return DQC_EINVAL;
+        }
+        h.ao_off = ao;
+        h.prim_off = (int)b.exps.size();
+        for (int d = 0; d < 3; d++) h.r[d] = b.atom_xyz[h.atom * 3 + d];
+        for (int p = 0; p < h.nprim; p++) {
+            b.exps.push_back(env[s[5] + p]);
+            b.coefs.push_back(env[s[6] + p]);
+        }
+        ao += 2 * h.l + 1;
+        b.shells.push_back(h);
+    }
+    b.nao = ao;
+    return 0;
+}
+
+int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st) {
+    int n = (int)b.shells.size();
+    std::vector<int> l(n), np(n), ao(n), po(n);
+    std::vector<double> xyz((size_t)n * 3);
+    for (int i = 0; i < n; i++) {
+        l[i] = b.shells[i].l; np[i] = b.shells[i].nprim; ao[i] = b.shells[i].ao_off; po[i] = b.shells[i].prim_off;
+        for (int k = 0; k < 3; k++) xyz[i * 3 + k] = b.shells[i].r[k];
+    }
+    int rc;
+    if ((rc = pool.upload(&d.l, l, st))) return rc;
+    if ((rc = pool.upload(&d.nprim, np, st))) return rc;
+    if ((rc = pool.upload(&d.ao_off, ao, st))) return rc;
+    if ((rc = pool.upload(&d.prim_off, po, st))) return rc;
+    if ((rc = pool.upload(&d.xyz, xyz, st))) return rc;
+    if ((rc = pool.upload(&d.exps, b.exps, st))) return rc;
+    if ((rc = pool.upload(&d.coefs, b.coefs, st))) return rc;
+    d.nsh = n;
+    return 0;
+}
+
+}  // namespace dqc
+
+extern "C" {
+
+const char *dqc_last_error(void) { return dqc::g_err.c_str(); }
+int dqc_version(void) { return 100; }
+
+int dqc_nao(const int *bas, int nbas) {
+    int n = 0;
+    for (int i = 0; i < nbas; i++) n += 2 * bas[i * 8 + 1] + 1;
+    return n;
+}
+
+int dqc_padded_nao(int nao) { return (nao + 15) / 16 * 16; }
+
+size_t dqc_eri_tile_count(int nao) {
+    size_t nb = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B;
+    size_t np = nb * (nb + 1) / 2;
+    return np * (np + 1) / 2;
+}
+
+// streaming-read probe: sum of a buffer, used by bench.py to measure achievable HBM bandwidth
+__global__ void probe_read_kernel(const double2 *__restrict__ buf, size_t n2, double *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    double s = 0;
+    for (; i < n2; i += stride) {
+        double2 v = buf[i];
+        s += v.x + v.y;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    DQC_HIP(hipMemsetAsync(d_out, 0, sizeof(double), st));
+    hipLaunchKernelGGL(probe_read_kernel, dim3(2048), dim3(256), 0, st, (const double2 *)d_buf, n / 2, d_out);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""ctypes binding of libdqc_amd.so (C ABI declared in include/dqc_amd.h).
+
+The product path has no CPU fallback: if the HIP library cannot be loaded this module raises.
+PyTorch is used only for device memory and streams (tensor.data_ptr(), current stream handle).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "libdqc_amd.so")
+_lib = None
+
+XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130}
+
+
+class DqcAmdError(RuntimeError):
+    pass
+
+
+def libpath():
+    return _LIBPATH
+
+
+def load():
+    """Load libdqc_amd.so; raises (loudly) when it is missing -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise DqcAmdError(
+            "libdqc_amd.so not found at %s -- build it with `python -m dqc_amd.build` "
+            "(hipcc --offload-arch=gfx950); the MI355X path has no CPU fallback" % _LIBPATH)
+    lib = ctypes.CDLL(_LIBPATH)
+    c_int, c_sz, c_vp, c_dp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p
+    ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
+    lib.dqc_last_error.restype = ctypes.c_char_p
+    lib.dqc_version.restype = c_int
+    lib.dqc_nao.argtypes = [ip, c_int]
+    lib.dqc_padded_nao.argtypes = [c_int]
+    lib.dqc_eri_tile_count.argtypes = [c_int]
+    lib.dqc_eri_tile_count.restype = c_sz
+    lib.dqc_jk_work_doubles.argtypes = [c_int]
+    lib.dqc_jk_work_doubles.restype = c_sz
+    tab = [ip, c_int, ip, c_int, dp, c_int]
+    lib.dqc_int1e.argtypes = [c_int, c_dp] + tab + [dp, c_vp]
+    lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
+    lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
+    lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
+    lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
+    lib.dqc_grid_density.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_vp]
+    lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
+    lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
+    lib.dqc_probe_stream_read.argtypes = [c_dp, c_sz, c_dp, c_vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DqcAmdError("%s failed (%d): %s" % (what, rc, load().dqc_last_error().decode()))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "need contiguous float64 device tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Tables:
+    """Host-side libcint-style tables (atm, bas, env) -- see dqc_amd.basis.make_tables."""
+
+    def __init__(self, atm, bas, env):
+        self.atm = np.ascontiguousarray(atm, dtype=np.int32)
+        self.bas = np.ascontiguousarray(bas, dtype=np.int32)
+        self.env = np.ascontiguousarray(env, dtype=np.float64)
+        self.natm, self.nbas = self.atm.shape[0], self.bas.shape[0]
+        self.nao = int(sum(2 * int(b[1]) + 1 for b in self.bas))
+
+    def args(self):
+        ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
+        return (self.atm.ctypes.data_as(ip), self.natm, self.bas.ctypes.data_as(ip), self.nbas,
+                self.env.ctypes.data_as(dp), self.env.shape[0])
+
+
+def padded_nao(nao):
+    return (nao + 15) // 16 * 16
+
+
+def int1e(which, tab, device, zs=None):
+    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao) device tensor"""
+    code = {"ovlp": 0, "kin": 1, "nuc": 2}[which]
+    out = torch.zeros((tab.nao, tab.nao), dtype=torch.float64, device=device)
+    zp = None
+    if zs is not None:
+        zs = np.ascontiguousarray(zs, dtype=np.float64)
+        zp = zs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    _check(load().dqc_int1e(code, _ptr(out), *tab.args(), zp, _stream()), "dqc_int1e")
+    return out
+
+
+def eri_tiles(tab, device):
+    ntile = load().dqc_eri_tile_count(tab.nao)
+    tiles = torch.empty(ntile * 4096, dtype=torch.float64, device=device)
+    _check(load().dqc_eri_fill_tiles(_ptr(tiles), *tab.args(), _stream()), "dqc_eri_fill_tiles")
+    return tiles
+
+
+def eri_dense(tiles, nao):
+    out = torch.empty((nao,) * 4, dtype=torch.float64, device=tiles.device)
+    _check(load().dqc_eri_tiles_to_dense(_ptr(out), _ptr(tiles), nao, _stream()), "dqc_eri_tiles_to_dense")
+    return out
+
+
+def jk_workspace(nao, device):
+    return torch.empty(load().dqc_jk_work_doubles(nao), dtype=torch.float64, device=device)
+
+
+def jk(tiles, dm_ao, work, with_k=True):
+    """dm_ao (nao,nao) -> J, K (K = None if not with_k); AO basis, symmetrised"""
+    nao = dm_ao.shape[-1]
+    J = torch.empty((nao, nao), dtype=torch.float64, device=dm_ao.device)
+    K = torch.empty_like(J) if with_k else None
+    _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
+                                    _stream()), "dqc_jk_from_tiles")
+    return J, K
+
+
+def eval_gto(tab, rgrid, deriv):
+    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0] or (4, ngrid, ld) [deriv 1]"""
+    ngrid = rgrid.shape[0]
+    ld = padded_nao(tab.nao)
+    shape = (ngrid, ld) if deriv == 0 else (4, ngrid, ld)
+    out = torch.empty(shape, dtype=torch.float64, device=rgrid.device)
+    _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), _stream()),
+           "dqc_eval_gto")
+    return out
+
+
+def pad_matrix(m, ld):
+    n = m.shape[-1]
+    if n == ld:
+        return m.contiguous()
+    out = torch.zeros((ld, ld), dtype=m.dtype, device=m.device)
+    out[:n, :n] = m
+    return out
+
+
+def grid_density(ao, nao, dm_pad, gga):
+    """ao (ngrid, ld) or (4, ngrid, ld); dm_pad (ld, ld) -> rho (ngrid,), grho (3,ngrid) or None"""
+    ncomp = 1 if ao.dim() == 2 else ao.shape[0]
+    ngrid = ao.shape[-2]
+    rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
+    grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
+    _check(load().dqc_grid_density(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(dm_pad), _stream()),
+           "dqc_grid_density")
+    return rho, grho
+
+
+def xc_eval(terms, rho, grho, want_e=True, want_v=True):
+    """terms: list of (coef, name).  -> edens, vrho, vgrad(3,n) (None where not requested/applicable)"""
+    n = rho.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    e = torch.empty_like(rho) if want_e else None
+    v = torch.empty_like(rho) if want_v else None
+    vg = torch.empty((3, n), dtype=torch.float64, device=rho.device) if (want_v and grho is not None) else None
+    _check(load().dqc_xc_eval(_ptr(e), _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), n, ids, cfs, len(terms), _stream()),
+           "dqc_xc_eval")
+    return e, v, vg
+
+
+def grid_vxc(ao, nao, w, vrho, vgrad):
+    """-> (ld, ld) symmetric AO-basis Vxc matrix (zero padded)"""
+    ncomp = 1 if ao.dim() == 2 else ao.shape[0]
+    ngrid = ao.shape[-2]
+    ld = ao.shape[-1]
+    vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
+    _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), _stream()),
+           "dqc_grid_vxc")
+    return vm
+
+
+def probe_stream_read(buf):
+    out = torch.zeros(1, dtype=torch.float64, device=buf.device)
+    _check(load().dqc_probe_stream_read(_ptr(buf), buf.numel(), _ptr(out), _stream()), "dqc_probe_stream_read")
+    return out

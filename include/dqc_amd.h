@@ -1,0 +1,111 @@
+/*
+ * dqc_amd.h -- C ABI of libdqc_amd.so: the MI355X (gfx950) native arithmetic behind DQC's
+ * SCF Fock-build hot path.  These entry points are what the reference's ctypes layer for this
+ * path would bind in place of dqclibs (libcint/libcgto) and pylibxc; INTEGRATION.md shows the
+ * reference-side stubs.  All matrices are float64; all integer tables int32.
+ *
+ * Conventions
+ *   - `atm`, `bas`, `env` are HOST pointers to libcint-style tables exactly as
+ *     LibcintWrapper builds them (reference: dqc/hamilton/intor/lcintwrap.py:37-86):
+ *     atm[natm][6] = {Z, ptr_xyz, 1, ptr_zeta, 0, 0}; bas[nbas][8] = {iatom, l, nprim, nctr=1,
+ *     kappa, ptr_exp, ptr_coef, 0}; env = doubles.  nctr must be 1 (the reference splits general
+ *     contractions upstream, dqc/api/loadbasis.py:72-82).  Spherical AOs, libcint order.
+ *   - every other pointer named d_* is a DEVICE pointer (HBM); the caller owns all buffers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work and
+ *     return; they synchronise only where stated.
+ *   - return value: 0 on success, negative DQC_E* on error; dqc_last_error() gives the text.
+ *   - `ld` ("leading dimension") of AO-indexed device matrices is dqc_padded_nao(nao)
+ *     (nao rounded up to a multiple of 16); padding columns/rows are zero.
+ */
+#ifndef DQC_AMD_H
+#define DQC_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQC_OK 0
+#define DQC_EINVAL (-1)   /* bad argument (unsupported l, nctr != 1, ...) */
+#define DQC_EHIP (-2)     /* a HIP runtime call failed */
+#define DQC_ENOMEM (-3)
+
+const char *dqc_last_error(void);
+int dqc_version(void);
+/* number of spherical AOs described by bas  (CINTcgto_spheric summed; lcintwrap.py:376-383) */
+int dqc_nao(const int *bas, int nbas);
+/* leading dimension used for all AO-indexed device matrices */
+int dqc_padded_nao(int nao);
+
+/* ---- one-electron integrals --------------------------------------------------------------
+ * Replaces GTOint2c(int1e_{ovlp,kin,nuc}_sph, ...)  (dqc/hamilton/intor/molintor.py:624-644,
+ * shortcuts :96-112).  which: 0 overlap, 1 kinetic, 2 nuclear attraction (-sum_A Z_A <i|1/r_A|j>).
+ * zs: optional HOST array of natm (possibly fractional) charges, NULL = use atm[:,0]
+ * (molintor.py:105-112).  d_out: (nao, nao) row-major, contiguous (ld = nao). */
+int dqc_int1e(int which, double *d_out, const int *atm, int natm, const int *bas, int nbas,
+              const double *env, int nenv, const double *zs, void *stream);
+
+/* ---- two-electron integrals into blocked-s8 tiles ------------------------------------------
+ * Replaces GTOnr2e_fill_drv(int2e_sph, GTOnr2e_fill_s4, prescreen=NULL, ...) + CSYMM().fills4
+ * (molintor.py:667-688, symmetry.py:40-69).  Instead of the reference's packed (npair,npair)
+ * buffer expanded to a dense nao^4 tensor, the integrals stay on the device in 8-fold-unique
+ * TILE storage: AOs are grouped in blocks of 8; tile (I>=J, K>=L, IJ>=KL) holds the full
+ * 8x8x8x8 sub-tensor g[i][j][k][l] contiguously (4096 doubles).  dqc_eri_tile_count gives the
+ * number of tiles; the buffer must hold 4096*count doubles and is fully overwritten. */
+size_t dqc_eri_tile_count(int nao);
+int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas, int nbas,
+                       const double *env, int nenv, void *stream);
+/* expand the tiles into the reference's dense (nao,nao,nao,nao) tensor (tests / small nao only) */
+int dqc_eri_tiles_to_dense(double *d_dense, const double *d_tiles, int nao, void *stream);
+
+/* ---- J / K contraction ---------------------------------------------------------------------
+ * Replaces einsum("ij,ijkl->kl", dm, el_mat) and einsum("il,ijkl->ijk").sum(-3)
+ * (dqc/hamilton/hcgto.py:209, :234) in the AO basis.  d_dm: (nao,nao) contiguous, symmetric
+ * part is used.  d_J: (nao,nao) <- J_kl = sum_ij D_ij (ij|kl), symmetrised.  d_K may be NULL;
+ * otherwise <- K_jk = sum_il D_il (ij|kl), symmetrised (NOT scaled by -1/2).
+ * d_work: dqc_jk_work_doubles(nao) doubles of scratch. */
+size_t dqc_jk_work_doubles(int nao);
+int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm,
+                      int nao, double *d_work, void *stream);
+
+/* ---- AO values on the grid -----------------------------------------------------------------
+ * Replaces GTOval_sph / GTOval_ip_sph (dqc/hamilton/intor/gtoeval.py:196-239) with the
+ * to_transpose=True layout of HamiltonCGTO.setup_grid (hcgto.py:168, :179).
+ * deriv 0: d_out (ngrid, ld) = phi;  deriv 1: d_out (4, ngrid, ld) = phi, d/dx, d/dy, d/dz.
+ * d_coords: (ngrid, 3).  ld = dqc_padded_nao(nao); padding columns are written as zero. */
+int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
+                 int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);
+
+/* ---- density on the grid  (HamiltonCGTO._dm2densinfo, hcgto.py:371-443) ---------------------
+ * d_ao: (ncomp, ngrid, ld) from dqc_eval_gto, ncomp = 1 (LDA) or 4 (GGA).  d_dm: (ld, ld)
+ * symmetric AO density (zero padded).  d_rho: (ngrid).  d_grho: (3, ngrid) or NULL. */
+int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid,
+                     int nao, const double *d_dm, void *stream);
+
+/* ---- exchange-correlation functional  (pylibxc LibXCFunctional.compute, unpolarised) --------
+ * Replaces dqc/xc/libxc.py:40-85 + libxc_wrapper.py:380-413 for sums of libxc functionals
+ * (dqc/xc/base_xc.py:197-268).  ids: HOST array of nterm functional ids (DQC_XC_*), coefs:
+ * HOST array of nterm weights.  Outputs (any may be NULL): d_edens (n) energy per unit volume
+ * (= zk*rho), d_vrho (n), d_vgrad (3,n) = 2*vsigma*grad rho  (libxc.py:239). */
+#define DQC_XC_LDA_X 1
+#define DQC_XC_LDA_C_PW 12
+#define DQC_XC_GGA_X_PBE 101
+#define DQC_XC_GGA_C_PBE 130
+int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
+                const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
+                void *stream);
+
+/* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
+ * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
+ * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
+int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao,
+                 const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream);
+
+/* ---- micro-benchmarks used by bench.py to price the roofline on the box it runs on ---------- */
+int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
