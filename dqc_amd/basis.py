@@ -1,0 +1,142 @@
+"""Basis-set and geometry input, mirroring the reference's dqc/api/loadbasis.py (Gaussian94 parser,
+one CGTOBasis per contraction column :54-83; file naming :89-122) and dqc/api/parser.py:8-62.
+The tables ship with the package (dqc_amd/data/basis/<normalised name>/<ZZ>.gaussian94) because there
+is no network; the reference downloads the same files from basis_set_exchange (loadbasis.py:124-128)."""
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+from .utils.datastruct import CGTOBasis, AtomCGTOBasis
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "basis")
+periodic_table_atomz = {s: i for i, s in enumerate(
+    ["X", "H", "He", "Li", "Be", "B", "C", "N", "O", "F", "Ne", "Na", "Mg", "Al", "Si", "P", "S", "Cl", "Ar"])}
+_SPDF = {"s": 0, "p": 1, "d": 2, "f": 3, "g": 4, "h": 5, "i": 6}
+
+
+def get_atomz(elmt):
+    if isinstance(elmt, str):
+        return periodic_table_atomz[elmt]
+    if isinstance(elmt, torch.Tensor):
+        return elmt.item()
+    return elmt
+
+
+def _normalize_basisname(name):
+    b = name.lower()
+    for a, r in (("+", "p"), ("*", "s"), ("(", "_"), (")", "_"), (",", "_")):
+        b = b.replace(a, r)
+    return b
+
+
+def loadbasis(cmd: str, dtype=torch.float64, device=torch.device("cpu"), requires_grad=False) -> List[CGTOBasis]:
+    """cmd = "<atomz>:<basis name>", e.g. "8:cc-pVDZ" -> list of normalised CGTOBasis (loadbasis.py:11-83)"""
+    atomz_str, raw = cmd.split(":")
+    atomz = int(atomz_str)
+    fpath = os.path.join(_DATA, _normalize_basisname(raw.strip()), "%02d.gaussian94" % atomz)
+    if not os.path.exists(fpath):
+        raise RuntimeError("The %s basis for atomz %d is not shipped with dqc_amd (%s) and cannot be "
+                           "downloaded here" % (raw, atomz, fpath))
+    with open(fpath) as f:
+        lines = f.read().split("\n")
+    while True:
+        line = lines.pop(0)
+        if line == "" or line.startswith("!"):
+            continue
+        break
+    res = []
+    while lines:
+        line = lines.pop(0)
+        if line.startswith("**"):
+            break
+        desc = line.split()
+        nlines = int(desc[1])
+        if nlines == 0:
+            raise RuntimeError("Zero line on basis %s" % fpath)
+        alphas, coeffsT = [], []
+        for _ in range(nlines):
+            ac = [float(x.replace("D", "E")) for x in lines.pop(0).split()]
+            alphas.append(ac[0])
+            coeffsT.append(ac[1:])
+        coeffs = list(zip(*coeffsT))
+        s = desc[0]
+        if len(s) != len(coeffs):
+            if len(coeffs) % len(s) != 0:
+                raise RuntimeError("Do not know how to read orbital %s with %d coefficient columns" % (s, len(coeffs)))
+            s = s * (len(coeffs) // len(s))
+        alpha = torch.tensor(alphas, dtype=dtype, device=device)
+        for c, ch in zip(coeffs, s.lower()):
+            b = CGTOBasis(angmom=_SPDF[ch], alphas=alpha, coeffs=torch.tensor(c, dtype=dtype, device=device))
+            b.wfnormalize_()
+            res.append(b)
+    return res
+
+
+def parse_moldesc(moldesc, dtype=torch.float64, device=torch.device("cpu")):
+    """'H 1 0 0; H -1 0 0' (Bohr) or (atomzs, atompos) -> (atomzs tensor, atompos (natm,3) tensor)"""
+    if isinstance(moldesc, str):
+        elmts = [[get_atomz(c.strip()) if i == 0 else float(c.strip()) for i, c in enumerate(line.split())]
+                 for line in moldesc.split(";") if line.strip()]
+        atomzs = torch.tensor([line[0] for line in elmts], device=device)
+        atompos = torch.tensor([line[1:] for line in elmts], dtype=dtype, device=device)
+    else:
+        atomzs_raw, atompos_raw = moldesc
+        assert len(atomzs_raw) == len(atompos_raw), "Mismatch length of atomz and atompos"
+        assert len(atomzs_raw) > 0, "Empty atom list"
+        if not isinstance(atomzs_raw, torch.Tensor):
+            atomzs = torch.tensor([get_atomz(at) for at in atomzs_raw], device=device)
+        else:
+            atomzs = atomzs_raw.to(device)
+        atompos = torch.as_tensor(np.asarray(atompos_raw) if not isinstance(atompos_raw, torch.Tensor)
+                                  else atompos_raw, dtype=dtype).to(device)
+    if atomzs.is_floating_point():
+        atomzs = atomzs.to(dtype)
+    return atomzs, atompos
+
+
+def make_atombases(atomzs, atompos, basis) -> List[AtomCGTOBasis]:
+    """basis: str | list of str | list of list of CGTOBasis | dict (the forms of dqc/system/mol.py:357-400)"""
+    natm = len(atomzs)
+    out = []
+    for i in range(natm):
+        z = atomzs[i].item() if isinstance(atomzs[i], torch.Tensor) else atomzs[i]
+        if isinstance(basis, str):
+            b = loadbasis("%d:%s" % (int(z), basis))
+        elif isinstance(basis, dict):
+            bi = basis[int(z)] if int(z) in basis else basis[[k for k, v in periodic_table_atomz.items() if v == int(z)][0]]
+            b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
+        else:
+            bi = basis[i]
+            b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
+        out.append(AtomCGTOBasis(atomz=z, bases=b, pos=atompos[i]))
+    return out
+
+
+def make_tables(atombases: List[AtomCGTOBasis]):
+    """libcint-style (atm, bas, env) numpy tables, the layout of LibcintWrapper
+    (dqc/hamilton/intor/lcintwrap.py:37-86): 20 pad doubles, then per atom xyz+0 followed by that atom's
+    shells' exponents and (normalised) coefficients."""
+    ptr = 20
+    atm, bas, env = [], [], [0.0] * ptr
+    fracz = False
+    zs = []
+    for ia, ab in enumerate(atombases):
+        z = ab.atomz.item() if isinstance(ab.atomz, torch.Tensor) else ab.atomz
+        zs.append(float(z))
+        fracz = fracz or (float(z) != int(z))
+        atm.append([int(z), ptr, 1, ptr + 3, 0, 0])
+        env.extend([float(x) for x in ab.pos.detach().cpu()])
+        env.append(0.0)
+        ptr += 4
+        for sh in ab.bases:
+            assert sh.alphas.shape == sh.coeffs.shape and sh.alphas.ndim == 1
+            sh.wfnormalize_()
+            ng = len(sh.alphas)
+            bas.append([ia, sh.angmom, ng, 1, 0, ptr, ptr + ng, 0])
+            env.extend([float(x) for x in sh.alphas.detach().cpu()])
+            env.extend([float(x) for x in sh.coeffs.detach().cpu()])
+            ptr += 2 * ng
+    return (np.array(atm, dtype=np.int32).reshape(-1, 6), np.array(bas, dtype=np.int32).reshape(-1, 8),
+            np.array(env, dtype=np.float64), (np.array(zs) if fracz else None))

@@ -1,0 +1,47 @@
+"""Molecule batches across the GPUs of one node.
+
+The reference has no batching (one Mol -> one Hamiltonian, dqc/system/mol.py:77-121); a batch is N
+independent SCF problems, so the path shards with NO data-path collective: every rank
+(one process per GPU) takes a cost-balanced share of the molecules, and one all_gather of
+(energy, iterations, fock seconds) per molecule closes the run.  Backend "nccl" is RCCL on ROCm;
+the CPU tests drive the same code with "gloo"."""
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def molecule_cost(nao: int, ngrid: int) -> float:
+    """relative per-iteration cost: ERI-tile stream ~ nao^4 bytes, grid passes ~ ngrid*nao^2 flops"""
+    return float(nao) ** 4 + 12.0 * float(ngrid) * float(nao) ** 2
+
+
+def shard_lpt(costs: Sequence[float], world_size: int) -> List[List[int]]:
+    """longest-processing-time-first assignment of molecule indices to ranks (deterministic)"""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        out[r].append(i)
+        loads[r] += costs[i]
+    for r in range(world_size):
+        out[r].sort()
+    return out
+
+
+def run_sharded(nmol: int, costs: Sequence[float], runner: Callable[[int], Sequence[float]],
+                nvals: int = 3, device=None) -> torch.Tensor:
+    """Run `runner(i) -> nvals floats` for this rank's molecules and return the (nmol, nvals) table on every
+    rank.  Works without an initialised process group (single process)."""
+    ws = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if ws > 1 else 0
+    mine = shard_lpt(costs, ws)[rank]
+    dev = torch.device("cpu") if device is None else torch.device(device)
+    table = torch.zeros((nmol, nvals), dtype=torch.float64, device=dev)
+    for i in mine:
+        table[i] = torch.as_tensor(list(runner(i)), dtype=torch.float64, device=dev)
+    if ws > 1:
+        # every row is owned by exactly one rank and zero elsewhere: a sum is a gather
+        dist.all_reduce(table, op=dist.ReduceOp.SUM)
+    return table

@@ -1,0 +1,281 @@
+"""HamiltonMI355 -- the drop-in boundary: same constructor, method names, argument meaning, basis
+convention (everything in the orthogonalised basis), return types and error behaviour as the reference's
+HamiltonCGTO (dqc/hamilton/hcgto.py:19-558) / BaseHamilton (dqc/hamilton/base_hamilton.py:11-279), with the
+arithmetic done by the gfx950 library:
+
+    build()        S, T, V_nuc         -> dqc_int1e            (hcgto.py:108-114)
+                   (ij|kl)             -> dqc_eri_fill_tiles   (hcgto.py:129; stays on the device as
+                                          8-fold-unique tiles instead of a dense, orthogonalised nao^4 tensor)
+    setup_grid()   AO (+gradient)      -> dqc_eval_gto         (hcgto.py:152-186)
+    get_elrep / get_exchange           -> dqc_jk_from_tiles    (hcgto.py:204-241)
+    get_vxc / get_e_xc                 -> dqc_grid_density, dqc_xc_eval, dqc_grid_vxc   (hcgto.py:260-269, 320-328)
+
+The reference orthogonalises the ERI tensor once (convert4, O(nao^5)); here the ERIs stay in the AO basis
+and the density / J / K / Vxc matrices are transformed instead (D_ao = X D X^T, J = X^T J_ao X), which is
+algebraically identical.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import lib
+from .basis import make_tables
+from .linop import LinearOperator
+from .utils.datastruct import AtomCGTOBasis, SpinParam, ValGrad
+from .xc import LibXC
+
+
+class HamiltonMI355:
+    def __init__(self, atombases: List[AtomCGTOBasis], spherical: bool = True, df=None, efield=None,
+                 vext: Optional[torch.Tensor] = None, cache=None, orthozer: bool = True,
+                 aoparamzer: str = "qr", device="cuda"):
+        if not spherical:
+            raise NotImplementedError("only spherical AOs (the reference default) are implemented on MI355X")
+        if df is not None:
+            raise NotImplementedError("density fitting is a 'next' row (SURVEY.md 8f2), not in this build")
+        if efield is not None:
+            raise NotImplementedError("electric-field integrals are outside the MI355X hot path")
+        if aoparamzer not in ("qr", "matexp"):
+            raise RuntimeError("Unknown ao parameterizer: %s. Available options are: ['qr', 'matexp']" % aoparamzer)
+        lib.load()  # fail loudly if the HIP library is missing
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise lib.DqcAmdError("HamiltonMI355 needs a ROCm device ('cuda'); there is no CPU path")
+        self.dtype = torch.float64
+        self.atombases = atombases
+        self.spherical = spherical
+        atm, bas, env, zs = make_tables(atombases)
+        self._tab = lib.Tables(atm, bas, env)
+        self._zs = zs
+        self._nao_ao = self._tab.nao
+        self._ld = lib.padded_nao(self._nao_ao)
+
+        ovlp = lib.int1e("ovlp", self._tab, self.device)
+        self._ovlp_ao = ovlp
+        if orthozer:
+            ev, evec = torch.linalg.eigh(ovlp)
+            acc = ev > 1e-6  # dqc/hamilton/orbconverter.py:73
+            self._orthozer = evec[:, acc] * ev[acc] ** (-0.5)
+        else:
+            self._orthozer = torch.eye(self._nao_ao, dtype=self.dtype, device=self.device)
+        self._vext = vext
+        self.is_grid_set = False
+        self.is_ao_set = False
+        self.is_grad_ao_set = False
+        self.is_built = False
+        self.xc = None
+        self.xcfamily = 1
+        self._fuse_k = False
+        self._jk_cache = None
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def nao(self) -> int:
+        return self._orthozer.shape[-1]
+
+    @property
+    def kpts(self):
+        raise TypeError("Isolated molecule Hamiltonian does not have kpts property")
+
+    @property
+    def df(self):
+        return None
+
+    # ------------------------------------------------------------------ orbital converter
+    def _convert2(self, mat):
+        return self._orthozer.transpose(-2, -1) @ mat @ self._orthozer
+
+    def _unconvert_dm(self, dm):
+        return self._orthozer @ dm @ self._orthozer.transpose(-2, -1)
+
+    # ------------------------------------------------------------------ setups
+    def build(self):
+        tab, dev = self._tab, self.device
+        kin = lib.int1e("kin", tab, dev)
+        nuc = lib.int1e("nuc", tab, dev, self._zs)
+        self.olp_mat = self._convert2(self._ovlp_ao)
+        self.kinnucl_mat = self._convert2(kin + nuc)
+        self.nucl_mat = self._convert2(nuc)
+        self._tiles = lib.eri_tiles(tab, dev)
+        self._jkwork = lib.jk_workspace(self._nao_ao, dev)
+        self.is_built = True
+        if self._vext is not None:
+            self.kinnucl_mat = self.kinnucl_mat + self.get_vext(self._vext).fullmatrix()
+        return self
+
+    def setup_grid(self, grid, xc=None) -> None:
+        self.xc = xc
+        self.xcfamily = 1 if xc is None else xc.family
+        if self.xcfamily not in (1, 2):
+            raise NotImplementedError("meta-GGA grids are a 'next' row (SURVEY.md 8f4)")
+        self.grid = grid
+        assert grid.coord_type == "cart"
+        self.rgrid = grid.get_rgrid().to(self.device)
+        self.dvolume = grid.get_dvolume().to(self.device).contiguous()
+        deriv = 0 if self.xcfamily == 1 else 1
+        self._ao = lib.eval_gto(self._tab, self.rgrid, deriv)  # (ngrid, ld) or (4, ngrid, ld)
+        self.is_grid_set = True
+        self.is_ao_set = True
+        self.is_grad_ao_set = deriv == 1
+
+    @property
+    def basis(self):
+        """(ngrid, nao) AO values, the attribute name of the reference (hcgto.py:168)"""
+        a = self._ao if self._ao.dim() == 2 else self._ao[0]
+        return a[:, :self._nao_ao]
+
+    # ------------------------------------------------------------------ Fock components
+    def get_nuclattr(self):
+        return LinearOperator.m(self.nucl_mat, is_hermitian=True)
+
+    def get_kinnucl(self):
+        return LinearOperator.m(self.kinnucl_mat, is_hermitian=True)
+
+    def get_overlap(self):
+        return LinearOperator.m(self.olp_mat, is_hermitian=True)
+
+    def _batched(self, fcn, dm):
+        if dm.dim() == 2:
+            return fcn(dm)
+        bshape = dm.shape[:-2]
+        res = [fcn(d) for d in dm.reshape(-1, *dm.shape[-2:])]
+        return torch.stack(res).reshape(*bshape, *res[0].shape)
+
+    def _jk_orth(self, dm, need_k):
+        """(J, K) in the orthogonalised basis for one (nao,nao) dm; one fused pass over the ERI tiles.
+        The reference calls get_elrep(dm) and get_exchange(dm) back to back (dqc/qccalc/hf.py:198-199);
+        the pair is memoised on the identity/version of dm so the tiles are streamed once."""
+        key = (dm.data_ptr(), dm._version, tuple(dm.shape))
+        c = self._jk_cache
+        if c is not None and c[0] == key and (c[2] is not None or not need_k):
+            return c[1], c[2]
+        dao = self._unconvert_dm(dm)
+        with_k = need_k or self._fuse_k
+        J, K = lib.jk(self._tiles, dao, self._jkwork, with_k)
+        J = self._convert2(J)
+        J = (J + J.transpose(-2, -1)) * 0.5
+        if K is not None:
+            K = self._convert2(K)
+            K = (K + K.transpose(-2, -1)) * 0.5
+        self._jk_cache = (key, J, K)
+        return J, K
+
+    def get_elrep(self, dm):
+        if not self.is_built:
+            raise RuntimeError("Please call `build()` before `get_elrep`")
+        mat = self._batched(lambda d: self._jk_orth(d, False)[0], dm)
+        return LinearOperator.m(mat, is_hermitian=True)
+
+    def get_exchange(self, dm):
+        """returns -K/2 (hcgto.py:234); SpinParam input uses K(2 D_sigma) per spin (hcgto.py:238-241)"""
+        if isinstance(dm, SpinParam):
+            return SpinParam(u=self.get_exchange(2 * dm.u), d=self.get_exchange(2 * dm.d))
+        if not self.is_built:
+            raise RuntimeError("Please call `build()` before `get_exchange`")
+        self._fuse_k = True
+        mat = self._batched(lambda d: -0.5 * self._jk_orth(d, True)[1], dm)
+        return LinearOperator.m(mat, is_hermitian=True)
+
+    def get_vext(self, vext):
+        if not self.is_ao_set:
+            raise RuntimeError("Please call `setup_grid(grid, xc)` to call this function")
+        ao = self._ao if self._ao.dim() == 2 else self._ao[0].contiguous()
+        zero = None
+        mat = self._batched1(lambda v: lib.grid_vxc(ao, self._nao_ao, self.dvolume, v.contiguous(), zero), vext)
+        mat = self._convert2(mat[..., :self._nao_ao, :self._nao_ao])
+        mat = (mat + mat.transpose(-2, -1)) * 0.5
+        return LinearOperator.m(mat, is_hermitian=True)
+
+    def _batched1(self, fcn, v):
+        if v.dim() == 1:
+            return fcn(v)
+        res = [fcn(x) for x in v.reshape(-1, v.shape[-1])]
+        return torch.stack(res).reshape(*v.shape[:-1], *res[0].shape)
+
+    def get_vxc(self, dm):
+        assert self.xc is not None, "Please call .setup_grid with the xc object"
+        if isinstance(dm, SpinParam):
+            raise NotImplementedError("spin-polarised Vxc is a 'next' row (SURVEY.md 8f1/f4)")
+
+        def one(d):
+            densinfo = self._dm2densinfo(d)
+            potinfo = self.xc.get_vxc(densinfo)
+            return self._get_vxc_from_potinfo(potinfo)
+
+        return LinearOperator.m(self._batched(one, dm), is_hermitian=True)
+
+    # ------------------------------------------------------------------ interface to dm
+    def ao_orb2dm(self, orb, orb_weight):
+        orb_w = orb * orb_weight.unsqueeze(-2)
+        return torch.matmul(orb, orb_w.transpose(-2, -1))
+
+    def aodm2dens(self, dm, xyz):
+        """density at arbitrary points (hcgto.py:283-299)"""
+        dao = self._unconvert_dm(dm)
+        pts = xyz.reshape(-1, xyz.shape[-1]).to(self.device).contiguous()
+        ao = lib.eval_gto(self._tab, pts, 0)
+        dp = lib.pad_matrix((dao + dao.transpose(-2, -1)) * 0.5, self._ld)
+        rho, _ = lib.grid_density(ao, self._nao_ao, dp, False)
+        return rho.reshape(xyz.shape[:-1])
+
+    # ------------------------------------------------------------------ energies
+    def get_e_hcore(self, dm):
+        return torch.einsum("...ij,...ji->...", self.kinnucl_mat, dm)
+
+    def get_e_elrep(self, dm):
+        return 0.5 * torch.einsum("...ij,...ji->...", self.get_elrep(dm).fullmatrix(), dm)
+
+    def get_e_exchange(self, dm):
+        exc = self.get_exchange(dm)
+        ene = SpinParam.apply_fcn(lambda e, d: 0.5 * torch.einsum("...ij,...ji->...", e.fullmatrix(), d), exc, dm)
+        return SpinParam.sum(ene)
+
+    def get_e_xc(self, dm):
+        assert self.xc is not None, "Please call .setup_grid with the xc object"
+        if isinstance(dm, SpinParam):
+            raise NotImplementedError("spin-polarised E_xc is a 'next' row (SURVEY.md 8f1/f4)")
+
+        def one(d):
+            edens = self.xc.get_edensityxc(self._dm2densinfo(d))
+            return torch.sum(self.dvolume * edens, dim=-1)
+
+        return self._batched(one, dm)
+
+    # ------------------------------------------------------------------ variational-solver hooks (not in scope)
+    def ao_orb_params2dm(self, *a, **k):
+        raise NotImplementedError("the variational orbital parametrisation is out of scope (SURVEY.md 2, row 3)")
+
+    def dm2ao_orb_params(self, *a, **k):
+        raise NotImplementedError("the variational orbital parametrisation is out of scope (SURVEY.md 2, row 3)")
+
+    # ------------------------------------------------------------------ grid passes
+    def _dm2densinfo(self, dm) -> ValGrad:
+        if not self.is_ao_set:
+            raise RuntimeError("Please call `setup_grid(grid, xc)` first")
+        dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
+        dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
+        gga = self.xcfamily == 2
+        if gga and not self.is_grad_ao_set:
+            raise RuntimeError("Please call `setup_grid(grid, gradlevel>=1)` to calculate the density gradient")
+        rho, grho = lib.grid_density(self._ao, self._nao_ao, dao, gga)
+        return ValGrad(value=rho, grad=grho)
+
+    def _get_vxc_from_potinfo(self, potinfo: ValGrad):
+        vg = potinfo.grad if self.xcfamily == 2 else None
+        vm = lib.grid_vxc(self._ao, self._nao_ao, self.dvolume, potinfo.value.contiguous(),
+                          None if vg is None else vg.contiguous())
+        mat = self._convert2(vm[:self._nao_ao, :self._nao_ao])
+        return (mat + mat.transpose(-2, -1)) * 0.5
+
+    def getparamnames(self, methodname: str, prefix: str = "") -> List[str]:
+        table = {
+            "get_kinnucl": ["kinnucl_mat"], "get_nuclattr": ["nucl_mat"], "get_overlap": ["olp_mat"],
+            "get_elrep": ["_tiles"], "get_exchange": ["_tiles"], "ao_orb2dm": [],
+            "get_e_hcore": ["kinnucl_mat"], "get_e_elrep": ["_tiles"], "get_e_exchange": ["_tiles"],
+            "get_e_xc": ["_ao", "_orthozer", "dvolume"], "get_vxc": ["_ao", "_orthozer", "dvolume"],
+            "get_vext": ["_ao", "_orthozer", "dvolume"], "_dm2densinfo": ["_ao", "_orthozer"],
+            "_get_vxc_from_potinfo": ["_ao", "_orthozer", "dvolume"],
+        }
+        if methodname not in table:
+            raise KeyError("getparamnames has no %s method" % methodname)
+        return [prefix + n for n in table[methodname]]

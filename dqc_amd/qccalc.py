@@ -1,0 +1,161 @@
+"""HF / KS drivers with the reference's surface -- HF(mol).run().energy(), KS(mol, xc=...).run().energy(),
+.aodm(), .dm2energy(dm) -- and the same engine data flow:
+
+   _HFEngine / _KSEngine:  dm2scp (Fock build), scp2dm (diagonalise, occupy), dm2energy
+        dqc/qccalc/hf.py:93-119, 166-247 ; dqc/qccalc/ks.py:110-130, 157-187
+   SCF_QCCalc.run: dm0 = "1e" core guess, then the fixed point F = dm2scp(scp2dm(F))
+        dqc/qccalc/scf_qccalc.py:84-116 (reference: xitorch Broyden-1, alpha=-0.5, maxiter=50)
+
+Everything runs on the device; the self-consistent parameter is the Fock matrix in the orthogonalised basis,
+as in the reference.  The fixed-point solver is Pulay DIIS on the commutator [F, D] (any convergent mixer
+gives the same fixed point; only converged energies are compared).  Closed-shell / restricted only; UHF/UKS
+is a "next" row."""
+from typing import Optional
+
+import torch
+
+from .utils.datastruct import SpinParam
+from .xc import get_xc
+
+
+class _Engine:
+    def __init__(self, system, xc=None, is_ks=False):
+        self._system = system
+        self.hamilton = system.get_hamiltonian()
+        self.is_ks = is_ks
+        self.xc = get_xc(xc) if is_ks else None
+        if system.spin != 0:
+            raise NotImplementedError("restricted closed-shell only; UHF/UKS is a 'next' row (SURVEY.md 8f1)")
+        if is_ks:
+            system.setup_grid()
+            self.hamilton.setup_grid(system.get_grid(), self.xc)
+        self.hamilton.build()
+        self.orb_weight = system.get_orbweight()
+        self.norb = self.orb_weight.shape[-1]
+        self.knvext = self.hamilton.get_kinnucl()
+        self.shape = self.knvext.shape
+        self.dtype, self.device = self.knvext.dtype, self.knvext.device
+
+    def get_system(self):
+        return self._system
+
+    # Fock build -- THE hot path (hf.py:182-201, ks.py:176-187)
+    def dm2scp(self, dm):
+        elrep = self.hamilton.get_elrep(dm)
+        if self.is_ks:
+            fock = self.knvext + elrep + self.hamilton.get_vxc(dm)
+        else:
+            fock = self.knvext + elrep + self.hamilton.get_exchange(dm)
+        return fock.fullmatrix()
+
+    def scp2dm(self, scp):
+        fock = (scp + scp.transpose(-2, -1)) * 0.5
+        # generalised problem F C = S C e with S = identity in the orthogonalised basis (hf.py:227-247)
+        _, evec = torch.linalg.eigh(fock)
+        return self.hamilton.ao_orb2dm(evec[..., :self.norb], self.orb_weight)
+
+    def scp2scp(self, scp):
+        return self.dm2scp(self.scp2dm(scp))
+
+    def dm2energy(self, dm):
+        h = self.hamilton
+        e = h.get_e_hcore(dm) + h.get_e_elrep(dm)
+        e = e + (h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
+        return e + self._system.get_nuclei_energy().to(e.device)
+
+    def energy_parts(self, dm):
+        h = self.hamilton
+        p = {"e_core": float(h.get_e_hcore(dm)), "e_elrep": float(h.get_e_elrep(dm)),
+             "e_nuc": float(self._system.get_nuclei_energy())}
+        p["e_xc" if self.is_ks else "e_exch"] = float(h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
+        p["e_tot"] = sum(p.values())
+        return p
+
+
+class SCF_QCCalc:
+    def __init__(self, engine):
+        self._engine = engine
+        self._has_run = False
+        self.niter = 0
+        self.converged = False
+
+    def get_system(self):
+        return self._engine.get_system()
+
+    def run(self, dm0="1e", eigen_options=None, fwd_options=None, bck_options=None):
+        opts = {"maxiter": 50, "f_tol": 1e-9, "history": 8}
+        opts.update(fwd_options or {})
+        eng = self._engine
+        if isinstance(dm0, str):
+            if dm0 != "1e":
+                raise RuntimeError("Unknown dm0: %s" % dm0)
+            n = eng.shape[-1]
+            scp0 = eng.dm2scp(torch.zeros((n, n), dtype=eng.dtype, device=eng.device))
+            dm = eng.scp2dm(scp0)
+        elif dm0 is None:
+            raise RuntimeError("dm0 must be '1e' or a density matrix")
+        else:
+            dm = dm0.to(eng.device)
+        fs, es = [], []
+        fock = eng.dm2scp(dm)
+        self.converged = False
+        for it in range(int(opts["maxiter"])):
+            self.niter = it + 1
+            err = fock @ dm - dm @ fock  # [F, D], S = 1
+            emax = float(err.abs().max())
+            if emax < opts["f_tol"]:
+                self.converged = True
+                break
+            fs.append(fock)
+            es.append(err.reshape(-1))
+            if len(fs) > opts["history"]:
+                fs.pop(0)
+                es.pop(0)
+            m = len(fs)
+            if m > 1:
+                E = torch.stack(es)
+                B = torch.zeros((m + 1, m + 1), dtype=fock.dtype, device=fock.device)
+                B[:m, :m] = E @ E.T
+                B[m, :m] = -1
+                B[:m, m] = -1
+                rhs = torch.zeros(m + 1, dtype=fock.dtype, device=fock.device)
+                rhs[m] = -1
+                c = torch.linalg.lstsq(B.cpu(), rhs.cpu().unsqueeze(-1)).solution[:m, 0].to(fock.device)
+                fmix = (c.reshape(-1, 1, 1) * torch.stack(fs)).sum(0)
+            else:
+                fmix = fock
+            dm = eng.scp2dm(fmix)
+            fock = eng.dm2scp(dm)
+        self._dm = dm
+        self._fock = fock
+        self._has_run = True
+        return self
+
+    def energy(self):
+        assert self._has_run
+        return self._engine.dm2energy(self._dm)
+
+    def aodm(self):
+        assert self._has_run
+        return self._dm
+
+    def dm2energy(self, dm):
+        return self._engine.dm2energy(dm)
+
+
+class HF(SCF_QCCalc):
+    def __init__(self, system, restricted: Optional[bool] = None, variational: bool = False):
+        if variational:
+            raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
+        if restricted is False:
+            raise NotImplementedError("UHF is a 'next' row (SURVEY.md 8f1)")
+        super().__init__(_Engine(system, None, is_ks=False))
+
+
+class KS(SCF_QCCalc):
+    def __init__(self, system, xc, restricted: Optional[bool] = None, variational: bool = False):
+        if variational:
+            raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
+        if restricted is False:
+            raise NotImplementedError("UKS is a 'next' row (SURVEY.md 8f1)")
+        super().__init__(_Engine(system, xc, is_ks=True))

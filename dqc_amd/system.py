@@ -1,0 +1,91 @@
+"""Mol: thin equivalent of the reference's dqc/system/mol.py (constructor :77-121, get_nuclei_energy :252-260,
+setup_grid :262-267, occupations :421-443) that owns a HamiltonMI355 and a device grid."""
+from typing import Optional
+
+import torch
+
+from .basis import parse_moldesc, make_atombases
+from .grid import get_predefined_grid
+from .hamilton import HamiltonMI355
+
+
+class Mol:
+    def __init__(self, moldesc, basis, *, grid="sg3", spin: Optional[int] = None, charge: int = 0,
+                 orthogonalize_basis: bool = True, ao_parameterizer: str = "qr", efield=None, vext=None,
+                 dtype=torch.float64, device="cuda"):
+        if dtype != torch.float64:
+            raise NotImplementedError("the MI355X path computes in float64 like the reference default (mol.py:90)")
+        self._dtype = dtype
+        self._device = torch.device(device)
+        self._grid_inp = grid
+        self._grid = None
+        atomzs, atompos = parse_moldesc(moldesc, dtype=dtype)
+        self._atomzs, self._atompos = atomzs, atompos
+        self._atombases = make_atombases(atomzs, atompos, basis)
+        nelecs = float(torch.sum(atomzs.to(torch.float64))) - charge
+        if spin is None:
+            spin = int(round(nelecs)) % 2
+        if (int(round(nelecs)) - spin) % 2 != 0 or spin < 0:
+            raise AssertionError("inconsistent spin %d for %g electrons" % (spin, nelecs))
+        self._spin, self._charge = spin, charge
+        self._nelecs = nelecs
+        self._nup = (int(round(nelecs)) + spin) // 2
+        self._ndn = (int(round(nelecs)) - spin) // 2
+        self._hamilton = HamiltonMI355(self._atombases, spherical=True, efield=efield, vext=vext,
+                                       orthozer=orthogonalize_basis, aoparamzer=ao_parameterizer,
+                                       device=self._device)
+
+    # ---- accessors with the reference's names (dqc/system/base_system.py:10-139) ----
+    @property
+    def atompos(self):
+        return self._atompos
+
+    @property
+    def atomzs(self):
+        return self._atomzs
+
+    @property
+    def spin(self):
+        return self._spin
+
+    @property
+    def charge(self):
+        return self._charge
+
+    @property
+    def numel(self):
+        return self._nelecs
+
+    def densityfit(self, method=None, auxbasis=None):
+        raise NotImplementedError("density fitting is a 'next' row (SURVEY.md 8f2)")
+
+    def get_hamiltonian(self):
+        return self._hamilton
+
+    def requires_grid(self):
+        return True
+
+    def setup_grid(self):
+        if self._grid is None:
+            self._grid = get_predefined_grid(self._grid_inp, self._atomzs.tolist(), self._atompos.to(self._device),
+                                             dtype=self._dtype, device=self._device)
+
+    def get_grid(self):
+        if self._grid is None:
+            raise RuntimeError("Please run mol.setup_grid() first before calling get_grid()")
+        return self._grid
+
+    def get_nuclei_energy(self):
+        z = self._atomzs.to(self._dtype)
+        r = torch.cdist(self._atompos, self._atompos) + torch.eye(len(z), dtype=self._dtype)
+        q = (z.unsqueeze(0) * z.unsqueeze(1)) / r
+        return (torch.sum(q) - torch.sum(torch.diagonal(q))) * 0.5
+
+    def get_orbweight(self, polarized: bool = False):
+        """occupation numbers of the lowest orbitals (mol.py:421-443, safeops.occnumber)"""
+        dev = self._device
+        if polarized:
+            raise NotImplementedError("spin-polarised occupations: 'next' row (SURVEY.md 8f1)")
+        w = torch.cat([torch.full((self._ndn,), 2.0, dtype=self._dtype, device=dev),
+                       torch.full((self._nup - self._ndn,), 1.0, dtype=self._dtype, device=dev)])
+        return w

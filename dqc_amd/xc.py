@@ -1,0 +1,129 @@
+"""Exchange-correlation objects with the reference's BaseXC surface (dqc/xc/base_xc.py:8-195):
+`.family`, `get_edensityxc(densinfo)`, `get_vxc(densinfo)`, '+' and scalar '*' combinators, and
+`get_xc("lda_x + gga_c_pbe")` (dqc/api/getxc.py:38-59).  Functional evaluation runs in the HIP kernel
+dqc_xc_eval (csrc/xc.hip) for trees made of the supported libxc names; any other object exposing the
+BaseXC methods (e.g. a user CustomXC, dqc/xc/custom_xc.py:7-25) is called as-is on device tensors by the
+Hamiltonian."""
+import re
+
+import torch
+
+from . import lib
+from .utils.datastruct import ValGrad, SpinParam
+
+_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "gga_x_pbe": 2, "gga_c_pbe": 2}
+
+
+class BaseXC:
+    @property
+    def family(self):
+        raise NotImplementedError
+
+    def get_edensityxc(self, densinfo):
+        raise NotImplementedError
+
+    def get_vxc(self, densinfo):
+        raise NotImplementedError
+
+    def __add__(self, other):
+        return LibXC(self.terms + other.terms) if isinstance(self, LibXC) and isinstance(other, LibXC) \
+            else _SumXC(self, other)
+
+    def __mul__(self, f):
+        if isinstance(self, LibXC):
+            return LibXC([(c * float(f), n) for c, n in self.terms])
+        return _MulXC(self, f)
+
+    __rmul__ = __mul__
+
+    def getparamnames(self, methodname, prefix=""):
+        return []
+
+
+class LibXC(BaseXC):
+    """weighted sum of libxc functionals evaluated by the fused HIP kernel (unpolarised)"""
+
+    def __init__(self, terms):
+        self.terms = list(terms)
+        for _, n in self.terms:
+            if n not in _FAMILY:
+                raise ValueError("libxc functional %s is not available in dqc_amd (supported: %s)"
+                                 % (n, sorted(_FAMILY)))
+
+    @property
+    def family(self):
+        return max([1] + [_FAMILY[n] for _, n in self.terms])
+
+    def _flat(self, densinfo):
+        if isinstance(densinfo, SpinParam):
+            raise NotImplementedError("polarised libxc evaluation is outside the MI355X hot path (SURVEY.md 8f4)")
+        rho = densinfo.value
+        grad = densinfo.grad
+        assert rho.dim() == 1, "batched densities are looped by the caller"
+        return rho.contiguous(), (None if (grad is None or self.family == 1) else grad.contiguous())
+
+    def get_edensityxc(self, densinfo):
+        rho, grad = self._flat(densinfo)
+        if not self.terms:
+            return torch.zeros_like(rho)
+        e, _, _ = lib.xc_eval(self.terms, rho, grad, want_e=True, want_v=False)
+        return e
+
+    def get_vxc(self, densinfo):
+        rho, grad = self._flat(densinfo)
+        if not self.terms:
+            return ValGrad(value=torch.zeros_like(rho), grad=None if grad is None else torch.zeros_like(grad))
+        _, v, vg = lib.xc_eval(self.terms, rho, grad, want_e=False, want_v=True)
+        return ValGrad(value=v, grad=vg)
+
+
+class _SumXC(BaseXC):
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    @property
+    def family(self):
+        return max(self.a.family, self.b.family)
+
+    def get_edensityxc(self, densinfo):
+        return self.a.get_edensityxc(densinfo) + self.b.get_edensityxc(densinfo)
+
+    def get_vxc(self, densinfo):
+        va, vb = self.a.get_vxc(densinfo), self.b.get_vxc(densinfo)
+        g = va.grad if vb.grad is None else (vb.grad if va.grad is None else va.grad + vb.grad)
+        return ValGrad(value=va.value + vb.value, grad=g)
+
+
+class _MulXC(BaseXC):
+    def __init__(self, a, f):
+        self.a, self.f = a, f
+
+    @property
+    def family(self):
+        return self.a.family
+
+    def get_edensityxc(self, densinfo):
+        return self.a.get_edensityxc(densinfo) * self.f
+
+    def get_vxc(self, densinfo):
+        v = self.a.get_vxc(densinfo)
+        return ValGrad(value=v.value * self.f, grad=None if v.grad is None else v.grad * self.f)
+
+
+def get_libxc(name):
+    return LibXC([(1.0, name)])
+
+
+def get_xc(xcstr):
+    """"lda_x + gga_c_pbe", "0.7*lda_x" ... ; None -> zero functional (reference ks.py:59-60 accepts None)"""
+    if xcstr is None:
+        return LibXC([])
+    if isinstance(xcstr, BaseXC) or hasattr(xcstr, "get_vxc"):
+        return xcstr
+    terms = []
+    for tok in xcstr.replace(" ", "").split("+"):
+        m = re.fullmatch(r"(?:([0-9.eE+-]+)\*)?([a-zA-Z0-9_]+)", tok)
+        if m is None:
+            raise ValueError("cannot parse xc term: %s" % tok)
+        terms.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2).lower()))
+    return LibXC(terms)
