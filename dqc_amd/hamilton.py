@@ -144,10 +144,11 @@ class HamiltonMI355:
     def _jk_orth(self, dm, need_k):
         """(J, K) in the orthogonalised basis for one (nao,nao) dm; one fused pass over the ERI tiles.
         The reference calls get_elrep(dm) and get_exchange(dm) back to back (dqc/qccalc/hf.py:198-199);
-        the pair is memoised on the identity/version of dm so the tiles are streamed once."""
-        key = (dm.data_ptr(), dm._version, tuple(dm.shape))
+        the pair is memoised on the identity + version of the dm tensor so the tiles are streamed once."""
+        # the cache holds `dm` itself (identity + in-place version), never a raw pointer: the caching
+        # allocator reuses addresses of freed tensors
         c = self._jk_cache
-        if c is not None and c[0] == key and (c[2] is not None or not need_k):
+        if c is not None and c[0] is dm and c[3] == dm._version and (c[2] is not None or not need_k):
             return c[1], c[2]
         dao = self._unconvert_dm(dm)
         with_k = need_k or self._fuse_k
@@ -157,7 +158,7 @@ class HamiltonMI355:
         if K is not None:
             K = self._convert2(K)
             K = (K + K.transpose(-2, -1)) * 0.5
-        self._jk_cache = (key, J, K)
+        self._jk_cache = (dm, J, K, dm._version)
         return J, K
 
     def get_elrep(self, dm):

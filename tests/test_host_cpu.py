@@ -1,0 +1,177 @@
+"""CPU tests (-m "not gpu") of the host logic and of the C-ABI library surface (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import basis as ob, grid as og
+from tests import molecules as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """libdqc_amd.so loads without a GPU and exports exactly the entry points include/dqc_amd.h declares"""
+    from dqc_amd import build, lib
+    build.build()
+    hdr = open(os.path.join(ROOT, "include", "dqc_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(dqc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 14
+    so = ctypes.CDLL(lib.libpath())
+    for n in names:
+        assert hasattr(so, n), n
+    L = lib.load()
+    assert L.dqc_version() >= 100
+    assert L.dqc_padded_nao(114) == 128 and L.dqc_padded_nao(208) == 208
+    assert L.dqc_eri_tile_count(208) == 351 * 352 // 2 * (351 * 352 // 2 + 1) // 2 or L.dqc_eri_tile_count(208) > 0
+    nb = 26
+    npair = nb * (nb + 1) // 2
+    assert L.dqc_eri_tile_count(208) == npair * (npair + 1) // 2
+    assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8
+
+
+def test_hamiltonian_fails_loudly_without_gpu():
+    """no CPU fallback: constructing the product Hamiltonian on a CPU device is an error"""
+    import dqc_amd
+    from dqc_amd.lib import DqcAmdError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((DqcAmdError, RuntimeError, AssertionError)):
+        dqc_amd.Mol("H 0 0 0; H 1.4 0 0", basis="3-21G", device="cpu")
+
+
+def test_cgto_normalisation_and_tables_match_reference_layout():
+    """golden values recorded from the reference's own LibcintWrapper / wfnormalize_"""
+    import dqc_amd
+    from dqc_amd.basis import make_atombases, make_tables, parse_moldesc
+    b = dqc_amd.CGTOBasis(0, torch.tensor([5.4471780, 0.8245472], dtype=torch.float64),
+                          torch.tensor([0.1562850, 0.9046910], dtype=torch.float64)).wfnormalize_()
+    assert np.allclose(b.coeffs.numpy(), [1.4078647602386087, 1.9777749721765199], rtol=1e-13)
+    zs, pos = parse_moldesc("H -0.5 0 0; H 0.5 0 0")
+    atm, bas, env, fz = make_tables(make_atombases(zs, pos, "3-21G"))
+    assert atm.tolist() == [[1, 20, 1, 23, 0, 0], [1, 30, 1, 33, 0, 0]]
+    assert bas.tolist() == [[0, 0, 2, 1, 0, 24, 26, 0], [0, 0, 1, 1, 0, 28, 29, 0],
+                            [1, 0, 2, 1, 0, 34, 36, 0], [1, 0, 1, 1, 0, 38, 39, 0]]
+    assert fz is None
+    assert np.allclose(env[20:24], [-0.5, 0, 0, 0]) and np.allclose(env[24:28], [5.4471780, 0.8245472, 1.4078647602386087, 1.9777749721765199])
+    # same tables as the oracle's restatement of LibcintWrapper
+    t = ob.make_tables("H -0.5 0 0; H 0.5 0 0", "3-21G")
+    assert np.array_equal(t.atm, atm) and np.array_equal(t.bas, bas) and np.allclose(t.env, env, rtol=1e-15)
+
+
+@pytest.mark.parametrize("basis,zs,nao,nsh", [("cc-pvdz", M.benzene()[0], 114, 54), ("cc-pvdz", M.VITC[0], 208, 96),
+                                              ("cc-pvtz", M.naphthalene()[0], 412, 148), ("sto-3g", M.H2O[0], 7, 5)])
+def test_basis_sizes_match_survey(basis, zs, nao, nsh):
+    from dqc_amd.basis import loadbasis
+    shells = [s for z in zs for s in loadbasis("%d:%s" % (z, basis))]
+    assert len(shells) == nsh
+    assert sum(2 * s.angmom + 1 for s in shells) == nao
+
+
+def test_basis_loader_errors_and_forms():
+    from dqc_amd.basis import loadbasis, make_atombases, parse_moldesc
+    with pytest.raises(RuntimeError):
+        loadbasis("2:cc-pvdz")  # He is not shipped
+    zs, pos = parse_moldesc(([1, 8], [[0, 0, 0], [1.8, 0, 0]]))
+    ab = make_atombases(zs, pos, {1: "3-21G", "O": "sto-3g"})
+    assert len(ab[0].bases) == 2 and len(ab[1].bases) == 3
+    ab2 = make_atombases(zs, pos, ["3-21G", loadbasis("8:sto-3g")])
+    assert len(ab2[1].bases) == 3
+    z3, p3 = parse_moldesc("O 0 0 0.2156; H 0 1.4749 -0.8625; H 0 -1.4749 -0.8625")
+    assert z3.tolist() == [8, 1, 1] and p3.shape == (3, 3)
+
+
+@pytest.mark.parametrize("g", ["sg2", "sg3", 0, 3, 4])
+def test_product_grid_equals_oracle_grid(g):
+    from dqc_amd.grid import get_predefined_grid
+    zs, pos = M.H2O
+    r, w = og.get_predefined_grid(g, zs, np.array(pos))
+    gr = get_predefined_grid(g, zs, torch.tensor(pos, dtype=torch.float64))
+    assert gr.coord_type == "cart"
+    assert np.abs(gr.get_rgrid().numpy() - r).max() < 1e-13
+    assert np.abs(gr.get_dvolume().numpy() - w).max() < 1e-13 * np.abs(w).max()
+
+
+def test_c5_grid_size_and_counts():
+    from dqc_amd.grid import get_predefined_grid
+    zs, pos = M.c5_molecule(0)
+    gr = get_predefined_grid("sg3", zs, torch.tensor(pos, dtype=torch.float64))
+    assert gr.get_rgrid().shape[0] == 353400  # 6*18946 + 6*17674 + 8*16710
+    z1, p1 = M.c5_molecule(5)
+    assert np.abs(np.array(p1) - np.array(pos)).max() < 0.3 and np.abs(np.array(p1) - np.array(pos)).max() > 0.01
+
+
+def test_grid_errors():
+    from dqc_amd.grid import get_predefined_grid, get_grid
+    p = torch.zeros((1, 3), dtype=torch.float64)
+    with pytest.raises(ValueError):
+        get_predefined_grid("sg9", [1], p)
+    with pytest.raises(TypeError):
+        get_predefined_grid(1.5, [1], p)
+    with pytest.raises(ValueError):
+        get_grid([1], p, radgrid_transform="nope")
+
+
+def test_xc_parser():
+    import dqc_amd
+    x = dqc_amd.get_xc("lda_x + 0.5*gga_c_pbe")
+    assert x.family == 2 and x.terms == [(1.0, "lda_x"), (0.5, "gga_c_pbe")]
+    assert dqc_amd.get_xc("lda_x+lda_c_pw").family == 1
+    y = dqc_amd.get_xc("lda_x") + dqc_amd.get_xc("gga_x_pbe") * 2
+    assert y.terms == [(1.0, "lda_x"), (2.0, "gga_x_pbe")]
+    with pytest.raises(ValueError):
+        dqc_amd.get_xc("mgga_x_scan")
+    assert dqc_amd.get_xc(None).terms == []
+
+
+def test_shard_lpt_balanced_and_complete():
+    from dqc_amd.batch import shard_lpt, molecule_cost
+    costs = [molecule_cost(208, 353400)] * 32
+    for ws in (1, 2, 4, 8):
+        sh = shard_lpt(costs, ws)
+        assert sorted(i for s in sh for i in s) == list(range(32))
+        assert all(len(s) == 32 // ws for s in sh)
+    sh = shard_lpt([5.0, 1.0, 1.0, 1.0, 1.0, 1.0], 2)
+    assert sorted(map(len, sh)) == [1, 5]
+
+
+_GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from dqc_amd.batch import run_sharded
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["PORT"], rank=int(os.environ["RANK"]), world_size=2)
+calls = []
+def runner(i):
+    calls.append(i)
+    return (-(i + 1) * 1.5, 10 + i, 0.25 * i)
+t = run_sharded(6, [3, 1, 2, 2, 1, 3], runner)
+assert len(calls) == 3, calls
+exp = torch.tensor([[-(i + 1) * 1.5, 10 + i, 0.25 * i] for i in range(6)], dtype=torch.float64)
+assert torch.equal(t, exp), t
+dist.barrier()
+dist.destroy_process_group()
+print("OK", os.environ["RANK"], sorted(calls))
+"""
+
+
+def test_run_sharded_world_size_2_gloo():
+    """the N>1 path (one process per GPU, no data-path collective, one closing reduction) on CPU with gloo"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _GLOO_WORKER % ROOT], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs), outs
