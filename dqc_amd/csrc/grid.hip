@@ -14,6 +14,8 @@
 //
 // f64 MFMA fragment layout (gfx950): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // C[row = (lane>>4) + 4*reg][col = lane&15].
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace dqc {
@@ -23,106 +25,149 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 DQC_DEV v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // ---------------------------------------------------------------------------------------------
-// density
+// density:  C[128 pts x n] = Phi_blk . D, K-chunks of 16 staged in double-buffered LDS, 8 waves per block,
+// wave w owns points 16w..16w+15 and all column tiles (accumulators in registers), fused row-dot epilogue.
 // ---------------------------------------------------------------------------------------------
+constexpr int DEN_BM = 128;   // points per block
+constexpr int DEN_KC = 16;    // K chunk
+constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-free ds_read_b64 fragments)
+
 template <int NCT, bool GGA>
-__global__ __launch_bounds__(256, 1) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
+__global__ __launch_bounds__(512, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
                                                          const double *__restrict__ dm, int ntile) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * 4 + wave) * 32;
-    if (g0 >= ngrid) return;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int LSB = NCT * 16;                 // width of the staged D column panel (== 16 mod 32 when NCT odd)
+    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    constexpr int A_SZ = DEN_BM * DEN_SA, B_SZ = DEN_KC * LSBP;
+    constexpr int NB2 = (DEN_KC * LSB / 2 + 511) / 512;  // double2 loads of the B chunk per thread
+    double *sA = lds, *sB = lds + 2 * A_SZ;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
-    const size_t cs = (size_t)ngrid * ld;  // component stride of ao
-    const double *a0p = ao + (size_t)min(g0 + lr, ngrid - 1) * ld + lk;
-    const double *a1p = ao + (size_t)min(g0 + 16 + lr, ngrid - 1) * ld + lk;
+    const int g0 = blockIdx.x * DEN_BM;
+    const size_t cs = (size_t)ngrid * ld;
+    // staging roles: A chunk = 128 rows x 16 doubles -> thread (row = tid/4, 4 doubles at seg = tid%4)
+    const int arow = tid >> 2, aseg = (tid & 3) * 4;
+    const double *asrc = ao + (size_t)min(g0 + arow, ngrid - 1) * ld + aseg;
 
-    double p[2][4][GGA ? 4 : 1];
+    double p[4][GGA ? 4 : 1];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int q = 0; q < (GGA ? 4 : 1); q++) p[i][r][q] = 0.0;
+        for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
 
+    const int nk = ld / DEN_KC;
     for (int jc = 0; jc < ntile; jc += NCT) {
-        v4d acc[2][NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ct++) { acc[0][ct] = v4d{0, 0, 0, 0}; acc[1][ct] = v4d{0, 0, 0, 0}; }
-        const double *bp = dm + (size_t)lk * ld + jc * 16 + lr;
         const int nvalid = min(NCT, ntile - jc);
-#pragma unroll 2
-        for (int k = 0; k < ld; k += 4) {
-            const double a0 = a0p[k], a1 = a1p[k];
-            const double *bk = bp + (size_t)k * ld;
+        v4d acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) acc[ct] = v4d{0, 0, 0, 0};
+        double2 pa[2], pb[NB2];
+        auto prefetch = [&](int kc) {
+            const double *s = asrc + kc * DEN_KC;
+            pa[0] = *reinterpret_cast<const double2 *>(s);
+            pa[1] = *reinterpret_cast<const double2 *>(s + 2);
+#pragma unroll
+            for (int i = 0; i < NB2; i++) {
+                const int e = (tid + i * 512) * 2;  // element of the (KC x LSB) panel
+                const int row = e / LSB, col = e - row * LSB;
+                pb[i] = (row < DEN_KC && jc * 16 + col < ld)
+                            ? *reinterpret_cast<const double2 *>(dm + (size_t)(kc * DEN_KC + row) * ld + jc * 16 + col)
+                            : make_double2(0.0, 0.0);
+            }
+        };
+        auto stage = [&](int buf) {
+            double *a = sA + buf * A_SZ + arow * DEN_SA + aseg;
+            *reinterpret_cast<double2 *>(a) = pa[0];
+            *reinterpret_cast<double2 *>(a + 2) = pa[1];
+#pragma unroll
+            for (int i = 0; i < NB2; i++) {
+                const int e = (tid + i * 512) * 2;
+                const int row = e / LSB, col = e - row * LSB;
+                if (row < DEN_KC) *reinterpret_cast<double2 *>(sB + buf * B_SZ + row * LSBP + col) = pb[i];
+            }
+        };
+        __syncthreads();  // buffers free (previous column panel fully consumed)
+        prefetch(0);
+        stage(0);
+        __syncthreads();
+        for (int kc = 0; kc < nk; kc++) {
+            const int buf = kc & 1;
+            if (kc + 1 < nk) prefetch(kc + 1);  // global loads in flight during the MFMAs below
+            const double *a = sA + buf * A_SZ + (wave * 16 + lr) * DEN_SA + lk;
+            const double *b = sB + buf * B_SZ + lk * LSBP + lr;
+#pragma unroll
+            for (int kk = 0; kk < DEN_KC / 4; kk++) {
+                const double av = a[kk * 4];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ct++)
+                    if (ct < nvalid) acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
+            }
+            if (kc + 1 < nk) stage(buf ^ 1);
+            __syncthreads();
+        }
+        // epilogue: row dots with Phi (and its gradient) in the accumulator layout, straight from global
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = min(g0 + wave * 16 + lk + 4 * r, ngrid - 1);
+            const double *ap = ao + (size_t)row * ld + jc * 16 + lr;
 #pragma unroll
             for (int ct = 0; ct < NCT; ct++) {
-                if (ct < nvalid) {  // wave-uniform
-                    const double b = bk[ct * 16];
-                    acc[0][ct] = mfma_f64(a0, b, acc[0][ct]);
-                    acc[1][ct] = mfma_f64(a1, b, acc[1][ct]);
+                if (ct < nvalid) {
+                    const double v = acc[ct][r];
+                    p[r][0] += v * ap[ct * 16];
+                    if (GGA) {
+                        p[r][1] += v * ap[cs + ct * 16];
+                        p[r][2] += v * ap[2 * cs + ct * 16];
+                        p[r][3] += v * ap[3 * cs + ct * 16];
+                    }
                 }
             }
         }
-        // epilogue: row dots with Phi (and its gradient) in the accumulator layout
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = min(g0 + rt * 16 + lk + 4 * r, ngrid - 1);
-                const double *ap = ao + (size_t)row * ld + jc * 16 + lr;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) {
-                    if (ct < nvalid) {
-                        const double v = acc[rt][ct][r];
-                        p[rt][r][0] += v * ap[ct * 16];
-                        if (GGA) {
-                            p[rt][r][1] += v * ap[cs + ct * 16];
-                            p[rt][r][2] += v * ap[2 * cs + ct * 16];
-                            p[rt][r][3] += v * ap[3 * cs + ct * 16];
-                        }
-                    }
-                }
-            }
     }
-    // reduce over the 16 lanes that share a row
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int q = 0; q < (GGA ? 4 : 1); q++) {
-                double v = p[rt][r][q];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                p[rt][r][q] = v;
-            }
+        for (int q = 0; q < (GGA ? 4 : 1); q++) {
+            double v = p[r][q];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            p[r][q] = v;
+        }
     if (lr == 0) {
 #pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = g0 + rt * 16 + lk + 4 * r;
-                if (row < ngrid) {
-                    rho[row] = p[rt][r][0];
-                    if (GGA) {
-                        grho[row] = 2.0 * p[rt][r][1];
-                        grho[(size_t)ngrid + row] = 2.0 * p[rt][r][2];
-                        grho[2 * (size_t)ngrid + row] = 2.0 * p[rt][r][3];
-                    }
+        for (int r = 0; r < 4; r++) {
+            const int row = g0 + wave * 16 + lk + 4 * r;
+            if (row < ngrid) {
+                rho[row] = p[r][0];
+                if (GGA) {
+                    grho[row] = 2.0 * p[r][1];
+                    grho[(size_t)ngrid + row] = 2.0 * p[r][2];
+                    grho[2 * (size_t)ngrid + row] = 2.0 * p[r][3];
                 }
             }
+        }
     }
+}
+
+template <int NCT>
+static constexpr size_t density_lds_bytes() {
+    constexpr int LSB = NCT * 16;
+    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    return sizeof(double) * 2 * (DEN_BM * DEN_SA + DEN_KC * LSBP);
 }
 
 template <bool GGA>
 static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
                           int ngrid, int ld, const double *dm, int ntile) {
-#define DQC_DENS_CASE(N)                                                                                  \
-    case N:                                                                                               \
-        hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(256), 0, st, rho, grho, ao, ngrid, ld, dm, ntile); \
+#define DQC_DENS_CASE(N)                                                                                           \
+    case N:                                                                                                        \
+        (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)density_lds_bytes<N>());                                                    \
+        hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(512), density_lds_bytes<N>(), st, rho, grho, ao,    \
+                           ngrid, ld, dm, ntile);                                                                  \
         break;
     switch (nct) {
         DQC_DENS_CASE(1) DQC_DENS_CASE(2) DQC_DENS_CASE(3) DQC_DENS_CASE(4) DQC_DENS_CASE(5) DQC_DENS_CASE(6)
@@ -137,34 +182,35 @@ static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
-// Vxc
+// Vxc:  M = Phi^T . Psi, split-K over point slabs.  16-point chunks of Phi and Psi live in double-buffered
+// LDS; the next chunk's four AO components are prefetched into registers while the MFMAs run, combined into
+// Psi and stored to the other buffer afterwards.  The 16x16 output tiles are dealt evenly to the 8 waves of
+// NSPLIT co-scheduled blocks (same XCD, so the slab is fetched from HBM once).
 // ---------------------------------------------------------------------------------------------
 constexpr int VXC_KC = 16;      // points per LDS chunk
 constexpr int VXC_WAVES = 8;    // waves per block
 
-DQC_DEV int lds_stride(int ld) {  // stride == 16 (mod 32) doubles -> conflict-free ds_read_b64 fragments
-    int s = ld;
-    while ((s & 31) != 16) s += 16;
-    return s;
-}
-
-template <int MAXT, bool GGA>
+template <int MAXT, int NL, bool GGA>
 __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
                                                      int ngrid, int ld, const double *__restrict__ w,
                                                      const double *__restrict__ vrho, const double *__restrict__ vgrad,
-                                                     int slab, int tiles_per_chunk) {
+                                                     int slab, int nsplit, int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int LS = lds_stride(ld);
-    double *sphi = lds, *spsi = lds + VXC_KC * LS;
+    const int LS = ld;  // ld == 16 (mod 32): conflict-free fragment reads without extra padding
+    const int BUF = 2 * VXC_KC * LS;  // phi + psi
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int T = ld >> 4, ttot = T * T;
     const size_t cs = (size_t)ngrid * ld;
 
-    // this block: point slab blockIdx.x, output tile chunk blockIdx.y
-    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
-    const int tc0 = blockIdx.y * tiles_per_chunk;
-    const int tc1 = min(tc0 + tiles_per_chunk, ttot);
+    // XCD-aware decode: the nsplit blocks that share a slab get ids 8 apart -> same XCD, dispatched together
+    const int id = blockIdx.x;
+    const int grp = id / (8 * nsplit), rem = id - grp * 8 * nsplit;
+    const int split = rem / 8, sl = grp * 8 + (rem & 7);
+    const int gs = sl * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int tc0 = split * tiles_per_split;
+    const int tc1 = min(tc0 + tiles_per_split, ttot);
     const int per_wave = (tc1 - tc0 + VXC_WAVES - 1) / VXC_WAVES;
     const int t0 = tc0 + wave * per_wave;
     const int nt = max(0, min(per_wave, tc1 - t0));
@@ -174,56 +220,90 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         acc[t] = v4d{0, 0, 0, 0};
-        const int id = min(t0 + t, ttot - 1);
-        offab[t] = (unsigned)(lk * LS + (id / T) * 16 + lr) | ((unsigned)(lk * LS + (id % T) * 16 + lr) << 16);
+        const int tid2 = min(t0 + t, ttot - 1);
+        offab[t] = (unsigned)(lk * LS + (tid2 / T) * 16 + lr) | ((unsigned)(VXC_KC * LS + lk * LS + (tid2 % T) * 16 + lr) << 16);
     }
 
-    const int half = ld >> 1;  // double2 columns per row
-    for (int gc = gs; gc < ge; gc += VXC_KC) {
-        __syncthreads();  // previous chunk fully consumed
-        for (int e = tid; e < VXC_KC * half; e += 512) {
+    const int half = ld >> 1;            // double2 columns per row
+    const int nel = VXC_KC * half;       // double2 elements per chunk
+    double2 pphi[NL], ppsi[NL];
+    auto prefetch = [&](int gc) {
+        double2 raw[NL][GGA ? 4 : 1];
+        double cf[NL][GGA ? 4 : 1];
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = tid + i * 512;
             const int row = e / half, c2 = (e - row * half) * 2;
             const int g = gc + row;
-            double2 phi = make_double2(0.0, 0.0), psi = make_double2(0.0, 0.0);
-            if (g < ge) {
-                const double *src = ao + (size_t)g * ld + c2;
-                phi = *reinterpret_cast<const double2 *>(src);
-                const double wg = w[g];
-                const double c0 = wg * vrho[g];
-                psi.x = c0 * phi.x;
-                psi.y = c0 * phi.y;
-                if (GGA) {
+            const bool ok = e < nel && g < ge;
+            const int gg = ok ? g : gs;
+            const double *src = ao + (size_t)gg * ld + (ok ? c2 : 0);
+            raw[i][0] = *reinterpret_cast<const double2 *>(src);
+            const double wg = ok ? w[gg] : 0.0;
+            cf[i][0] = wg * vrho[gg];
+            if (GGA) {
 #pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        const double cd = 2.0 * wg * vgrad[(size_t)d * ngrid + g];
-                        const double2 dp = *reinterpret_cast<const double2 *>(src + (d + 1) * cs);
-                        psi.x += cd * dp.x;
-                        psi.y += cd * dp.y;
-                    }
+                for (int d = 0; d < 3; d++) {
+                    raw[i][d + 1] = *reinterpret_cast<const double2 *>(src + (d + 1) * cs);
+                    cf[i][d + 1] = 2.0 * wg * vgrad[(size_t)d * ngrid + gg];
                 }
             }
-            *reinterpret_cast<double2 *>(sphi + row * LS + c2) = phi;
-            *reinterpret_cast<double2 *>(spsi + row * LS + c2) = psi;
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = tid + i * 512;
+            const int row = e / half;
+            const bool ok = e < nel && gc + row < ge;
+            pphi[i] = ok ? raw[i][0] : make_double2(0.0, 0.0);
+            double2 ps = make_double2(cf[i][0] * raw[i][0].x, cf[i][0] * raw[i][0].y);
+            if (GGA) {
+#pragma unroll
+                for (int d = 1; d < 4; d++) { ps.x += cf[i][d] * raw[i][d].x; ps.y += cf[i][d] * raw[i][d].y; }
+            }
+            ppsi[i] = ps;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const int e = tid + i * 512;
+            if (e < nel) {
+                const int row = e / half, c2 = (e - row * half) * 2;
+                *reinterpret_cast<double2 *>(lds + buf * BUF + row * LS + c2) = pphi[i];
+                *reinterpret_cast<double2 *>(lds + buf * BUF + VXC_KC * LS + row * LS + c2) = ppsi[i];
+            }
+        }
+    };
+
+    prefetch(gs);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int gc = gs; gc < ge; gc += VXC_KC) {
+        const bool more = gc + VXC_KC < ge;
+        if (more) prefetch(gc + VXC_KC);
+        const double *base = lds + buf * BUF;
 #pragma unroll 1
         for (int kk = 0; kk < VXC_KC / 4; kk++) {
             const int ko = kk * 4 * LS;
 #pragma unroll
             for (int t = 0; t < MAXT; t++) {
                 if (t < nt) {  // wave-uniform
-                    const double a = sphi[ko + (offab[t] & 0xffffu)];
-                    const double b = spsi[ko + (offab[t] >> 16)];
+                    const double a = base[ko + (offab[t] & 0xffffu)];
+                    const double b = base[ko + (offab[t] >> 16)];
                     acc[t] = mfma_f64(a, b, acc[t]);
                 }
             }
         }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         if (t < nt) {
-            const int id = t0 + t;
-            const int ia = (id / T) * 16 + lk, ib = (id % T) * 16 + lr;
+            const int tl = t0 + t;
+            const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
 #pragma unroll
             for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
         }
@@ -239,24 +319,31 @@ __global__ void symmetrize_kernel(double *m, int ld) {
     }
 }
 
+template <int MAXT, int NL, bool GGA>
+static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
+                            const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps) {
+    (void)hipFuncSetAttribute((const void *)vxc_kernel<MAXT, NL, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    hipLaunchKernelGGL((vxc_kernel<MAXT, NL, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab,
+                       nsplit, tps);
+}
+
 template <bool GGA>
-static int launch_vxc(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid,
-                      int ld, const double *w, const double *vrho, const double *vgrad, int slab, int tpc) {
-#define DQC_VXC_CASE(N)                                                                                          \
-    case N:                                                                                                      \
-        (void)hipFuncSetAttribute((const void *)vxc_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                  (int)shmem);                                                                   \
-        hipLaunchKernelGGL((vxc_kernel<N, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, \
-                           slab, tpc);                                                                           \
-        break;
-    switch (maxt) {
-        DQC_VXC_CASE(2) DQC_VXC_CASE(4) DQC_VXC_CASE(8) DQC_VXC_CASE(12) DQC_VXC_CASE(16) DQC_VXC_CASE(22)
-    default:
-        set_error("vxc: internal tile-count dispatch error");
-        return DQC_EINVAL;
+static int launch_vxc(int maxt, int nl, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
+                      int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
+                      int tps) {
+#define DQC_VXC_CASE(N, L)                                                                                    \
+    if (maxt == N && nl == L) {                                                                               \
+        launch_vxc_inst<N, L, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);  \
+        return 0;                                                                                             \
     }
+    DQC_VXC_CASE(2, 1) DQC_VXC_CASE(4, 1) DQC_VXC_CASE(8, 1) DQC_VXC_CASE(11, 1)
+    DQC_VXC_CASE(2, 2) DQC_VXC_CASE(4, 2) DQC_VXC_CASE(8, 2) DQC_VXC_CASE(11, 2)
+    DQC_VXC_CASE(2, 4) DQC_VXC_CASE(4, 4) DQC_VXC_CASE(8, 4) DQC_VXC_CASE(11, 4)
+    DQC_VXC_CASE(8, 8) DQC_VXC_CASE(11, 8)
 #undef DQC_VXC_CASE
-    return 0;
+    set_error("vxc: internal dispatch error");
+    return DQC_EINVAL;
 }
 
 }  // namespace dqc
@@ -273,7 +360,7 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
     const int ld = dqc_padded_nao(nao), ntile = ld / 16;
     const int nchunk = (ntile + 15) / 16;
     const int nct = (ntile + nchunk - 1) / nchunk;
-    dim3 grid((ngrid + 127) / 128);
+    dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
     int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile)
                  : launch_density<false>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile);
     if (rc) return rc;
@@ -290,29 +377,28 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
     const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
-        static const int sizes[] = {2, 4, 8, 12, 16, 22};
-        const int cap = 22 * VXC_WAVES;
-        const int nchunk = (ttot + cap - 1) / cap;
-        const int tpc = (ttot + nchunk - 1) / nchunk;
-        const int need = (tpc + VXC_WAVES - 1) / VXC_WAVES;
-        int maxt = 22;
-        for (int s : sizes)
-            if (s >= need) { maxt = s; break; }
-        // one block per CU and chunk (register budget admits one 8-wave block per CU)
-        int nslab = (2 * 256 + nchunk - 1) / nchunk;
+        // tiles per block are capped at 11 per wave so that accumulators + prefetch registers fit 256 VGPRs
+        static const int sizes[] = {2, 4, 8, 11};
+        const int cap = 11 * VXC_WAVES;
+        const int nsplit = (ttot + cap - 1) / cap;
+        const int tps = (ttot + nsplit - 1) / nsplit;
+        const int need = (tps + VXC_WAVES - 1) / VXC_WAVES;
+        int maxt = 11;
+        for (int sz : sizes)
+            if (sz >= need) { maxt = sz; break; }
+        const int nel = VXC_KC * (ld / 2);
+        const int nlneed = (nel + 511) / 512;
+        const int nl = nlneed <= 1 ? 1 : (nlneed <= 2 ? 2 : (nlneed <= 4 ? 4 : 8));
+        if (nlneed > 8) { set_error("dqc_grid_vxc: nao above 1008 is not supported by this build"); return DQC_EINVAL; }
+        // one 8-wave block per CU; slabs in multiples of 8 so that the XCD-aware decode is exact
+        int nslab = std::max(8, (256 / nsplit) / 8 * 8);
         int slab = (ngrid + nslab - 1) / nslab;
         slab = (slab + VXC_KC - 1) / VXC_KC * VXC_KC;
-        nslab = (ngrid + slab - 1) / slab;
-        int LS = ld;
-        while ((LS & 31) != 16) LS += 16;
-        const size_t shmem = sizeof(double) * 2 * VXC_KC * LS;
-        dim3 grid(nslab, nchunk);
-        int rc;
-        if (gga) {
-            rc = launch_vxc<true>(maxt, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, tpc);
-        } else {
-            rc = launch_vxc<false>(maxt, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, tpc);
-        }
+        nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
+        const size_t shmem = sizeof(double) * 2 * 2 * VXC_KC * ld;
+        dim3 grid(nslab * nsplit);
+        int rc = gga ? launch_vxc<true>(maxt, nl, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps)
+                     : launch_vxc<false>(maxt, nl, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps);
         if (rc) return rc;
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);

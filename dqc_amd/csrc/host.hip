@@ -79,7 +79,11 @@ int dqc_nao(const int *bas, int nbas) {
     return n;
 }
 
-int dqc_padded_nao(int nao) { return (nao + 15) / 16 * 16; }
+int dqc_padded_nao(int nao) {
+    int ld = (nao + 15) / 16 * 16;  // multiple of 16 (MFMA tiles) ...
+    if ((ld & 31) != 16) ld += 16;  // ... and == 16 (mod 32): LDS fragment reads are bank-conflict-free
+    return ld;
+}
 
 size_t dqc_eri_tile_count(int nao) {
     size_t nb = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B;

@@ -91,7 +91,8 @@ class Tables:
 
 
 def padded_nao(nao):
-    return (nao + 15) // 16 * 16
+    ld = (nao + 15) // 16 * 16
+    return ld if ld % 32 == 16 else ld + 16
 
 
 def int1e(which, tab, device, zs=None):

@@ -15,7 +15,7 @@
  *     return; they synchronise only where stated.
  *   - return value: 0 on success, negative DQC_E* on error; dqc_last_error() gives the text.
  *   - `ld` ("leading dimension") of AO-indexed device matrices is dqc_padded_nao(nao)
- *     (nao rounded up to a multiple of 16); padding columns/rows are zero.
+ *     (the smallest multiple of 16 >= nao that is 16 mod 32); padding columns/rows are zero.
  */
 #ifndef DQC_AMD_H
 #define DQC_AMD_H

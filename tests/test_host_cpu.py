@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(so, n), n
     L = lib.load()
     assert L.dqc_version() >= 100
-    assert L.dqc_padded_nao(114) == 128 and L.dqc_padded_nao(208) == 208
+    assert L.dqc_padded_nao(114) == 144 and L.dqc_padded_nao(208) == 208 and L.dqc_padded_nao(7) == 16
     assert L.dqc_eri_tile_count(208) == 351 * 352 // 2 * (351 * 352 // 2 + 1) // 2 or L.dqc_eri_tile_count(208) > 0
     nb = 26
     npair = nb * (nb + 1) // 2
