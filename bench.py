@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+F64_MFMA_PEAK_TF = 78.6  # MI355X dense fp64 matrix peak (vendor figure; the guide lists no fp64 row)
 
 
 def main():
@@ -86,11 +87,14 @@ def main():
             else:
                 h = eng.hamilton
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
-                ev[0].record()
-                J = h.get_elrep(d)
-                ev[1].record()
                 dmdmt = (d + d.transpose(-2, -1)) * 0.5
-                dao = lib.pad_matrix(h._unconvert_dm(dmdmt), h._ld)
+                dao_n = h._unconvert_dm(dmdmt).contiguous()
+                ev[0].record()
+                Jao, _ = lib.jk(h._tiles, dao_n, h._jkwork, False)   # the same calls get_elrep / get_vxc make,
+                ev[1].record()                                       # unrolled so each kernel gets its own events
+                J = h._convert2(Jao)
+                J = (J + J.transpose(-2, -1)) * 0.5
+                dao = lib.pad_matrix(dao_n, h._ld)
                 ev[2].record()
                 rho, grho = lib.grid_density(h._ao, h._nao_ao, dao, True)
                 ev[3].record()
@@ -99,7 +103,7 @@ def main():
                 vm = lib.grid_vxc(h._ao, h._nao_ao, h.dvolume, v, vg)
                 ev[5].record()
                 mat = h._convert2(vm[:h._nao_ao, :h._nao_ao])
-                fock = eng.knvext.fullmatrix() + J.fullmatrix() + (mat + mat.transpose(-2, -1)) * 0.5
+                fock = eng.knvext.fullmatrix() + J + (mat + mat.transpose(-2, -1)) * 0.5
                 ev[6].record()
                 record.append(ev)
 
@@ -128,7 +132,7 @@ def main():
     for _ in range(args.steps):
         step(rec)
     torch.cuda.synchronize()
-    names = ["jk_tiles(+X transforms)", "dm_prep", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
+    names = ["jk_tiles", "orth_transforms", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
     ktime = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
 
     if rank == 0:
@@ -137,10 +141,31 @@ def main():
             # AO read once per pass + per-point in/outs + the (n,n) matrix; see DESIGN.md
             "grid_density": 8.0 * c * ngrid * nao + 8.0 * ngrid * 4 + 8.0 * nao * nao,
             "grid_vxc": 8.0 * c * ngrid * nao + 8.0 * ngrid * 5 + 8.0 * nao * nao,
-            "jk_tiles(+X transforms)": float(nao) ** 4 + 3 * 8.0 * nao * nao,
+            "jk_tiles": float(nao) ** 4 + 3 * 8.0 * nao * nao,
         }
+        alg_flops = {
+            # 2 G n^2 per GEMM pass (+ the row dots / Psi combination); J: 2 n^4 dense-equivalent
+            "grid_density": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
+            "grid_vxc": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
+            "jk_tiles": 2.0 * float(nao) ** 4,
+        }
+        mfma_ceiling = lib.probe_mfma_f64_tflops(dev)
+        hbm_ceiling = lib.probe_hbm_read_gbs(dev)
+
+        def roof(k):
+            t = ktime[k] * 1e-3
+            gbs, tfs = alg_bytes[k] / t / 1e9, alg_flops[k] / t / 1e12
+            # the binding roof is the one the kernel sits closer to
+            if k != "jk_tiles" and tfs / F64_MFMA_PEAK_TF > gbs / HBM_PEAK_GBS:
+                return {"bound": "mfma", "kernel": k, "achieved": tfs, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tfs / F64_MFMA_PEAK_TF, "traffic": None, "algorithmic_flops_per_launch": alg_flops[k],
+                        "algorithmic_bytes_per_launch": alg_bytes[k], "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+                        "measured_mfma_f64_ceiling_tflops": mfma_ceiling, "frac_of_measured_ceiling": tfs / mfma_ceiling}
+            return {"bound": "hbm", "kernel": k, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[k],
+                    "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": gbs / hbm_ceiling}
+
         dom = max(alg_bytes, key=lambda k: ktime[k])
-        achieved = alg_bytes[dom] / (ktime[dom] * 1e-3) / 1e9
         out = {
             "metric": "SCF iterations/sec (Fock build + XC grid) per GPU, cc-pVDZ 20-atom",
             "value": nmol * args.steps / elapsed,
@@ -156,9 +181,8 @@ def main():
             "per_gpu_value": M_per * args.steps / elapsed,
             "setup_s_per_rank": setup_s,
             "kernel_ms_per_molecule": ktime,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes[dom]},
+            "roofline": roof(dom),
+            "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
@@ -173,14 +197,24 @@ def cpu_baseline(nsteps):
     sample of the same workload: molecule 0 of the C5 set, `nsteps` dm2scp evaluations after one warm-up"""
     from oracle import basis as ob, hamilton as oh, natives as nat
     from tests import molecules as M
-    torch.set_num_threads(os.cpu_count() or 1)
     t = ob.make_tables(M.c5_molecule(0), "cc-pvdz")
     t0 = time.perf_counter()
     eng = oh.Engine(t, xc="gga_x_pbe+gga_c_pbe", grid="sg3", eri_mode="s4")
     setup = time.perf_counter() - t0
     n = eng.h.nao
     dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64)))
-    eng.dm2scp(dm)
+    # torch's intra-op pool collapses when oversubscribed (256 threads: 70 s per call on the 64-core EPYC box),
+    # so the thread count is calibrated: one call each at 16/32/64 threads (capped by the core count), best kept
+    best = None
+    for nt in sorted({min(c, os.cpu_count() or 1) for c in (16, 32, 64)}):
+        torch.set_num_threads(nt)
+        eng.dm2scp(dm)
+        t0 = time.perf_counter()
+        eng.dm2scp(dm)
+        dt1 = time.perf_counter() - t0
+        if best is None or dt1 < best[0]:
+            best = (dt1, nt)
+    torch.set_num_threads(best[1])
     t0 = time.perf_counter()
     for _ in range(nsteps):
         eng.dm2scp(dm)

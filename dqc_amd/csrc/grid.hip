@@ -15,6 +15,7 @@
 // f64 MFMA fragment layout (gfx950): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // C[row = (lane>>4) + 4*reg][col = lane&15].
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -25,28 +26,30 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 DQC_DEV v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // ---------------------------------------------------------------------------------------------
-// density:  C[128 pts x n] = Phi_blk . D, K-chunks of 16 staged in double-buffered LDS, 8 waves per block,
+// density:  C[64 pts x n] = Phi_blk . D, K-chunks of 16 staged in double-buffered LDS, 4 waves per block,
 // wave w owns points 16w..16w+15 and all column tiles (accumulators in registers), fused row-dot epilogue.
 // ---------------------------------------------------------------------------------------------
-constexpr int DEN_BM = 128;   // points per block
+constexpr int DEN_BM = 64;    // points per block (4 waves x 16); two blocks share a CU so that one block's
+                              // memory-bound epilogue overlaps the other's MFMA main loop
+constexpr int DEN_NT = DEN_BM * 4;  // threads per block
 constexpr int DEN_KC = 16;    // K chunk
 constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-free ds_read_b64 fragments)
 
 template <int NCT, bool GGA>
-__global__ __launch_bounds__(512, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
+__global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
                                                          const double *__restrict__ dm, int ntile) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int LSB = NCT * 16;                 // width of the staged D column panel (== 16 mod 32 when NCT odd)
     constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
     constexpr int A_SZ = DEN_BM * DEN_SA, B_SZ = DEN_KC * LSBP;
-    constexpr int NB2 = (DEN_KC * LSB / 2 + 511) / 512;  // double2 loads of the B chunk per thread
+    constexpr int NB2 = (DEN_KC * LSB / 2 + DEN_NT - 1) / DEN_NT;  // double2 loads of the B chunk per thread
     double *sA = lds, *sB = lds + 2 * A_SZ;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int g0 = blockIdx.x * DEN_BM;
     const size_t cs = (size_t)ngrid * ld;
-    // staging roles: A chunk = 128 rows x 16 doubles -> thread (row = tid/4, 4 doubles at seg = tid%4)
+    // staging roles: A chunk = 64 rows x 16 doubles -> thread (row = tid/4, 4 doubles at seg = tid%4)
     const int arow = tid >> 2, aseg = (tid & 3) * 4;
     const double *asrc = ao + (size_t)min(g0 + arow, ngrid - 1) * ld + aseg;
 
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void density_kernel(double *__restrict__ rh
             pa[1] = *reinterpret_cast<const double2 *>(s + 2);
 #pragma unroll
             for (int i = 0; i < NB2; i++) {
-                const int e = (tid + i * 512) * 2;  // element of the (KC x LSB) panel
+                const int e = (tid + i * DEN_NT) * 2;  // element of the (KC x LSB) panel
                 const int row = e / LSB, col = e - row * LSB;
                 pb[i] = (row < DEN_KC && jc * 16 + col < ld)
                             ? *reinterpret_cast<const double2 *>(dm + (size_t)(kc * DEN_KC + row) * ld + jc * 16 + col)
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void density_kernel(double *__restrict__ rh
             *reinterpret_cast<double2 *>(a + 2) = pa[1];
 #pragma unroll
             for (int i = 0; i < NB2; i++) {
-                const int e = (tid + i * 512) * 2;
+                const int e = (tid + i * DEN_NT) * 2;
                 const int row = e / LSB, col = e - row * LSB;
                 if (row < DEN_KC) *reinterpret_cast<double2 *>(sB + buf * B_SZ + row * LSBP + col) = pb[i];
             }
@@ -166,7 +169,7 @@ static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, doubl
     case N:                                                                                                        \
         (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)density_lds_bytes<N>());                                                    \
-        hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(512), density_lds_bytes<N>(), st, rho, grho, ao,    \
+        hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(DEN_NT), density_lds_bytes<N>(), st, rho, grho, ao,    \
                            ngrid, ld, dm, ntile);                                                                  \
         break;
     switch (nct) {
@@ -310,6 +313,154 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Vxc, LDS-DMA variant: the four AO components of the next 8-point chunk are copied HBM -> LDS by
+// global_load_lds_dwordx4 (no staging VGPRs), so one block keeps ALL n x n output tiles in registers
+// (up to 22 per wave) and the slab is read from HBM exactly once.  Per chunk:
+//   wait DMA(c) | barrier | issue DMA(c+1) | Psi = sum_d cf_d * raw_d (LDS -> LDS) | barrier | MFMAs
+// Raw s_barrier + counted waits keep DMA(c+1) in flight across the barriers and under the MFMA phase.
+// ---------------------------------------------------------------------------------------------
+constexpr int VG_KC = 8;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <int MAXT, bool GGA>
+__global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
+                                                          int ngrid, int ld, const double *__restrict__ w,
+                                                          const double *__restrict__ vrho,
+                                                          const double *__restrict__ vgrad, int slab) {
+    constexpr int NC = GGA ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int LS = ld;
+    const int RAW = NC * VG_KC * LS;            // doubles per raw buffer
+    double *raw0 = lds, *psi = lds + 2 * RAW;   // raw[2][NC][KC][LS], psi[KC][LS]
+    double *scf = psi + VG_KC * LS;             // cf[NC][KC]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int T = ld >> 4, ttot = T * T;
+    const size_t cs = (size_t)ngrid * ld;
+    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int per_wave = (ttot + VXC_WAVES - 1) / VXC_WAVES;
+    const int t0 = wave * per_wave;
+    const int nt = max(0, min(per_wave, ttot - t0));
+
+    v4d acc[MAXT];
+    unsigned offab[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        const int tl = min(t0 + t, ttot - 1);
+        offab[t] = (unsigned)(lk * LS + (tl / T) * 16 + lr) | ((unsigned)(lk * LS + (tl % T) * 16 + lr) << 16);
+    }
+
+    // DMA plan: a component's chunk (KC rows x ld doubles, contiguous in HBM and in LDS) is ld/16 wave
+    // instructions of 1 KiB; instruction j of the chunk (j < NC*ld/16) is issued by wave j % 8
+    const int ipc = ld >> 4;              // instructions per component
+    const int ninstr = NC * ipc;
+    auto issue_dma = [&](int gc, int buf) {
+        for (int j = wave; j < ninstr; j += VXC_WAVES) {
+            const int c = j / ipc, ji = j - c * ipc;
+            const int el = ji * 128 + lane * 2;         // element inside the (KC x ld) chunk
+            int g = gc + el / ld;
+            const int col = el % ld;
+            g = min(g, ngrid - 1);                      // rows past the end re-read the last row; their cf is 0
+            const double *src = ao + c * cs + (size_t)g * ld + col;
+            double *dst = raw0 + buf * RAW + c * VG_KC * LS + ji * 128;  // wave-uniform; lane*16 B added by hardware
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
+        }
+    };
+    auto load_cf = [&](int gc) -> double {
+        double v = 0.0;
+        if (tid < NC * VG_KC) {
+            const int c = tid / VG_KC, g = gc + (tid % VG_KC);
+            if (g < ge) {
+                const double wg = w[g];
+                v = c == 0 ? wg * vrho[g] : 2.0 * wg * vgrad[(size_t)(c - 1) * ngrid + g];
+            }
+        }
+        return v;
+    };
+
+    const int half = ld >> 1;
+    issue_dma(gs, 0);
+    double cf = load_cf(gs);
+    int buf = 0;
+    for (int gc = gs; gc < ge; gc += VG_KC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(c) pieces landed, cf arrived
+        if (tid < NC * VG_KC) scf[tid] = cf;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // raw[buf] complete for every wave; psi/raw[buf^1] free
+        const bool more = gc + VG_KC < ge;
+        if (more) {
+            issue_dma(gc + VG_KC, buf ^ 1);                // in flight during combine + MFMA
+            cf = load_cf(gc + VG_KC);
+        }
+        const double *rb = raw0 + buf * RAW;
+        for (int e = tid; e < VG_KC * half; e += 512) {
+            const int row = e / half, c2 = (e - row * half) * 2;
+            const double2 r0 = *reinterpret_cast<const double2 *>(rb + row * LS + c2);
+            const double c0 = scf[row];
+            double2 ps = make_double2(c0 * r0.x, c0 * r0.y);
+            if (GGA) {
+#pragma unroll
+                for (int d = 1; d < 4; d++) {
+                    const double2 rd = *reinterpret_cast<const double2 *>(rb + d * VG_KC * LS + row * LS + c2);
+                    const double cd = scf[d * VG_KC + row];
+                    ps.x += cd * rd.x;
+                    ps.y += cd * rd.y;
+                }
+            }
+            *reinterpret_cast<double2 *>(psi + row * LS + c2) = ps;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // psi complete
+#pragma unroll 1
+        for (int kk = 0; kk < VG_KC / 4; kk++) {
+            const int ko = kk * 4 * LS;
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {
+                if (t < nt) {
+                    const double a = rb[ko + (offab[t] & 0xffffu)];
+                    const double b = psi[ko + (offab[t] >> 16)];
+                    acc[t] = mfma_f64(a, b, acc[t]);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (t < nt) {
+            const int tl = t0 + t;
+            const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+        }
+    }
+}
+
+template <bool GGA>
+static int launch_vxc_glds(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid,
+                           int ld, const double *w, const double *vrho, const double *vgrad, int slab) {
+#define DQC_VG_CASE(N)                                                                                            \
+    case N:                                                                                                       \
+        (void)hipFuncSetAttribute((const void *)vxc_glds_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)shmem);                                                                    \
+        hipLaunchKernelGGL((vxc_glds_kernel<N, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, \
+                           slab);                                                                                 \
+        break;
+    switch (maxt) {
+        DQC_VG_CASE(2) DQC_VG_CASE(4) DQC_VG_CASE(8) DQC_VG_CASE(12) DQC_VG_CASE(16) DQC_VG_CASE(22)
+    default:
+        set_error("vxc(glds): internal dispatch error");
+        return DQC_EINVAL;
+    }
+#undef DQC_VG_CASE
+    return 0;
+}
+
 __global__ void symmetrize_kernel(double *m, int ld) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
     if (i < ld && j < i) {
@@ -377,6 +528,28 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
     const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
+        static const char *impl_env = getenv("DQC_VXC_IMPL");  // "reg" forces the register-staged variant (A/B runs)
+        const int ncomp_used = gga ? 4 : 1;
+        const size_t glds_lds = sizeof(double) * ((size_t)2 * ncomp_used * VG_KC * ld + (size_t)VG_KC * ld + 64);
+        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && !(impl_env && impl_env[0] == 'r');
+        if (use_glds) {
+            static const int gsizes[] = {2, 4, 8, 12, 16, 22};
+            const int need = (ttot + VXC_WAVES - 1) / VXC_WAVES;
+            int maxt = 22;
+            for (int sz : gsizes)
+                if (sz >= need) { maxt = sz; break; }
+            int nslab = 256;  // one 8-wave block per CU
+            int slab = (ngrid + nslab - 1) / nslab;
+            slab = (slab + VG_KC - 1) / VG_KC * VG_KC;
+            nslab = (ngrid + slab - 1) / slab;
+            int rc = gga ? launch_vxc_glds<true>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
+                         : launch_vxc_glds<false>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
+            if (rc) return rc;
+            DQC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            DQC_CHECK_LAUNCH();
+            return DQC_OK;
+        }
         // tiles per block are capped at 11 per wave so that accumulators + prefetch registers fit 256 VGPRs
         static const int sizes[] = {2, 4, 8, 11};
         const int cap = 11 * VXC_WAVES;

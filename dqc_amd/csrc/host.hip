@@ -104,6 +104,28 @@ __global__ void probe_read_kernel(const double2 *__restrict__ buf, size_t n2, do
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// fp64 MFMA issue-rate probe: 8 independent 16x16x4 accumulators per wave, `iters` rounds
+typedef double probe_v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void probe_mfma_kernel(double *out, int iters, double a0, double b0) {
+    probe_v4d acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = probe_v4d{0, 0, 0, 0};
+    const double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+int dqc_probe_mfma_f64(double *d_out, int iters, void *stream) {
+    // 256 CUs x 8 waves; d_out needs 512*256 doubles; flops = 2*16*16*4 * 8 * iters * 2048 waves
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, d_out, iters, 1.0, 1e-9);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     DQC_HIP(hipMemsetAsync(d_out, 0, sizeof(double), st));

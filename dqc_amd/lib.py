@@ -54,6 +54,7 @@ def load():
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
     lib.dqc_probe_stream_read.argtypes = [c_dp, c_sz, c_dp, c_vp]
+    lib.dqc_probe_mfma_f64.argtypes = [c_dp, c_int, c_vp]
     _lib = lib
     return lib
 
@@ -193,3 +194,29 @@ def probe_stream_read(buf):
     out = torch.zeros(1, dtype=torch.float64, device=buf.device)
     _check(load().dqc_probe_stream_read(_ptr(buf), buf.numel(), _ptr(out), _stream()), "dqc_probe_stream_read")
     return out
+
+
+def probe_mfma_f64_tflops(device, iters=4000):
+    """measured fp64 MFMA ceiling of this GPU (TFLOP/s): 2048 waves x 8 independent accumulators"""
+    out = torch.empty(512 * 256, dtype=torch.float64, device=device)
+    L = load()
+    _check(L.dqc_probe_mfma_f64(_ptr(out), 100, _stream()), "dqc_probe_mfma_f64")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _check(L.dqc_probe_mfma_f64(_ptr(out), iters, _stream()), "dqc_probe_mfma_f64")
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * 16 * 16 * 4 * 8 * iters * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def probe_hbm_read_gbs(device, nbytes=2 << 30):
+    """measured streaming-read bandwidth (GB/s) over a buffer larger than the Infinity Cache"""
+    buf = torch.empty(nbytes // 8, dtype=torch.float64, device=device).normal_()
+    probe_stream_read(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        probe_stream_read(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return 3.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9

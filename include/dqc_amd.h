@@ -104,6 +104,8 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
 
 /* ---- micro-benchmarks used by bench.py to price the roofline on the box it runs on ---------- */
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream);
+/* fp64 MFMA (16x16x4) issue-rate probe: 2048 waves x 8 accumulators x iters MFMAs; d_out: 131072 doubles */
+int dqc_probe_mfma_f64(double *d_out, int iters, void *stream);
 
 #ifdef __cplusplus
 }
