@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             for (int kk = 0; kk < DEN_KC / 4; kk++) {
                 const double av = a[kk * 4];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ct++)
-                    if (ct < nvalid) acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
+                for (int ct = 0; ct < NCT; ct++)  // straight-line: panels past ld hold zeros in LDS
+                    acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
             }
             if (kc + 1 < nk) stage(buf ^ 1);
             __syncthreads();
@@ -193,14 +193,14 @@ static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, doubl
 constexpr int VXC_KC = 16;      // points per LDS chunk
 constexpr int VXC_WAVES = 8;    // waves per block
 
-template <int MAXT, int NL, bool GGA>
+template <int MAXT, int NL, int KCH, bool GGA>
 __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
                                                      int ngrid, int ld, const double *__restrict__ w,
                                                      const double *__restrict__ vrho, const double *__restrict__ vgrad,
                                                      int slab, int nsplit, int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int LS = ld;  // ld == 16 (mod 32): conflict-free fragment reads without extra padding
-    const int BUF = 2 * VXC_KC * LS;  // phi + psi
+    const int BUF = 2 * KCH * LS;  // phi + psi
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int T = ld >> 4, ttot = T * T;
@@ -224,56 +224,50 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
     for (int t = 0; t < MAXT; t++) {
         acc[t] = v4d{0, 0, 0, 0};
         const int tid2 = min(t0 + t, ttot - 1);
-        offab[t] = (unsigned)(lk * LS + (tid2 / T) * 16 + lr) | ((unsigned)(VXC_KC * LS + lk * LS + (tid2 % T) * 16 + lr) << 16);
+        offab[t] = (unsigned)(lk * LS + (tid2 / T) * 16 + lr) | ((unsigned)(KCH * LS + lk * LS + (tid2 % T) * 16 + lr) << 16);
     }
 
-    const int half = ld >> 1;            // double2 columns per row
-    const int nel = VXC_KC * half;       // double2 elements per chunk
-    double2 pphi[NL], ppsi[NL];
+    // staging roles: a thread serves ONE row of the chunk (row = tid / TPR) and up to NL double2 columns of it, so
+    // its four Psi coefficients are loaded once; the raw AO loads stay in flight during the MFMA phase and are
+    // only combined into Psi when they are written to LDS afterwards.
+    constexpr int TPR = 512 / KCH;       // threads per row
+    const int prow = tid / TPR, pcol = tid % TPR;
+    double2 raw[NL][GGA ? 4 : 1];
+    double cf[GGA ? 4 : 1];
+    bool rowok = false;
     auto prefetch = [&](int gc) {
-        double2 raw[NL][GGA ? 4 : 1];
-        double cf[NL][GGA ? 4 : 1];
+        const int g = gc + prow;
+        rowok = g < ge;
+        const int gg = rowok ? g : gs;
+        const double wg = rowok ? w[gg] : 0.0;
+        cf[0] = wg * vrho[gg];
+        if (GGA) {
 #pragma unroll
-        for (int i = 0; i < NL; i++) {
-            const int e = tid + i * 512;
-            const int row = e / half, c2 = (e - row * half) * 2;
-            const int g = gc + row;
-            const bool ok = e < nel && g < ge;
-            const int gg = ok ? g : gs;
-            const double *src = ao + (size_t)gg * ld + (ok ? c2 : 0);
-            raw[i][0] = *reinterpret_cast<const double2 *>(src);
-            const double wg = ok ? w[gg] : 0.0;
-            cf[i][0] = wg * vrho[gg];
-            if (GGA) {
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    raw[i][d + 1] = *reinterpret_cast<const double2 *>(src + (d + 1) * cs);
-                    cf[i][d + 1] = 2.0 * wg * vgrad[(size_t)d * ngrid + gg];
-                }
-            }
+            for (int d = 0; d < 3; d++) cf[d + 1] = 2.0 * wg * vgrad[(size_t)d * ngrid + gg];
         }
+        const double *src = ao + (size_t)gg * ld;
 #pragma unroll
         for (int i = 0; i < NL; i++) {
-            const int e = tid + i * 512;
-            const int row = e / half;
-            const bool ok = e < nel && gc + row < ge;
-            pphi[i] = ok ? raw[i][0] : make_double2(0.0, 0.0);
-            double2 ps = make_double2(cf[i][0] * raw[i][0].x, cf[i][0] * raw[i][0].y);
-            if (GGA) {
+            const int c2 = (pcol + i * TPR) * 2;
+            const int cc = c2 < ld ? c2 : 0;
 #pragma unroll
-                for (int d = 1; d < 4; d++) { ps.x += cf[i][d] * raw[i][d].x; ps.y += cf[i][d] * raw[i][d].y; }
-            }
-            ppsi[i] = ps;
+            for (int d = 0; d < (GGA ? 4 : 1); d++) raw[i][d] = *reinterpret_cast<const double2 *>(src + d * cs + cc);
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
-            const int e = tid + i * 512;
-            if (e < nel) {
-                const int row = e / half, c2 = (e - row * half) * 2;
-                *reinterpret_cast<double2 *>(lds + buf * BUF + row * LS + c2) = pphi[i];
-                *reinterpret_cast<double2 *>(lds + buf * BUF + VXC_KC * LS + row * LS + c2) = ppsi[i];
+            const int c2 = (pcol + i * TPR) * 2;
+            if (c2 < ld) {
+                double2 ph = raw[i][0];
+                double2 ps = make_double2(cf[0] * ph.x, cf[0] * ph.y);
+                if (GGA) {
+#pragma unroll
+                    for (int d = 1; d < 4; d++) { ps.x += cf[d] * raw[i][d].x; ps.y += cf[d] * raw[i][d].y; }
+                }
+                if (!rowok) ph = make_double2(0.0, 0.0);
+                *reinterpret_cast<double2 *>(lds + buf * BUF + prow * LS + c2) = ph;
+                *reinterpret_cast<double2 *>(lds + buf * BUF + KCH * LS + prow * LS + c2) = ps;
             }
         }
     };
@@ -282,20 +276,18 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
     stage(0);
     __syncthreads();
     int buf = 0;
-    for (int gc = gs; gc < ge; gc += VXC_KC) {
-        const bool more = gc + VXC_KC < ge;
-        if (more) prefetch(gc + VXC_KC);
+    for (int gc = gs; gc < ge; gc += KCH) {
+        const bool more = gc + KCH < ge;
+        if (more) prefetch(gc + KCH);
         const double *base = lds + buf * BUF;
 #pragma unroll 1
-        for (int kk = 0; kk < VXC_KC / 4; kk++) {
+        for (int kk = 0; kk < KCH / 4; kk++) {
             const int ko = kk * 4 * LS;
 #pragma unroll
-            for (int t = 0; t < MAXT; t++) {
-                if (t < nt) {  // wave-uniform
-                    const double a = base[ko + (offab[t] & 0xffffu)];
-                    const double b = base[ko + (offab[t] >> 16)];
-                    acc[t] = mfma_f64(a, b, acc[t]);
-                }
+            for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
+                const double a = base[ko + (offab[t] & 0xffffu)];
+                const double b = base[ko + (offab[t] >> 16)];
+                acc[t] = mfma_f64(a, b, acc[t]);
             }
         }
         if (more) stage(buf ^ 1);
@@ -420,12 +412,10 @@ __global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ v
         for (int kk = 0; kk < VG_KC / 4; kk++) {
             const int ko = kk * 4 * LS;
 #pragma unroll
-            for (int t = 0; t < MAXT; t++) {
-                if (t < nt) {
-                    const double a = rb[ko + (offab[t] & 0xffffu)];
-                    const double b = psi[ko + (offab[t] >> 16)];
-                    acc[t] = mfma_f64(a, b, acc[t]);
-                }
+            for (int t = 0; t < MAXT; t++) {  // straight-line; clamped duplicate tiles are discarded at the end
+                const double a = rb[ko + (offab[t] & 0xffffu)];
+                const double b = psi[ko + (offab[t] >> 16)];
+                acc[t] = mfma_f64(a, b, acc[t]);
             }
         }
         buf ^= 1;
@@ -470,23 +460,27 @@ __global__ void symmetrize_kernel(double *m, int ld) {
     }
 }
 
-template <int MAXT, int NL, bool GGA>
+template <int MAXT, int NL, int KCH, bool GGA>
 static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                             const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps) {
-    (void)hipFuncSetAttribute((const void *)vxc_kernel<MAXT, NL, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)vxc_kernel<MAXT, NL, KCH, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)shmem);
-    hipLaunchKernelGGL((vxc_kernel<MAXT, NL, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab,
+    hipLaunchKernelGGL((vxc_kernel<MAXT, NL, KCH, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab,
                        nsplit, tps);
 }
 
 template <bool GGA>
-static int launch_vxc(int maxt, int nl, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
+static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                       int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
                       int tps) {
-#define DQC_VXC_CASE(N, L)                                                                                    \
-    if (maxt == N && nl == L) {                                                                               \
-        launch_vxc_inst<N, L, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);  \
-        return 0;                                                                                             \
+#define DQC_VXC_CASE(N, L)                                                                                        \
+    if (maxt == N && nl == L && kch == 16) {                                                                      \
+        launch_vxc_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);  \
+        return 0;                                                                                                 \
+    }                                                                                                             \
+    if (maxt == N && nl == L && kch == 8) {                                                                       \
+        launch_vxc_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);   \
+        return 0;                                                                                                 \
     }
     DQC_VXC_CASE(2, 1) DQC_VXC_CASE(4, 1) DQC_VXC_CASE(8, 1) DQC_VXC_CASE(11, 1)
     DQC_VXC_CASE(2, 2) DQC_VXC_CASE(4, 2) DQC_VXC_CASE(8, 2) DQC_VXC_CASE(11, 2)
@@ -559,19 +553,21 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
         int maxt = 11;
         for (int sz : sizes)
             if (sz >= need) { maxt = sz; break; }
-        const int nel = VXC_KC * (ld / 2);
-        const int nlneed = (nel + 511) / 512;
+        // chunk depth: 16 points while the double-buffered (phi, psi) chunk fits LDS, else 8
+        const int kch = (sizeof(double) * 2 * 2 * 16 * (size_t)ld <= 150 * 1024) ? 16 : 8;
+        const int tpr = 512 / kch;  // threads per chunk row
+        const int nlneed = (ld / 2 + tpr - 1) / tpr;  // double2 columns per thread
         const int nl = nlneed <= 1 ? 1 : (nlneed <= 2 ? 2 : (nlneed <= 4 ? 4 : 8));
         if (nlneed > 8) { set_error("dqc_grid_vxc: nao above 1008 is not supported by this build"); return DQC_EINVAL; }
         // one 8-wave block per CU; slabs in multiples of 8 so that the XCD-aware decode is exact
         int nslab = std::max(8, (256 / nsplit) / 8 * 8);
         int slab = (ngrid + nslab - 1) / nslab;
-        slab = (slab + VXC_KC - 1) / VXC_KC * VXC_KC;
+        slab = (slab + kch - 1) / kch * kch;
         nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
-        const size_t shmem = sizeof(double) * 2 * 2 * VXC_KC * ld;
+        const size_t shmem = sizeof(double) * 2 * 2 * kch * ld;
         dim3 grid(nslab * nsplit);
-        int rc = gga ? launch_vxc<true>(maxt, nl, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps)
-                     : launch_vxc<false>(maxt, nl, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps);
+        int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps)
+                     : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps);
         if (rc) return rc;
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
