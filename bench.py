@@ -149,6 +149,15 @@ def main():
             "grid_vxc": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
             "jk_tiles": 2.0 * float(nao) ** 4,
         }
+        # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (bench.py cannot sample
+        # counters itself); only used when the workload matches
+        traffic = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj["workload"] == {"nao": nao, "ngrid": ngrid, "xc": "gga"}:
+                traffic = tj["hbm_read_bytes_per_launch"]
+        except Exception:
+            pass
         mfma_ceiling = lib.probe_mfma_f64_tflops(dev)
         hbm_ceiling = lib.probe_hbm_read_gbs(dev)
 
@@ -158,11 +167,11 @@ def main():
             # the binding roof is the one the kernel sits closer to
             if k != "jk_tiles" and tfs / F64_MFMA_PEAK_TF > gbs / HBM_PEAK_GBS:
                 return {"bound": "mfma", "kernel": k, "achieved": tfs, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": tfs / F64_MFMA_PEAK_TF, "traffic": None, "algorithmic_flops_per_launch": alg_flops[k],
+                        "frac": tfs / F64_MFMA_PEAK_TF, "traffic": traffic.get(k), "algorithmic_flops_per_launch": alg_flops[k],
                         "algorithmic_bytes_per_launch": alg_bytes[k], "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
                         "measured_mfma_f64_ceiling_tflops": mfma_ceiling, "frac_of_measured_ceiling": tfs / mfma_ceiling}
             return {"bound": "hbm", "kernel": k, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes[k],
+                    "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(k), "algorithmic_bytes_per_launch": alg_bytes[k],
                     "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": gbs / hbm_ceiling}
 
         dom = max(alg_bytes, key=lambda k: ktime[k])

@@ -51,5 +51,19 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """perf-bisection builds: grid.hip recompiled with -D<define>, linked as libdqc_amd_<name>.so
+    (select with the DQC_AMD_LIB environment variable); never used by tests or bench defaults"""
+    build()
+    hipcc = _hipcc()
+    obj = os.path.join(OBJ, "grid_%s.o" % name)
+    subprocess.check_call([hipcc] + FLAGS + ["-D" + d for d in defines] +
+                          ["-c", os.path.join(CSRC, "grid.hip"), "-o", obj])
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "grid.hip"] + [obj]
+    out = os.path.join(HERE, "libdqc_amd_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

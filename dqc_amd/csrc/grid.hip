@@ -104,12 +104,19 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
                 const double av = a[kk * 4];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ct++)  // straight-line: panels past ld hold zeros in LDS
+#ifndef ABL_DEN_NO_MFMA
                     acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
+#else
+                    acc[ct][0] += av * b[kk * 4 * LSBP + ct * 16];
+#endif
             }
             if (kc + 1 < nk) stage(buf ^ 1);
             __syncthreads();
         }
         // epilogue: row dots with Phi (and its gradient) in the accumulator layout, straight from global
+#ifdef ABL_DEN_NO_EPI
+        if (ngrid < 0)
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = min(g0 + wave * 16 + lk + 4 * r, ngrid - 1);
@@ -251,7 +258,12 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
             const int c2 = (pcol + i * TPR) * 2;
             const int cc = c2 < ld ? c2 : 0;
 #pragma unroll
-            for (int d = 0; d < (GGA ? 4 : 1); d++) raw[i][d] = *reinterpret_cast<const double2 *>(src + d * cs + cc);
+            for (int d = 0; d < (GGA ? 4 : 1); d++)
+#ifndef ABL_VXC_NO_LOAD
+                raw[i][d] = *reinterpret_cast<const double2 *>(src + d * cs + cc);
+#else
+                raw[i][d] = make_double2(1e-3 * cc, 2e-3 * d);
+#endif
         }
     };
     auto stage = [&](int buf) {
@@ -287,7 +299,11 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
             for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
                 const double a = base[ko + (offab[t] & 0xffffu)];
                 const double b = base[ko + (offab[t] >> 16)];
+#ifndef ABL_VXC_NO_MFMA
                 acc[t] = mfma_f64(a, b, acc[t]);
+#else
+                acc[t][0] += a * b;
+#endif
             }
         }
         if (more) stage(buf ^ 1);
@@ -300,7 +316,11 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
             const int tl = t0 + t;
             const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+            for (int r = 0; r < 4; r++)
+#ifdef ABL_VXC_NO_ATOMIC
+                if (acc[t][r] == 12345.678)
+#endif
+                    atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
         }
     }
 }
@@ -360,7 +380,9 @@ __global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ v
             g = min(g, ngrid - 1);                      // rows past the end re-read the last row; their cf is 0
             const double *src = ao + c * cs + (size_t)g * ld + col;
             double *dst = raw0 + buf * RAW + c * VG_KC * LS + ji * 128;  // wave-uniform; lane*16 B added by hardware
+#ifndef ABL_VXC_NO_LOAD
             __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
+#endif
         }
     };
     auto load_cf = [&](int gc) -> double {
@@ -415,7 +437,11 @@ __global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ v
             for (int t = 0; t < MAXT; t++) {  // straight-line; clamped duplicate tiles are discarded at the end
                 const double a = rb[ko + (offab[t] & 0xffffu)];
                 const double b = psi[ko + (offab[t] >> 16)];
+#ifndef ABL_VXC_NO_MFMA
                 acc[t] = mfma_f64(a, b, acc[t]);
+#else
+                acc[t][0] += a * b;
+#endif
             }
         }
         buf ^= 1;
@@ -426,7 +452,11 @@ __global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ v
             const int tl = t0 + t;
             const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+            for (int r = 0; r < 4; r++)
+#ifdef ABL_VXC_NO_ATOMIC
+                if (acc[t][r] == 12345.678)
+#endif
+                    atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
         }
     }
 }
@@ -522,10 +552,11 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
     const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
-        static const char *impl_env = getenv("DQC_VXC_IMPL");  // "reg" forces the register-staged variant (A/B runs)
+        static const char *impl_env = getenv("DQC_VXC_IMPL");  // "glds" selects the LDS-DMA variant (A/B runs); measured
+                                                               // slower than register staging on MI355X (profiles/)
         const int ncomp_used = gga ? 4 : 1;
         const size_t glds_lds = sizeof(double) * ((size_t)2 * ncomp_used * VG_KC * ld + (size_t)VG_KC * ld + 64);
-        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && !(impl_env && impl_env[0] == 'r');
+        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && (impl_env && impl_env[0] == 'g');
         if (use_glds) {
             static const int gsizes[] = {2, 4, 8, 12, 16, 22};
             const int need = (ttot + VXC_WAVES - 1) / VXC_WAVES;

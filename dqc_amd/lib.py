@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBPATH = os.path.join(_HERE, "libdqc_amd.so")
+_LIBPATH = os.environ.get("DQC_AMD_LIB") or os.path.join(_HERE, "libdqc_amd.so")  # override: perf-bisection variants
 _lib = None
 
 XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130}
