@@ -118,6 +118,124 @@ __global__ void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// spin-polarised functionals (polarised branches of dqc/xc/libxc.py:124-242): five inputs
+// (rho_u, rho_d, sigma_uu, sigma_ud, sigma_dd), forward-mode duals with five derivative slots.
+// lda_x / gga_x_pbe by exact spin scaling; PW92 with the zeta interpolation (constants of
+// dqc/test/test_xc.py:399-414); PBE correlation with phi(zeta) and the modified-PW92 LDA part.
+// ---------------------------------------------------------------------------------------------
+struct D5 {
+    double v, d[5];
+};
+DQC_DEV D5 c5(double v) { D5 r; r.v = v; for (int i = 0; i < 5; i++) r.d[i] = 0.0; return r; }
+DQC_DEV D5 var5(double v, int k) { D5 r = c5(v); r.d[k] = 1.0; return r; }
+DQC_DEV D5 operator+(D5 a, D5 b) { D5 r; r.v = a.v + b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+DQC_DEV D5 operator-(D5 a, D5 b) { D5 r; r.v = a.v - b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+DQC_DEV D5 operator*(D5 a, D5 b) { D5 r; r.v = a.v * b.v; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+DQC_DEV D5 operator/(D5 a, D5 b) {
+    D5 r; const double ib = 1.0 / b.v; r.v = a.v * ib;
+    for (int i = 0; i < 5; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+DQC_DEV D5 operator*(double a, D5 b) { D5 r; r.v = a * b.v; for (int i = 0; i < 5; i++) r.d[i] = a * b.d[i]; return r; }
+DQC_DEV D5 operator+(double a, D5 b) { b.v += a; return b; }
+DQC_DEV D5 operator-(double a, D5 b) { D5 r; r.v = a - b.v; for (int i = 0; i < 5; i++) r.d[i] = -b.d[i]; return r; }
+DQC_DEV D5 operator/(double a, D5 b) { return c5(a) / b; }
+DQC_DEV D5 chain(D5 a, double f, double df) { D5 r; r.v = f; for (int i = 0; i < 5; i++) r.d[i] = a.d[i] * df; return r; }
+DQC_DEV D5 p5(D5 a, double e) { const double f = pow(a.v, e); return chain(a, f, e * f / a.v); }
+DQC_DEV D5 cbrt5(D5 a) { const double f = cbrt(a.v); return chain(a, f, f / (3.0 * a.v)); }
+DQC_DEV D5 sqrt5(D5 a) { const double f = sqrt(a.v); return chain(a, f, 0.5 / f); }
+DQC_DEV D5 log1p5(D5 a) { return chain(a, log1p(a.v), 1.0 / (1.0 + a.v)); }
+DQC_DEV D5 expm15(D5 a) { return chain(a, expm1(a.v), exp(a.v)); }
+
+DQC_DEV D5 pw92_pol_eps(D5 rho, D5 zeta, const double *a3) {
+    const double alpha1[3] = {0.21370, 0.20548, 0.11125}, b1[3] = {7.5957, 14.1189, 10.357},
+                 b2[3] = {3.5876, 6.1977, 3.6231}, b3[3] = {1.6382, 3.3662, 0.88026}, b4[3] = {0.49294, 0.62517, 0.49671};
+    const double fz20 = 1.709920934161365617563962776245;
+    D5 rs = cbrt5((3.0 / (4.0 * kPi)) / rho);
+    D5 sq = sqrt5(rs);
+    D5 g[3];
+    for (int i = 0; i < 3; i++) {
+        D5 q1 = (2.0 * a3[i]) * (b1[i] * sq + b2[i] * rs + b3[i] * (rs * sq) + b4[i] * (rs * rs));
+        g[i] = (-2.0 * a3[i]) * (1.0 + alpha1[i] * rs) * log1p5(1.0 / q1);
+    }
+    D5 fz = (p5(1.0 + zeta, 4.0 / 3.0) + p5(1.0 - zeta, 4.0 / 3.0) - c5(2.0)) / c5(0.51984209978974632953);  // 2^(4/3)-2
+    D5 z2 = zeta * zeta, z4 = z2 * z2;
+    return g[0] + z4 * fz * (g[1] - g[0] + g[2] / c5(fz20)) - fz * g[2] / c5(fz20);
+}
+
+DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s) {
+    const double kappa = 0.8040, mu = 0.2195149727645171, c2 = 4.0 * 9.5707800006273038;
+    D5 r43 = r * cbrt5(r);
+    D5 s2 = s / (c2 * (r43 * r43));
+    D5 F = (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2);
+    return (-0.75 * 0.98474502184269641) * (r43 * F);
+}
+
+
+__global__ void xc_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
+                              double *__restrict__ vgu, double *__restrict__ vgd, const double *__restrict__ ru_,
+                              const double *__restrict__ rd_, const double *__restrict__ gu_,
+                              const double *__restrict__ gd_, int n, XcTerms terms, int gga) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double ru = ru_[i], rd = rd_[i];
+        double gu[3] = {0, 0, 0}, gd[3] = {0, 0, 0};
+        if (gga)
+            for (int d = 0; d < 3; d++) { gu[d] = gu_[(size_t)d * n + i]; gd[d] = gd_[(size_t)d * n + i]; }
+        double e = 0, dv[5] = {0, 0, 0, 0, 0};
+        if (ru + rd > 1e-15) {
+            ru = fmax(ru, 0.5e-15);
+            rd = fmax(rd, 0.5e-15);
+            const D5 u = var5(ru, 0), d = var5(rd, 1);
+            const D5 suu = var5(gu[0] * gu[0] + gu[1] * gu[1] + gu[2] * gu[2], 2);
+            const D5 sud = var5(gu[0] * gd[0] + gu[1] * gd[1] + gu[2] * gd[2], 3);
+            const D5 sdd = var5(gd[0] * gd[0] + gd[1] * gd[1] + gd[2] * gd[2], 4);
+            const D5 rho = u + d;
+            D5 zeta = (u - d) / rho;
+            zeta.v = fmin(fmax(zeta.v, -1.0 + 1e-10), 1.0 - 1e-10);
+            for (int t = 0; t < terms.n; t++) {
+                D5 f;
+                switch (terms.id[t]) {
+                case DQC_XC_LDA_X:
+                    f = (-0.75 * 0.98474502184269641 * 1.2599210498948732) * (u * cbrt5(u) + d * cbrt5(d));
+                    break;
+                case DQC_XC_LDA_C_PW: {
+                    const double a3[3] = {0.0310907, 0.01554535, 0.0168869};
+                    f = rho * pw92_pol_eps(rho, zeta, a3);
+                } break;
+                case DQC_XC_GGA_X_PBE:
+                    f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu) + pbe_x_unpol5(2.0 * d, 4.0 * sdd));
+                    break;
+                default: {
+                    const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
+                    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
+                    D5 eps = pw92_pol_eps(rho, zeta, a3);
+                    D5 phi = 0.5 * (p5(1.0 + zeta, 2.0 / 3.0) + p5(1.0 - zeta, 2.0 / 3.0));
+                    D5 phi3 = phi * phi * phi;
+                    D5 sig = suu + 2.0 * sud + sdd;
+                    D5 kf = cbrt5((3.0 * kPi * kPi) * rho);
+                    D5 t2 = sig / (4.0 * (phi * phi) * ((4.0 / kPi) * kf) * (rho * rho));
+                    D5 A = c5(beta / gamma) / expm15(c5(0.0) - eps / (gamma * phi3));
+                    D5 At2 = A * t2;
+                    D5 X = (beta / gamma) * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2);
+                    f = rho * (eps + gamma * phi3 * log1p5(X));
+                } break;
+                }
+                e += terms.c[t] * f.v;
+                for (int k = 0; k < 5; k++) dv[k] += terms.c[t] * f.d[k];
+            }
+        }
+        if (edens) edens[i] = e;
+        if (vru) { vru[i] = dv[0]; vrd[i] = dv[1]; }
+        if (vgu && gga)
+            for (int k = 0; k < 3; k++) {  // libxc.py:205-215
+                vgu[(size_t)k * n + i] = 2.0 * dv[2] * gu[k] + dv[3] * gd[k];
+                vgd[(size_t)k * n + i] = 2.0 * dv[4] * gd[k] + dv[3] * gu[k];
+            }
+    }
+}
+
 }  // namespace dqc
 
 extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
@@ -143,6 +261,36 @@ extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, con
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(xc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
                        d_grho, n, t, d_grho ? 1 : 0);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
+                               const double *d_rho_u, const double *d_rho_d, const double *d_grho_u,
+                               const double *d_grho_d, int n, const int *ids, const double *coefs, int nterm,
+                               void *stream) {
+    using namespace dqc;
+    if (nterm < 0 || nterm > 8) { set_error("dqc_xc_eval_pol: at most 8 functional terms"); return DQC_EINVAL; }
+    XcTerms t;
+    t.n = nterm;
+    bool need_grad = false;
+    for (int i = 0; i < nterm; i++) {
+        t.id[i] = ids[i];
+        t.c[i] = coefs[i];
+        switch (ids[i]) {
+        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: break;
+        case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: need_grad = true; break;
+        default: set_error("dqc_xc_eval_pol: unknown functional id"); return DQC_EINVAL;
+        }
+    }
+    const bool gga = d_grho_u && d_grho_d;
+    if (need_grad && !gga) { set_error("dqc_xc_eval_pol: GGA functional needs both density gradients"); return DQC_EINVAL; }
+    if ((d_vrho_u == nullptr) != (d_vrho_d == nullptr)) { set_error("dqc_xc_eval_pol: give both vrho outputs or none"); return DQC_EINVAL; }
+    if (n <= 0) return DQC_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xc_pol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
+                       d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -195,8 +195,12 @@ class HamiltonMI355:
 
     def get_vxc(self, dm):
         assert self.xc is not None, "Please call .setup_grid with the xc object"
-        if isinstance(dm, SpinParam):
-            raise NotImplementedError("spin-polarised Vxc is a 'next' row (SURVEY.md 8f1/f4)")
+        if isinstance(dm, SpinParam):  # polarised branch of hcgto.py:260-269
+            assert dm.u.dim() == 2, "batched polarised densities are not supported"
+            densinfo = SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
+            potinfo = self.xc.get_vxc(densinfo)
+            return SpinParam(u=LinearOperator.m(self._get_vxc_from_potinfo(potinfo.u), is_hermitian=True),
+                             d=LinearOperator.m(self._get_vxc_from_potinfo(potinfo.d), is_hermitian=True))
 
         def one(d):
             densinfo = self._dm2densinfo(d)
@@ -233,8 +237,9 @@ class HamiltonMI355:
 
     def get_e_xc(self, dm):
         assert self.xc is not None, "Please call .setup_grid with the xc object"
-        if isinstance(dm, SpinParam):
-            raise NotImplementedError("spin-polarised E_xc is a 'next' row (SURVEY.md 8f1/f4)")
+        if isinstance(dm, SpinParam):  # hcgto.py:320-328 with SpinParam densinfo
+            densinfo = SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
+            return torch.sum(self.dvolume * self.xc.get_edensityxc(densinfo), dim=-1)
 
         def one(d):
             edens = self.xc.get_edensityxc(self._dm2densinfo(d))

@@ -52,6 +52,7 @@ def load():
     lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
     lib.dqc_grid_density.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_vp]
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
+    lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
     lib.dqc_probe_stream_read.argtypes = [c_dp, c_sz, c_dp, c_vp]
     lib.dqc_probe_mfma_f64.argtypes = [c_dp, c_int, c_vp]
@@ -177,6 +178,22 @@ def xc_eval(terms, rho, grho, want_e=True, want_v=True):
     _check(load().dqc_xc_eval(_ptr(e), _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), n, ids, cfs, len(terms), _stream()),
            "dqc_xc_eval")
     return e, v, vg
+
+
+def xc_eval_pol(terms, rho_u, rho_d, grho_u, grho_d, want_e=True, want_v=True):
+    """-> edens, (vrho_u, vrho_d), (vgrad_u, vgrad_d)   (None where not requested / LDA)"""
+    n = rho_u.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    gga = grho_u is not None
+    e = torch.empty_like(rho_u) if want_e else None
+    vu = torch.empty_like(rho_u) if want_v else None
+    vd = torch.empty_like(rho_u) if want_v else None
+    gu = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if (want_v and gga) else None
+    gd = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if (want_v and gga) else None
+    _check(load().dqc_xc_eval_pol(_ptr(e), _ptr(vu), _ptr(vd), _ptr(gu), _ptr(gd), _ptr(rho_u), _ptr(rho_d),
+                                  _ptr(grho_u), _ptr(grho_d), n, ids, cfs, len(terms), _stream()), "dqc_xc_eval_pol")
+    return e, (vu, vd), (gu, gd)
 
 
 def grid_vxc(ao, nao, w, vrho, vgrad):

@@ -8,8 +8,8 @@
 
 Everything runs on the device; the self-consistent parameter is the Fock matrix in the orthogonalised basis,
 as in the reference.  The fixed-point solver is Pulay DIIS on the commutator [F, D] (any convergent mixer
-gives the same fixed point; only converged energies are compared).  Closed-shell / restricted only; UHF/UKS
-is a "next" row."""
+gives the same fixed point; only converged energies are compared).  Restricted closed-shell and
+unrestricted (UHF/UKS, SpinParam densities, stacked Fock matrices) are implemented."""
 from typing import Optional
 
 import torch
@@ -19,19 +19,21 @@ from .xc import get_xc
 
 
 class _Engine:
-    def __init__(self, system, xc=None, is_ks=False):
+    def __init__(self, system, xc=None, is_ks=False, restricted=None):
         self._system = system
         self.hamilton = system.get_hamiltonian()
         self.is_ks = is_ks
         self.xc = get_xc(xc) if is_ks else None
-        if system.spin != 0:
-            raise NotImplementedError("restricted closed-shell only; UHF/UKS is a 'next' row (SURVEY.md 8f1)")
+        # hf.py:49-53: polarised iff spin != 0 unless `restricted` says otherwise
+        self.polarized = bool(system.spin != 0) if restricted is None else (not restricted)
+        if system.spin != 0 and not self.polarized:
+            raise NotImplementedError("restricted open-shell is not implemented (the reference treats it via orb weights)")
         if is_ks:
             system.setup_grid()
             self.hamilton.setup_grid(system.get_grid(), self.xc)
         self.hamilton.build()
-        self.orb_weight = system.get_orbweight()
-        self.norb = self.orb_weight.shape[-1]
+        self.orb_weight = system.get_orbweight(polarized=self.polarized)
+        self.norb = SpinParam.apply_fcn(lambda w: int(w.shape[-1]), self.orb_weight)
         self.knvext = self.hamilton.get_kinnucl()
         self.shape = self.knvext.shape
         self.dtype, self.device = self.knvext.dtype, self.knvext.device
@@ -41,6 +43,12 @@ class _Engine:
 
     # Fock build -- THE hot path (hf.py:182-201, ks.py:176-187)
     def dm2scp(self, dm):
+        if self.polarized:  # scp = stacked (F_u, F_d)  (hf.py:93-103)
+            if not isinstance(dm, SpinParam):
+                dm = SpinParam(u=dm[0], d=dm[1])
+            core = self.knvext + self.hamilton.get_elrep(dm.u + dm.d)
+            v = self.hamilton.get_vxc(dm) if self.is_ks else self.hamilton.get_exchange(dm)
+            return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])
         elrep = self.hamilton.get_elrep(dm)
         if self.is_ks:
             fock = self.knvext + elrep + self.hamilton.get_vxc(dm)
@@ -49,6 +57,12 @@ class _Engine:
         return fock.fullmatrix()
 
     def scp2dm(self, scp):
+        if self.polarized:
+            out = []
+            for f, w, n in ((scp[0], self.orb_weight.u, self.norb.u), (scp[1], self.orb_weight.d, self.norb.d)):
+                _, evec = torch.linalg.eigh((f + f.transpose(-2, -1)) * 0.5)
+                out.append(self.hamilton.ao_orb2dm(evec[..., :n], w))
+            return SpinParam(u=out[0], d=out[1])
         fock = (scp + scp.transpose(-2, -1)) * 0.5
         # generalised problem F C = S C e with S = identity in the orthogonalised basis (hf.py:227-247)
         _, evec = torch.linalg.eigh(fock)
@@ -59,6 +73,10 @@ class _Engine:
 
     def dm2energy(self, dm):
         h = self.hamilton
+        if self.polarized:  # hf.py:166-172 / ks.py:157-166 with dmtot = dm.u + dm.d
+            tot = dm.u + dm.d
+            e = h.get_e_hcore(tot) + h.get_e_elrep(tot) + (h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
+            return e + self._system.get_nuclei_energy().to(e.device)
         e = h.get_e_hcore(dm) + h.get_e_elrep(dm)
         e = e + (h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
         return e + self._system.get_nuclei_energy().to(e.device)
@@ -90,18 +108,26 @@ class SCF_QCCalc:
             if dm0 != "1e":
                 raise RuntimeError("Unknown dm0: %s" % dm0)
             n = eng.shape[-1]
-            scp0 = eng.dm2scp(torch.zeros((n, n), dtype=eng.dtype, device=eng.device))
+            z = torch.zeros((n, n), dtype=eng.dtype, device=eng.device)
+            scp0 = eng.dm2scp(SpinParam(u=z, d=z) if eng.polarized else z)
             dm = eng.scp2dm(scp0)
         elif dm0 is None:
             raise RuntimeError("dm0 must be '1e' or a density matrix")
         else:
-            dm = dm0.to(eng.device)
+            dm = SpinParam.apply_fcn(lambda d: d.to(eng.device), dm0)
+        if eng.polarized and not isinstance(dm, SpinParam):  # scf_qccalc.py:97-100
+            dm = SpinParam(u=dm * 0.5, d=dm * 0.5)
+        pol = eng.polarized
         fs, es = [], []
         fock = eng.dm2scp(dm)
         self.converged = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
-            err = fock @ dm - dm @ fock  # [F, D], S = 1
+            if pol:
+                dms = torch.stack([dm.u, dm.d])
+                err = fock @ dms - dms @ fock
+            else:
+                err = fock @ dm - dm @ fock  # [F, D], S = 1
             emax = float(err.abs().max())
             if emax < opts["f_tol"]:
                 self.converged = True
@@ -121,7 +147,7 @@ class SCF_QCCalc:
                 rhs = torch.zeros(m + 1, dtype=fock.dtype, device=fock.device)
                 rhs[m] = -1
                 c = torch.linalg.lstsq(B.cpu(), rhs.cpu().unsqueeze(-1)).solution[:m, 0].to(fock.device)
-                fmix = (c.reshape(-1, 1, 1) * torch.stack(fs)).sum(0)
+                fmix = (c.reshape((-1,) + (1,) * fock.dim()) * torch.stack(fs)).sum(0)
             else:
                 fmix = fock
             dm = eng.scp2dm(fmix)
@@ -147,15 +173,11 @@ class HF(SCF_QCCalc):
     def __init__(self, system, restricted: Optional[bool] = None, variational: bool = False):
         if variational:
             raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
-        if restricted is False:
-            raise NotImplementedError("UHF is a 'next' row (SURVEY.md 8f1)")
-        super().__init__(_Engine(system, None, is_ks=False))
+        super().__init__(_Engine(system, None, is_ks=False, restricted=restricted))
 
 
 class KS(SCF_QCCalc):
     def __init__(self, system, xc, restricted: Optional[bool] = None, variational: bool = False):
         if variational:
             raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
-        if restricted is False:
-            raise NotImplementedError("UKS is a 'next' row (SURVEY.md 8f1)")
-        super().__init__(_Engine(system, xc, is_ks=True))
+        super().__init__(_Engine(system, xc, is_ks=True, restricted=restricted))

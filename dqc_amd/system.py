@@ -85,7 +85,11 @@ class Mol:
         """occupation numbers of the lowest orbitals (mol.py:421-443, safeops.occnumber)"""
         dev = self._device
         if polarized:
-            raise NotImplementedError("spin-polarised occupations: 'next' row (SURVEY.md 8f1)")
+            from .utils.datastruct import SpinParam
+            wu = torch.ones(self._nup, dtype=self._dtype, device=dev)
+            wd = torch.ones(self._ndn, dtype=self._dtype, device=dev) if self._ndn > 0 \
+                else torch.zeros(1, dtype=self._dtype, device=dev)  # mol.py:437-441: one empty orbital
+            return SpinParam(u=wu, d=wd)
         w = torch.cat([torch.full((self._ndn,), 2.0, dtype=self._dtype, device=dev),
                        torch.full((self._nup - self._ndn,), 1.0, dtype=self._dtype, device=dev)])
         return w

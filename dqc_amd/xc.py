@@ -55,14 +55,17 @@ class LibXC(BaseXC):
         return max([1] + [_FAMILY[n] for _, n in self.terms])
 
     def _flat(self, densinfo):
-        if isinstance(densinfo, SpinParam):
-            raise NotImplementedError("polarised libxc evaluation is outside the MI355X hot path (SURVEY.md 8f4)")
         rho = densinfo.value
         grad = densinfo.grad
         assert rho.dim() == 1, "batched densities are looped by the caller"
         return rho.contiguous(), (None if (grad is None or self.family == 1) else grad.contiguous())
 
     def get_edensityxc(self, densinfo):
+        if isinstance(densinfo, SpinParam):  # polarised (libxc.py:66-85 polarised branch)
+            (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
+            if not self.terms:
+                return torch.zeros_like(ru)
+            return lib.xc_eval_pol(self.terms, ru, rd, gu, gd, want_e=True, want_v=False)[0]
         rho, grad = self._flat(densinfo)
         if not self.terms:
             return torch.zeros_like(rho)
@@ -70,6 +73,13 @@ class LibXC(BaseXC):
         return e
 
     def get_vxc(self, densinfo):
+        if isinstance(densinfo, SpinParam):  # polarised (libxc.py:40-63 polarised branch)
+            (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
+            if not self.terms:
+                z = lambda r, g: ValGrad(value=torch.zeros_like(r), grad=None if g is None else torch.zeros_like(g))  # noqa: E731
+                return SpinParam(u=z(ru, gu), d=z(rd, gd))
+            _, (vu, vd), (ggu, ggd) = lib.xc_eval_pol(self.terms, ru, rd, gu, gd, want_e=False, want_v=True)
+            return SpinParam(u=ValGrad(value=vu, grad=ggu), d=ValGrad(value=vd, grad=ggd))
         rho, grad = self._flat(densinfo)
         if not self.terms:
             return ValGrad(value=torch.zeros_like(rho), grad=None if grad is None else torch.zeros_like(grad))

@@ -96,6 +96,13 @@ int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *
                 const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
                 void *stream);
 
+/* spin-polarised variant (polarised branches of dqc/xc/libxc.py:124-242): inputs rho_u, rho_d (n) and their
+ * gradients (3,n) or NULL; outputs edens (n) = zk*(rho_u+rho_d), vrho_{u,d} (n), and
+ * vgrad_u = 2 vsigma_uu grad_u + vsigma_ud grad_d, vgrad_d = 2 vsigma_dd grad_d + vsigma_ud grad_u  (libxc.py:205-215) */
+int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
+                    const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
+                    int n, const int *ids, const double *coefs, int nterm, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */

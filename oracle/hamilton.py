@@ -272,3 +272,103 @@ def run_scf(moldesc, basis, xc=None, grid="sg3", **kw):
     eng = Engine(t, xc=xc, grid=grid)
     e = eng.run(**kw)
     return e, eng
+
+
+class EnginePol:
+    """UHF / UKS engine (polarised branches of dqc/qccalc/hf.py:93-119,182-216 and ks.py:110-187):
+    scp = stacked (F_u, F_d); J from the total density; exchange per spin = get_exchange(2 D_s) = -K[D_s]
+    (hcgto.py:238-241); occupations from Mol (dqc/system/mol.py:421-443)."""
+
+    def __init__(self, tables, spin, xc=None, grid="sg3", hf=None):
+        self.t = tables
+        self.is_hf = (xc is None) if hf is None else hf
+        self.xc = None if self.is_hf else (oxc.get_xc(xc) if isinstance(xc, str) else xc)
+        self.h = Hamilton(tables).build()
+        if not self.is_hf:
+            rgrid, dvol = ogrid.get_predefined_grid(grid, tables.atomzs, tables.atompos)
+            self.h.setup_grid(rgrid, dvol, self.xc)
+        nel = int(round(float(np.sum(tables.atomzs))))
+        assert (nel - spin) % 2 == 0
+        self.ndn = (nel - spin) // 2
+        self.nup = self.ndn + spin
+        self.enuc = nuclei_energy(tables.atomzs, tables.atompos)
+
+    def _vxc(self, dmu, dmd):
+        ru, gu = self.h.dm2densinfo(dmu)
+        rd, gd = self.h.dm2densinfo(dmd)
+        f = lambda a: None if a is None else a.numpy()  # noqa: E731
+        e, vr, vg, _ = oxc.compute_pol(self.xc, ru.numpy(), rd.numpy(), f(gu), f(gd))
+        t = lambda a: None if a is None else torch.as_tensor(a)  # noqa: E731
+        vu = self.h.vxc_from_potinfo(torch.as_tensor(vr[0]), t(vg[0]))
+        vd = self.h.vxc_from_potinfo(torch.as_tensor(vr[1]), t(vg[1]))
+        exc = float(torch.sum(self.h.dvolume * torch.as_tensor(e)))
+        return vu, vd, exc
+
+    def dm2scp(self, dm):
+        dmu, dmd = dm
+        core = self.h.kinnucl_mat + self.h.get_elrep(dmu + dmd)
+        if self.is_hf:
+            return torch.stack([core + self.h.get_exchange(2 * dmu), core + self.h.get_exchange(2 * dmd)])
+        vu, vd, _ = self._vxc(dmu, dmd)
+        return torch.stack([core + vu, core + vd])
+
+    def scp2dm(self, scp):
+        out = []
+        for f, nocc in ((scp[0], self.nup), (scp[1], self.ndn)):
+            f = (f + f.T) * 0.5
+            _, C = torch.linalg.eigh(f)
+            out.append(C[:, :nocc] @ C[:, :nocc].T if nocc > 0 else torch.zeros_like(f))
+        return tuple(out)
+
+    def dm2energy(self, dm):
+        dmu, dmd = dm
+        tot = dmu + dmd
+        e = float(self.h.get_e_hcore(tot) + self.h.get_e_elrep(tot))
+        if self.is_hf:
+            e += float(0.5 * torch.sum(self.h.get_exchange(2 * dmu) * dmu) + 0.5 * torch.sum(self.h.get_exchange(2 * dmd) * dmd))
+        else:
+            e += self._vxc(dmu, dmd)[2]
+        return e + self.enuc
+
+    def run(self, maxiter=200, tol=1e-9):
+        n = self.h.nao
+        z = torch.zeros((n, n), dtype=torch.float64)
+        dm = self.scp2dm(self.dm2scp((z, z)))
+        if self.nup == self.ndn:  # the reference halves a restricted guess (scf_qccalc.py:97-100)
+            dm = ((dm[0] + dm[1]) * 0.5, (dm[0] + dm[1]) * 0.5)
+        fs, es = [], []
+        fock = self.dm2scp(dm)
+        self.niter = 0
+        for it in range(maxiter):
+            self.niter = it + 1
+            err = torch.stack([fock[s] @ dm[s] - dm[s] @ fock[s] for s in range(2)])
+            if err.abs().max() < tol:
+                break
+            fs.append(fock)
+            es.append(err.reshape(-1))
+            if len(fs) > 8:
+                fs.pop(0)
+                es.pop(0)
+            m = len(fs)
+            if m > 1:
+                E = torch.stack(es)
+                B = torch.zeros((m + 1, m + 1), dtype=torch.float64)
+                B[:m, :m] = E @ E.T
+                B[m, :m] = -1
+                B[:m, m] = -1
+                rhs = torch.zeros(m + 1, dtype=torch.float64)
+                rhs[m] = -1
+                c = torch.linalg.lstsq(B, rhs.unsqueeze(-1)).solution[:m, 0]
+                fmix = (c.reshape(-1, 1, 1, 1) * torch.stack(fs)).sum(0)
+            else:
+                fmix = fock
+            dm = self.scp2dm(fmix)
+            fock = self.dm2scp(dm)
+        self.dm = dm
+        return self.dm2energy(dm)
+
+
+def run_scf_pol(moldesc, basis, spin, xc=None, grid="sg3", **kw):
+    t = obasis.make_tables(moldesc, basis)
+    eng = EnginePol(t, spin, xc=xc, grid=grid)
+    return eng.run(**kw), eng

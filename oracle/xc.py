@@ -171,3 +171,204 @@ def get_xc(xcstr):
                 raise ValueError("unsupported xc term: %s" % tok)
             terms.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2)))
     return XC(terms)
+
+
+# =====================================================================================================
+# Spin-polarised functionals (reference: polarised branches of dqc/xc/libxc.py:124-242 and
+# CalcLDALibXCPol / CalcGGALibXCPol in dqc/xc/libxc_wrapper.py; inputs rho_u, rho_d, sigma_uu, sigma_ud,
+# sigma_dd; outputs e = zk*(rho_u+rho_d), vrho (2), vsigma (3)).  Derivatives by forward-mode dual arrays;
+# tests check them against finite differences and against the unpolarised functions at rho_u = rho_d.
+#   lda_x, gga_x_pbe : exact spin scaling  E[ru, rd] = (E[2 ru] + E[2 rd]) / 2
+#   lda_c_pw         : PW92 with the zeta interpolation of dqc/test/test_xc.py:393-414
+#   gga_c_pbe        : PBE correlation with phi(zeta) and libxc's modified-PW92 constants -- PARITY UNPINNED
+# =====================================================================================================
+class Dual:
+    """value + gradient w.r.t. the 5 polarised inputs (numpy arrays)"""
+    __slots__ = ("v", "d")
+
+    def __init__(self, v, d):
+        self.v, self.d = v, d
+
+    @staticmethod
+    def var(v, i, n=5):
+        d = [np.zeros_like(v) for _ in range(n)]
+        d[i] = np.ones_like(v)
+        return Dual(v, d)
+
+    @staticmethod
+    def const(c, like):
+        return Dual(np.full_like(like.v, c), [np.zeros_like(like.v) for _ in like.d])
+
+    def _wrap(self, o):
+        return o if isinstance(o, Dual) else Dual.const(o, self)
+
+    def __add__(self, o):
+        o = self._wrap(o)
+        return Dual(self.v + o.v, [a + b for a, b in zip(self.d, o.d)])
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = self._wrap(o)
+        return Dual(self.v - o.v, [a - b for a, b in zip(self.d, o.d)])
+
+    def __rsub__(self, o):
+        return self._wrap(o) - self
+
+    def __neg__(self):
+        return Dual(-self.v, [-a for a in self.d])
+
+    def __mul__(self, o):
+        o = self._wrap(o)
+        return Dual(self.v * o.v, [a * o.v + self.v * b for a, b in zip(self.d, o.d)])
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        o = self._wrap(o)
+        q = self.v / o.v
+        return Dual(q, [(a - q * b) / o.v for a, b in zip(self.d, o.d)])
+
+    def __rtruediv__(self, o):
+        return self._wrap(o) / self
+
+    def fn(self, f, df):
+        g = df(self.v)
+        return Dual(f(self.v), [a * g for a in self.d])
+
+    def pow(self, p):
+        return self.fn(lambda x: x ** p, lambda x: p * x ** (p - 1))
+
+    def log1p(self):
+        return self.fn(np.log1p, lambda x: 1.0 / (1.0 + x))
+
+    def expm1(self):
+        return self.fn(np.expm1, np.exp)
+
+    def sqrt(self):
+        return self.pow(0.5)
+
+
+_PW_POL = {  # dqc/test/test_xc.py:399-405 : index 0 paramagnetic, 1 ferromagnetic, 2 -alpha_c
+    "a": (0.0310907, 0.01554535, 0.0168869), "alpha1": (0.21370, 0.20548, 0.11125),
+    "beta1": (7.5957, 14.1189, 10.357), "beta2": (3.5876, 6.1977, 3.6231),
+    "beta3": (1.6382, 3.3662, 0.88026), "beta4": (0.49294, 0.62517, 0.49671)}
+_PW_A_MOD3 = (0.0310906908696548950, 0.01554534543482745, 0.0168868639403896)
+_FZ20 = 1.709920934161365617563962776245
+
+
+def _pw92_pol_eps(rho, zeta, a3):
+    rs = ((3.0 / (4.0 * np.pi)) / rho).pow(1.0 / 3)
+    sq = rs.sqrt()
+    g = []
+    for i in range(3):
+        a, p = a3[i], _PW_POL
+        q1 = 2.0 * a * (p["beta1"][i] * sq + p["beta2"][i] * rs + p["beta3"][i] * (rs * sq) + p["beta4"][i] * (rs * rs))
+        g.append((-2.0 * a) * (1.0 + p["alpha1"][i] * rs) * (1.0 / q1).log1p())
+    fz = ((1.0 + zeta).pow(4.0 / 3) + (1.0 - zeta).pow(4.0 / 3) - 2.0) / (2.0 ** (4.0 / 3) - 2.0)
+    z4 = (zeta * zeta) * (zeta * zeta)
+    return g[0] + z4 * fz * (g[1] - g[0] + g[2] / _FZ20) - fz * g[2] / _FZ20
+
+
+def _pol_inputs(ru, rd, suu, sud, sdd):
+    return [Dual.var(np.asarray(x, dtype=np.float64), i) for i, x in enumerate((ru, rd, suu, sud, sdd))]
+
+
+def _safe_zeta(ru, rd):
+    rho = ru + rd
+    z = (ru - rd) / rho
+    # keep (1 +- zeta)^(1/3) differentiable for fully polarised points (libxc zeta_threshold behaviour)
+    z.v = np.clip(z.v, -1.0 + 1e-10, 1.0 - 1e-10)
+    return rho, z
+
+
+def _finish(e, mask):
+    z = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+    return z(e.v), (z(e.d[0]), z(e.d[1])), (z(e.d[2]), z(e.d[3]), z(e.d[4]))
+
+
+def _masked(ru, rd):
+    ru, rd = np.asarray(ru, float), np.asarray(rd, float)
+    mask = (ru + rd) > DENS_THRESHOLD
+    fl = 0.5 * DENS_THRESHOLD
+    return mask, np.where(mask, np.maximum(ru, fl), 1.0), np.where(mask, np.maximum(rd, fl), 1.0)
+
+
+def lda_x_pol(ru, rd, suu=None, sud=None, sdd=None):
+    mask, ru_, rd_ = _masked(ru, rd)
+    z0 = np.zeros_like(ru_)
+    u, d, _, _, _ = _pol_inputs(ru_, rd_, z0, z0, z0)
+    c = -0.75 * (3.0 / np.pi) ** (1.0 / 3) * 2.0 ** (1.0 / 3)
+    return _finish(c * (u.pow(4.0 / 3) + d.pow(4.0 / 3)), mask)
+
+
+def lda_c_pw_pol(ru, rd, suu=None, sud=None, sdd=None):
+    mask, ru_, rd_ = _masked(ru, rd)
+    z0 = np.zeros_like(ru_)
+    u, d, _, _, _ = _pol_inputs(ru_, rd_, z0, z0, z0)
+    rho, zeta = _safe_zeta(u, d)
+    return _finish(rho * _pw92_pol_eps(rho, zeta, _PW_POL["a"]), mask)
+
+
+def gga_x_pbe_pol(ru, rd, suu, sud, sdd):
+    mask, ru_, rd_ = _masked(ru, rd)
+    u, d, suu_, sud_, sdd_ = _pol_inputs(ru_, rd_, suu, sud, sdd)
+    A = -0.75 * (3.0 / np.pi) ** (1.0 / 3)
+    c2 = 4.0 * (3.0 * np.pi ** 2) ** (2.0 / 3)
+
+    def ex(r, s):  # unpolarised E_x[r, s]
+        r43 = r.pow(4.0 / 3)
+        s2 = s / (c2 * r43 * r43)
+        F = (1.0 + _PBE_KAPPA) - _PBE_KAPPA / (1.0 + (_PBE_MU / _PBE_KAPPA) * s2)
+        return A * r43 * F
+
+    e = 0.5 * (ex(2.0 * u, 4.0 * suu_) + ex(2.0 * d, 4.0 * sdd_))
+    return _finish(e, mask)
+
+
+def gga_c_pbe_pol(ru, rd, suu, sud, sdd):
+    mask, ru_, rd_ = _masked(ru, rd)
+    u, d, suu_, sud_, sdd_ = _pol_inputs(ru_, rd_, suu, sud, sdd)
+    rho, zeta = _safe_zeta(u, d)
+    g_, b_ = _PBE_GAMMA, _PBE_BETA
+    eps = _pw92_pol_eps(rho, zeta, _PW_A_MOD3)
+    phi = 0.5 * ((1.0 + zeta).pow(2.0 / 3) + (1.0 - zeta).pow(2.0 / 3))
+    phi3 = phi * phi * phi
+    sig = suu_ + 2.0 * sud_ + sdd_
+    kf = ((3.0 * np.pi ** 2) * rho).pow(1.0 / 3)
+    ks2 = (4.0 / np.pi) * kf
+    t2 = sig / (4.0 * phi * phi * ks2 * rho * rho)
+    Ac = (b_ / g_) / (-(eps / (g_ * phi3))).expm1()
+    At2 = Ac * t2
+    X = (b_ / g_) * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2)
+    H = g_ * phi3 * X.log1p()
+    return _finish(rho * (eps + H), mask)
+
+
+_FUNCS_POL = {"lda_x": lda_x_pol, "lda_c_pw": lda_c_pw_pol, "gga_x_pbe": gga_x_pbe_pol, "gga_c_pbe": gga_c_pbe_pol}
+
+
+def compute_pol(xc, ru, rd, gu=None, gd=None):
+    """XC (linear combination) on spin densities -> e, (vrho_u, vrho_d), (vgrad_u, vgrad_d) with
+    vgrad_u = 2 vsigma_uu grad_u + vsigma_ud grad_d (dqc/xc/libxc.py:205-215); gradients (3, n) or None"""
+    n = ru.shape[0]
+    if xc.family == 2:
+        suu, sud, sdd = (gu * gu).sum(0), (gu * gd).sum(0), (gd * gd).sum(0)
+    else:
+        suu = sud = sdd = np.zeros(n)
+    e = np.zeros(n)
+    vr = [np.zeros(n), np.zeros(n)]
+    vs = [np.zeros(n), np.zeros(n), np.zeros(n)]
+    for c, nm in xc.terms:
+        ee, vv, ss = _FUNCS_POL[nm](ru, rd, suu, sud, sdd)
+        e += c * ee
+        for i in range(2):
+            vr[i] += c * vv[i]
+        for i in range(3):
+            vs[i] += c * ss[i]
+    if xc.family == 2:
+        vgu = 2.0 * vs[0][None] * gu + vs[1][None] * gd
+        vgd = 2.0 * vs[2][None] * gd + vs[1][None] * gu
+    else:
+        vgu = vgd = None
+    return e, (vr[0], vr[1]), (vgu, vgd), vs

@@ -228,3 +228,91 @@ def test_cart2sph_tables_agree(golden_dir):
     vals = np.array([float(x) for x in body.replace("\n", " ").split(",") if x.strip()])
     for l in range(5):
         assert np.abs(vals[offs[l]:offs[l + 1]].reshape(2 * l + 1, -1) - nat.cart2sph(l)).max() < 1e-13
+
+
+# ------------------------------------------------------------------------------------------------
+# spin-polarised path: functionals, UHF / UKS engines
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe"])
+def test_polarised_xc_derivatives_and_unpolarised_limit(name):
+    rng = np.random.default_rng(0)
+    n = 40
+    ru, rd = rng.uniform(0.05, 1.0, n), rng.uniform(0.02, 0.8, n)
+    suu, sdd = rng.uniform(0.01, 1, n), rng.uniform(0.01, 1, n)
+    sud = rng.uniform(-0.5, 0.5, n) * np.sqrt(suu * sdd)
+    f = oxc._FUNCS_POL[name]
+    args = [ru, rd, suu, sud, sdd]
+    e, vr, vs = f(*args)
+    an = [vr[0], vr[1], vs[0], vs[1], vs[2]]
+    h = 1e-6
+    for i in range(5):
+        ap = [a + (h if k == i else 0) for k, a in enumerate(args)]
+        am = [a - (h if k == i else 0) for k, a in enumerate(args)]
+        assert np.allclose((f(*ap)[0] - f(*am)[0]) / (2 * h), an[i], rtol=1e-6, atol=2e-9), (name, i)
+    r, s = rng.uniform(0.05, 1.0, n), rng.uniform(0.01, 1, n)
+    e2, vr2, vs2 = f(r / 2, r / 2, s / 4, s / 4, s / 4)
+    e1, v1, s1 = oxc._FUNCS[name][1](r, s)
+    assert np.allclose(e2, e1, rtol=1e-13) and np.allclose(vr2[0], v1, rtol=1e-12)
+    assert np.allclose((vs2[0] + vs2[1] + vs2[2]) / 4, s1, rtol=1e-11, atol=1e-16)
+
+
+def test_polarised_pw92_closed_form():
+    """ldac_e_true(rho, xi) of dqc/test/test_xc.py:393-414"""
+    rng = np.random.default_rng(2)
+    rho, xi = rng.uniform(0.01, 2.0, 100), rng.uniform(-0.95, 0.95, 100)
+    rs = (4 * np.pi * rho / 3) ** (-1 / 3)
+    a = np.array([0.0310907, 0.01554535, 0.0168869])[:, None]
+    a1 = np.array([0.21370, 0.20548, 0.11125])[:, None]
+    b1 = np.array([7.5957, 14.1189, 10.357])[:, None]
+    b2 = np.array([3.5876, 6.1977, 3.6231])[:, None]
+    b3 = np.array([1.6382, 3.3662, 0.88026])[:, None]
+    b4 = np.array([0.49294, 0.62517, 0.49671])[:, None]
+    fz20 = 1.709920934161365617563962776245
+    gaux = b1 * np.sqrt(rs) + b2 * rs + b3 * rs ** 1.5 + b4 * rs ** 2
+    g = -2 * a * (1 + a1 * rs) * np.log1p(1 / (2 * a * gaux))
+    fxi = ((1 + xi) ** (4 / 3) + (1 - xi) ** (4 / 3) - 2) / (2 ** (4 / 3) - 2)
+    ref = (g[0] + xi ** 4 * fxi * (g[1] - g[0] + g[2] / fz20) - fxi * g[2] / fz20) * rho
+    e = oxc.lda_c_pw_pol(rho * (1 + xi) / 2, rho * (1 - xi) / 2)[0]
+    assert np.allclose(e, ref, rtol=1e-12)
+
+
+def test_uhf_reference_literals(lit):
+    """dqc/test/test_hf.py:141-206: UHF/3-21G atoms (H, Li, B, O) and NO, rtol 1e-7"""
+    for z, spin, ref in lit["uhf_321g"]["atoms"]:
+        e, _ = oh.run_scf_pol(([z], [[0, 0, 0.0]]), "3-21G", spin)
+        assert abs(e - ref) <= lit["uhf_321g"]["tol_rel"] * abs(ref), (z, e, ref)
+    for zs, d, spin, ref in lit["uhf_321g"]["mols"]:
+        e, _ = oh.run_scf_pol((zs, [[-d / 2, 0, 0], [d / 2, 0, 0]]), "3-21G", spin)
+        assert abs(e - ref) <= lit["uhf_321g"]["tol_rel"] * abs(ref), (zs, e, ref)
+    e, _ = oh.run_scf_pol(([1, 1], [[-0.5, 0, 0], [0.5, 0, 0]]), "3-21G", 0)  # UHF == RHF for a closed shell
+    assert abs(e + 1.07195346) < 2e-8
+
+
+def test_uks_o2_reference_literals(lit):
+    """dqc/test/test_ks.py:325-345: UKS O2 / 6-311++G** / grid 3 (reference tolerance 1.3e-3)"""
+    for xc, ref in lit["uks_6311ppgss"]["o2"].items():
+        e, _ = oh.run_scf_pol(([8, 8], [[-1.0, 0, 0], [1.0, 0, 0]]), "6-311++G**", 2, xc=xc, grid=3)
+        assert abs(e - ref) < 2e-5, (xc, e, ref)
+
+
+@pytest.mark.parametrize("name", ["no_321g_uhf", "ch3_ccpvdz_upbe_sg2", "o2_ccpvdz_ulda_sg2"])
+def test_oracle_vs_reference_generated_polarised_golden(name, golden_dir):
+    import torch
+    g = np.load(os.path.join(golden_dir, "refpol_%s.npz" % name))
+    p = name.split("_")
+    basis = {"321g": "3-21G", "ccpvdz": "cc-pvdz"}[p[1]]
+    xc = {"uhf": None, "upbe": "gga_x_pbe+gga_c_pbe", "ulda": "lda_x+lda_c_pw"}[p[2]]
+    grid = p[3] if len(p) > 3 else "sg3"
+    e, eng = oh.run_scf_pol((g["atomzs"].tolist(), g["atompos"]), basis, int(g["spin"]), xc=xc, grid=grid, tol=1e-10)
+    assert abs(e - float(g["e_tot"])) < 1e-7
+    S = torch.as_tensor(nat.int1e("ovlp", eng.t))
+    SX = S @ eng.h.X
+    dmo = tuple(SX.T @ torch.as_tensor(g[k]) @ SX for k in ("probe_du_ao", "probe_dd_ao"))
+    if xc is None:
+        ku = (SX @ eng.h.get_exchange(2 * dmo[0]) @ SX.T).numpy()
+        assert np.abs(ku - g["probe_ku_ao"]).max() < 1e-9 * max(1.0, np.abs(ku).max())
+    else:
+        vu, vd, exc = eng._vxc(*dmo)
+        assert np.abs((SX @ vu @ SX.T).numpy() - g["probe_vu_ao"]).max() < 1e-9
+        assert np.abs((SX @ vd @ SX.T).numpy() - g["probe_vd_ao"]).max() < 1e-9
+        assert abs(exc - float(g["probe_exc"])) < 1e-9

@@ -56,6 +56,14 @@ CASES = {
     "benzene_ccpvdz_rhf": (benzene(), "cc-pvdz", None, None),
     "benzene_ccpvdz_lda_sg3": (benzene(), "cc-pvdz", "lda_x+lda_c_pw", "sg3"),
 }
+# unrestricted cases: (moldesc, basis, xc, grid, spin)
+CASES_POL = {
+    "no_321g_uhf": (([7, 8], [[-1.0, 0, 0], [1.0, 0, 0]]), "3-21G", None, None, 1),
+    # planar methyl radical (non-degenerate 2A2''), r_CH = 2.04 Bohr
+    "ch3_ccpvdz_upbe_sg2": (([6, 1, 1, 1], [[0, 0, 0.0], [2.04, 0, 0], [-1.02, 1.766691, 0], [-1.02, -1.766691, 0]]),
+                            "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2", 1),
+    "o2_ccpvdz_ulda_sg2": (([8, 8], [[-1.14, 0, 0], [1.14, 0, 0]]), "cc-pvdz", "lda_x+lda_c_pw", "sg2", 2),
+}
 SMALL = ["h2o_sto3g_rhf", "h2o_ccpvdz_rhf", "h2o_ccpvdz_lda_sg3", "h2o_ccpvdz_pbe_sg3", "ch4_ccpvtz_pbe_sg2"]
 
 
@@ -126,6 +134,48 @@ def run_case(name):
     print("%-28s E = %.10f  (%.1f s)" % (name, e_tot, time.time() - t0), flush=True)
 
 
+def run_case_pol(name):
+    """UHF / UKS through the reference's own polarised engine code (SpinParam plumbing of hf.py / ks.py / hcgto.py)"""
+    from dqc.utils.datastruct import SpinParam
+    moldesc, basis, xc, grid, spin = CASES_POL[name]
+    t0 = time.time()
+    kw = {"spin": spin}
+    if grid is not None:
+        kw["grid"] = grid
+    mol = rh.ref_mol(moldesc, basis, **kw)
+    qc = dqc.HF(mol) if xc is None else dqc.KS(mol, xc=xc)
+    qc.run()
+    eng = qc._engine
+    dm = qc.aodm()
+    assert isinstance(dm, SpinParam)
+    hamilt = mol.get_hamiltonian()
+    X = hamilt._orthozer._orthozer.detach()
+    tabs = obasis.make_tables(moldesc, basis)
+    S = torch.as_tensor(natives.int1e("ovlp", tabs))
+    SX = S @ X
+    to_ao = lambda m: (SX @ m @ SX.T).numpy()  # noqa: E731
+    fock = eng.dm2scp(dm)
+    out = {"atomzs": np.array(moldesc[0]), "atompos": np.array(moldesc[1], dtype=float), "spin": spin,
+           "e_tot": float(qc.energy()), "dm_u_ao": (X @ dm.u @ X.T).numpy(), "dm_d_ao": (X @ dm.d @ X.T).numpy(),
+           "fock_u_ao": to_ao(fock[0]), "fock_d_ao": to_ao(fock[1])}
+    # probe: seeded spin densities -> polarised Vxc / exchange in the AO basis
+    nel = int(sum(moldesc[0]))
+    XtS = SX.T
+    Du = seeded_dm_ao(tabs.nao, nel + spin, S.numpy(), 77) * 0.5
+    Dd = seeded_dm_ao(tabs.nao, nel - spin, S.numpy(), 78) * 0.5
+    dmo = SpinParam(u=XtS @ torch.as_tensor(Du) @ XtS.T, d=XtS @ torch.as_tensor(Dd) @ XtS.T)
+    out["probe_du_ao"], out["probe_dd_ao"] = Du, Dd
+    if xc is None:
+        ex = hamilt.get_exchange(dmo)
+        out["probe_ku_ao"], out["probe_kd_ao"] = to_ao(ex.u.fullmatrix()), to_ao(ex.d.fullmatrix())
+    else:
+        v = hamilt.get_vxc(dmo)
+        out["probe_vu_ao"], out["probe_vd_ao"] = to_ao(v.u.fullmatrix()), to_ao(v.d.fullmatrix())
+        out["probe_exc"] = float(hamilt.get_e_xc(dmo))
+    np.savez_compressed(os.path.join(GOLD, "refpol_%s.npz" % name), **out)
+    print("%-28s E = %.10f  (%.1f s)" % (name, out["e_tot"], time.time() - t0), flush=True)
+
+
 def write_kats():
     """literal known answers held by the reference's own tests"""
     kat = {
@@ -144,6 +194,13 @@ def write_kats():
                        "z": [0.0, 0.4, 0.8], "rho": [0.18742819, 0.23469519, 0.30250292]},
         "grid_gauss_integral": {"src": "dqc/test/test_grid.py:16-78", "value": 15.7496099457224,
                                 "sg3_points": {"1": 16710, "6": 17674, "7": 18286, "8": 18946}},
+        "uhf_321g": {"tol_rel": 1e-7, "src": "dqc/test/test_hf.py:141-206",
+                     "atoms": [[1, 1, -4.96198609e-01], [3, 1, -7.38151326e+00], [5, 1, -2.43897617e+01], [8, 2, -7.43936572e+01]],
+                     "mols": [[[7, 8], 2.0, 1, -1.28477807e+02]]},
+        "uks_6311ppgss": {"tol_abs": 1.3e-3, "src": "dqc/test/test_ks.py:296-345 (atoms: grid 4, O2: grid 3)",
+                          "atoms": {"lda_x": [[1, 1, -0.456918307830999], [3, 1, -7.19137615551071], [8, 2, -73.987463670134]],
+                                    "gga_x_pbe": [[1, 1, -0.49413365762347017], [3, 1, -7.408839641982052], [8, 2, -74.77107826628823]]},
+                          "o2": {"lda_x": -148.149998931489, "lda_x+lda_c_pw": -1.49259447e+02, "gga_x_pbe": -149.64097658035521}},
         "nuclei_energy": {"src": "dqc/test/test_system.py:61-72", "z": [1, 4], "dist": 1.5, "value": 4 / 1.5},
     }
     with open(os.path.join(GOLD, "reference_literals.json"), "w") as f:
@@ -153,5 +210,5 @@ def write_kats():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     write_kats()
-    for c in (sys.argv[1:] or SMALL):
-        run_case(c)
+    for c in (sys.argv[1:] or SMALL + list(CASES_POL)):
+        (run_case_pol if c in CASES_POL else run_case)(c)

@@ -172,11 +172,24 @@ def _install_stubs():
             return self._fam
 
         def compute(self, inp, do_exc=True, do_vxc=False, **kw):
-            assert self.spin in ("unpolarized", 1), "harness supports unpolarised functionals only"
-            rho = np.asarray(inp["rho"]).reshape(-1)
+            rho = np.asarray(inp["rho"])
+            res = {}
+            if self.spin in ("polarized", 2):  # rho (n,2), sigma (n,3) -- libxc's polarised layout
+                rho = rho.reshape(-1, 2)
+                n = rho.shape[0]
+                sg = np.asarray(inp["sigma"]).reshape(-1, 3) if "sigma" in inp else np.zeros((n, 3))
+                e, vr, vs = _oxc._FUNCS_POL[self.name](rho[:, 0], rho[:, 1], sg[:, 0], sg[:, 1], sg[:, 2])
+                tot = rho.sum(-1)
+                if do_exc:
+                    res["zk"] = np.where(tot > _oxc.DENS_THRESHOLD, e / np.where(tot > 0, tot, 1), 0.0)[:, None]
+                if do_vxc:
+                    res["vrho"] = np.stack(vr, axis=-1)
+                    if self._fam == 2:
+                        res["vsigma"] = np.stack(vs, axis=-1)
+                return res
+            rho = rho.reshape(-1)
             sigma = np.asarray(inp["sigma"]).reshape(-1) if "sigma" in inp else None
             e, vr, vs = _oxc._FUNCS[self.name][1](rho, sigma)
-            res = {}
             if do_exc:
                 res["zk"] = np.where(rho > _oxc.DENS_THRESHOLD, e / np.where(rho > 0, rho, 1), 0.0)[:, None]
             if do_vxc:
