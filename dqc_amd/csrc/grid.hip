@@ -38,7 +38,9 @@ constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-f
 template <int NCT, bool GGA>
 __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
-                                                         const double *__restrict__ dm, int ntile) {
+                                                         const double *__restrict__ dm, int ntile,
+                                                         const double *__restrict__ aoe) {
+    // aoe: array the row dots are taken with (== ao except for the "pair" form rowdot(ao . D, aoe), LDA mode only)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int LSB = NCT * 16;                 // width of the staged D column panel (== 16 mod 32 when NCT odd)
     constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = min(g0 + wave * 16 + lk + 4 * r, ngrid - 1);
-            const double *ap = ao + (size_t)row * ld + jc * 16 + lr;
+            const double *ap = (GGA ? ao : aoe) + (size_t)row * ld + jc * 16 + lr;
 #pragma unroll
             for (int ct = 0; ct < NCT; ct++) {
                 if (ct < nvalid) {
@@ -171,13 +173,13 @@ static constexpr size_t density_lds_bytes() {
 
 template <bool GGA>
 static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
-                          int ngrid, int ld, const double *dm, int ntile) {
+                          int ngrid, int ld, const double *dm, int ntile, const double *aoe) {
 #define DQC_DENS_CASE(N)                                                                                           \
     case N:                                                                                                        \
         (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)density_lds_bytes<N>());                                                    \
         hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(DEN_NT), density_lds_bytes<N>(), st, rho, grho, ao,    \
-                           ngrid, ld, dm, ntile);                                                                  \
+                           ngrid, ld, dm, ntile, aoe);                                                                  \
         break;
     switch (nct) {
         DQC_DENS_CASE(1) DQC_DENS_CASE(2) DQC_DENS_CASE(3) DQC_DENS_CASE(4) DQC_DENS_CASE(5) DQC_DENS_CASE(6)
@@ -204,7 +206,9 @@ template <int MAXT, int NL, int KCH, bool GGA>
 __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
                                                      int ngrid, int ld, const double *__restrict__ w,
                                                      const double *__restrict__ vrho, const double *__restrict__ vgrad,
-                                                     int slab, int nsplit, int tiles_per_split) {
+                                                     int slab, int nsplit, int tiles_per_split,
+                                                     const double *__restrict__ aob) {
+    // aob: LDA mode only -- array the Psi operand is built from (== ao except for the "pair" form ao^T diag(w v) aob)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int LS = ld;  // ld == 16 (mod 32): conflict-free fragment reads without extra padding
     const int BUF = 2 * KCH * LS;  // phi + psi
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
     // only combined into Psi when they are written to LDS afterwards.
     constexpr int TPR = 512 / KCH;       // threads per row
     const int prow = tid / TPR, pcol = tid % TPR;
-    double2 raw[NL][GGA ? 4 : 1];
+    double2 raw[NL][GGA ? 4 : 2];  // LDA mode: [0] = phi (A operand), [1] = the array Psi is built from
     double cf[GGA ? 4 : 1];
     bool rowok = false;
     auto prefetch = [&](int gc) {
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 #else
                 raw[i][d] = make_double2(1e-3 * cc, 2e-3 * d);
 #endif
+            if (!GGA) raw[i][1] = *reinterpret_cast<const double2 *>(aob + (size_t)gg * ld + cc);
         }
     };
     auto stage = [&](int buf) {
@@ -272,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
             const int c2 = (pcol + i * TPR) * 2;
             if (c2 < ld) {
                 double2 ph = raw[i][0];
-                double2 ps = make_double2(cf[0] * ph.x, cf[0] * ph.y);
+                const double2 pb = GGA ? ph : raw[i][1];
+                double2 ps = make_double2(cf[0] * pb.x, cf[0] * pb.y);
                 if (GGA) {
 #pragma unroll
                     for (int d = 1; d < 4; d++) { ps.x += cf[d] * raw[i][d].x; ps.y += cf[d] * raw[i][d].y; }
@@ -492,24 +498,25 @@ __global__ void symmetrize_kernel(double *m, int ld) {
 
 template <int MAXT, int NL, int KCH, bool GGA>
 static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
-                            const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps) {
+                            const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps,
+                            const double *aob) {
     (void)hipFuncSetAttribute((const void *)vxc_kernel<MAXT, NL, KCH, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)shmem);
     hipLaunchKernelGGL((vxc_kernel<MAXT, NL, KCH, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab,
-                       nsplit, tps);
+                       nsplit, tps, aob);
 }
 
 template <bool GGA>
 static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                       int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
-                      int tps) {
+                      int tps, const double *aob) {
 #define DQC_VXC_CASE(N, L)                                                                                        \
     if (maxt == N && nl == L && kch == 16) {                                                                      \
-        launch_vxc_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);  \
+        launch_vxc_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);  \
         return 0;                                                                                                 \
     }                                                                                                             \
     if (maxt == N && nl == L && kch == 8) {                                                                       \
-        launch_vxc_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps);   \
+        launch_vxc_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);   \
         return 0;                                                                                                 \
     }
     DQC_VXC_CASE(2, 1) DQC_VXC_CASE(4, 1) DQC_VXC_CASE(8, 1) DQC_VXC_CASE(11, 1)
@@ -536,15 +543,30 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
     const int nchunk = (ntile + 15) / 16;
     const int nct = (ntile + nchunk - 1) / nchunk;
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
-    int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile)
-                 : launch_density<false>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile);
+    int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao)
+                 : launch_density<false>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao);
     if (rc) return rc;
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
 
-int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao, const double *d_w,
-                 const double *d_vrho, const double *d_vgrad, void *stream) {
+int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
+                          const double *d_dm, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ngrid <= 0) return DQC_OK;
+    const int ld = dqc_padded_nao(nao), ntile = ld / 16;
+    const int nchunk = (ntile + 15) / 16;
+    const int nct = (ntile + nchunk - 1) / nchunk;
+    dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
+    int rc = launch_density<false>(nct, grid, st, d_out, nullptr, d_ao_a, ngrid, ld, d_dm, ntile, d_ao_b);
+    if (rc) return rc;
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob, int ncomp, int ngrid, int nao,
+                         const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream) {
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     const bool gga = d_vgrad != nullptr;
@@ -556,7 +578,8 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
                                                                // slower than register staging on MI355X (profiles/)
         const int ncomp_used = gga ? 4 : 1;
         const size_t glds_lds = sizeof(double) * ((size_t)2 * ncomp_used * VG_KC * ld + (size_t)VG_KC * ld + 64);
-        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && (impl_env && impl_env[0] == 'g');
+        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && (impl_env && impl_env[0] == 'g') &&
+                              d_aob == d_ao;
         if (use_glds) {
             static const int gsizes[] = {2, 4, 8, 12, 16, 22};
             const int need = (ttot + VXC_WAVES - 1) / VXC_WAVES;
@@ -597,14 +620,24 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
         nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
         const size_t shmem = sizeof(double) * 2 * 2 * kch * ld;
         dim3 grid(nslab * nsplit);
-        int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps)
-                     : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps);
+        int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob)
+                     : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob);
         if (rc) return rc;
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
         DQC_CHECK_LAUNCH();
     }
     return DQC_OK;
+}
+
+int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao, const double *d_w,
+                 const double *d_vrho, const double *d_vgrad, void *stream) {
+    return grid_vxc_impl(d_vmat, d_ao, d_ao, ncomp, ngrid, nao, d_w, d_vrho, d_vgrad, stream);
+}
+
+int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao, const double *d_w,
+                      const double *d_v, void *stream) {
+    return grid_vxc_impl(d_vmat, d_ao_a, d_ao_b, 1, ngrid, nao, d_w, d_v, nullptr, stream);
 }
 
 }  // extern "C"

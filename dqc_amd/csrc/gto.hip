@@ -15,7 +15,7 @@ constexpr int GTO_CW = 16;  // columns staged per flush
 template <int DERIV>
 __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, const double *__restrict__ coords,
                                                        int ngrid, int nao, int ld, DevShells sh) {
-    constexpr int NC = DERIV ? 4 : 1;
+    constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : 5);  // phi | + gradient | + laplacian
     __shared__ double tile[1][NC][64][GTO_CW + 1];
     constexpr int wave = 0;
     const int lane = threadIdx.x;
@@ -43,21 +43,22 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
         const int l = sh.l[is], np = sh.nprim[is], po = sh.prim_off[is];
         const double x = px - sh.xyz[is * 3], y = py - sh.xyz[is * 3 + 1], z = pz - sh.xyz[is * 3 + 2];
         const double r2 = x * x + y * y + z * z;
-        double e0 = 0, e1 = 0;
+        double e0 = 0, e1 = 0, e2 = 0;
         for (int ip = 0; ip < np; ip++) {
             double a = sh.exps[po + ip];
             double e = sh.coefs[po + ip] * exp(-a * r2);
             e0 += e;
             e1 -= 2.0 * a * e;
+            e2 += 4.0 * a * a * e;
         }
-        double xp[DQC_LMAX + 2], yp[DQC_LMAX + 2], zp[DQC_LMAX + 2];
+        double xp[DQC_LMAX + 3], yp[DQC_LMAX + 3], zp[DQC_LMAX + 3];
         xp[0] = yp[0] = zp[0] = 1.0;
 #pragma unroll
-        for (int k = 1; k <= DQC_LMAX + 1; k++) { xp[k] = xp[k - 1] * x; yp[k] = yp[k - 1] * y; zp[k] = zp[k - 1] * z; }
+        for (int k = 1; k <= DQC_LMAX + 2; k++) { xp[k] = xp[k - 1] * x; yp[k] = yp[k - 1] * y; zp[k] = zp[k - 1] * z; }
         const int nc = (l + 1) * (l + 2) / 2, ns = 2 * l + 1;
         const double *C = C2S + C2S_OFF[l];
         for (int m = 0; m < ns; m++) {
-            double v = 0, vx = 0, vy = 0, vz = 0;
+            double v = 0, vx = 0, vy = 0, vz = 0, vl = 0;
             int c = 0;
             for (int lx = l; lx >= 0; lx--)
                 for (int ly = l - lx; ly >= 0; ly--, c++) {
@@ -71,6 +72,13 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
                         vy += cf * ((ly ? ly * yp[ly - 1] : 0.0) * xp[lx] * zp[lz] * e0 + xp[lx] * yp[ly + 1] * zp[lz] * e1);
                         vz += cf * ((lz ? lz * zp[lz - 1] : 0.0) * xp[lx] * yp[ly] * e0 + xp[lx] * yp[ly] * zp[lz + 1] * e1);
                     }
+                    if (DERIV == 2) {
+                        // d2/dx2 [x^i exp(-a x^2)] = i(i-1) x^(i-2) - 2a(2i+1) x^i + 4a^2 x^(i+2), summed over primitives
+                        const double dxx = (lx >= 2 ? lx * (lx - 1) * xp[lx - 2] : 0.0) * e0 + (2 * lx + 1) * xp[lx] * e1 + xp[lx + 2] * e2;
+                        const double dyy = (ly >= 2 ? ly * (ly - 1) * yp[ly - 2] : 0.0) * e0 + (2 * ly + 1) * yp[ly] * e1 + yp[ly + 2] * e2;
+                        const double dzz = (lz >= 2 ? lz * (lz - 1) * zp[lz - 2] : 0.0) * e0 + (2 * lz + 1) * zp[lz] * e1 + zp[lz + 2] * e2;
+                        vl += cf * (dxx * yp[ly] * zp[lz] + xp[lx] * dyy * zp[lz] + xp[lx] * yp[ly] * dzz);
+                    }
                 }
             tile[wave][0][lane][nfill] = v;
             if (DERIV) {
@@ -78,6 +86,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
                 tile[wave][2][lane][nfill] = vy;
                 tile[wave][3][lane][nfill] = vz;
             }
+            if (DERIV == 2) tile[wave][4][lane][nfill] = vl;
             nfill++;
             if (nfill == GTO_CW) {
                 flush(GTO_CW);
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
 extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
                             int natm, const int *bas, int nbas, const double *env, int nenv, void *stream) {
     using namespace dqc;
-    if (deriv != 0 && deriv != 1) { set_error("dqc_eval_gto: deriv must be 0 or 1"); return DQC_EINVAL; }
+    if (deriv < 0 || deriv > 2) { set_error("dqc_eval_gto: deriv must be 0, 1 or 2"); return DQC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
@@ -117,8 +126,10 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
         int ld = dqc_padded_nao(b.nao);
         if (deriv == 0)
             hipLaunchKernelGGL(eval_gto_kernel<0>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
-        else
+        else if (deriv == 1)
             hipLaunchKernelGGL(eval_gto_kernel<1>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+        else
+            hipLaunchKernelGGL(eval_gto_kernel<2>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
         DQC_CHECK_LAUNCH();
     }
     DQC_HIP(hipStreamSynchronize(st));  // the shell tables are freed on return

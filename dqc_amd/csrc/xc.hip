@@ -265,6 +265,107 @@ extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, con
     return DQC_OK;
 }
 
+namespace dqc {
+
+DQC_DEV D5 exp5c(D5 a) {  // exp with the argument clipped at 50 (only active in a discarded branch)
+    if (a.v >= 50.0) return c5(5.184705528587072e21);
+    const double f = exp(a.v);
+    return chain(a, f, f);
+}
+DQC_DEV D5 operator*(D5 a, double b) { return b * a; }
+DQC_DEV D5 operator+(D5 a, double b) { a.v += b; return a; }
+DQC_DEV D5 operator-(D5 a, double b) { a.v -= b; return a; }
+
+// SCAN exchange, unpolarised: slots 0 = rho, 1 = sigma, 2 = tau  (closed form of dqc/test/test_xc.py:427-455)
+DQC_DEV D5 f_mgga_x_scan(D5 r, D5 sg, D5 ta) {
+    const double a1 = 4.9479, c1x = 0.667, c2x = 0.8, dx = 1.24, mu_ak = 10.0 / 81.0;
+    const double b2 = 0.12083045973594572, b1 = 0.15663207743548518, b3 = 0.5, k1 = 0.065, h0 = 1.174;
+    const double b4 = mu_ak * mu_ak / k1 - 1606.0 / 18225.0 - b1 * b1;
+    D5 kf2 = p5((3.0 * kPi * kPi) * r, 2.0 / 3.0);
+    D5 s2 = sg / (4.0 * (r * r) * kf2);
+    D5 tau_w = sg / (8.0 * r);
+    D5 tau_unif = 0.3 * kf2 * r;
+    D5 alpha = (ta - tau_w) / tau_unif;
+    D5 oma = 1.0 - alpha;
+    D5 t1 = b1 * s2 + b2 * oma * exp5c((-b3) * (oma * oma));
+    D5 x = mu_ak * s2 * (1.0 + (b4 / mu_ak) * s2 * exp5c((-fabs(b4) / mu_ak) * s2)) + t1 * t1;
+    D5 h1 = 1.0 + k1 * (1.0 - k1 / (k1 + x));
+    D5 gs = 1.0 - exp5c(c5(-a1) / p5(s2, 0.25));
+    D5 fa = c5(0.0);
+    if (fabs(oma.v) >= 1e-12) {
+        if (alpha.v < 1.0) fa = exp5c((-c1x) * alpha / oma);
+        else fa = (-dx) * exp5c(c2x / oma);
+    }
+    D5 Fx = (h1 + fa * (h0 - h1)) * gs;
+    return (-0.75 * 0.98474502184269641) * (r * cbrt5(r)) * Fx;
+}
+
+__global__ void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
+                               double *__restrict__ vtau, const double *__restrict__ rho,
+                               const double *__restrict__ grho, const double *__restrict__ tau, int n, XcTerms terms) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double r = rho[i];
+        const double gx = grho[i], gy = grho[(size_t)n + i], gz = grho[2 * (size_t)n + i];
+        double e = 0, vr = 0, vs = 0, vt = 0;
+        if (r > 1e-15) {
+            const double sig = fmax(gx * gx + gy * gy + gz * gz, 1e-40), tk = fmax(tau[i], 1e-20);
+            const Dual dr = mk(r, 1.0, 0.0), ds = mk(sig, 0.0, 1.0);
+            for (int t = 0; t < terms.n; t++) {
+                double fv, fr, fs, ft = 0.0;
+                if (terms.id[t] == DQC_XC_MGGA_X_SCAN) {
+                    D5 f = f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                    fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
+                } else {
+                    Dual f;
+                    switch (terms.id[t]) {
+                    case DQC_XC_LDA_X: f = f_lda_x(dr); break;
+                    case DQC_XC_LDA_C_PW: f = f_lda_c_pw(dr); break;
+                    case DQC_XC_GGA_X_PBE: f = f_gga_x_pbe(dr, ds); break;
+                    default: f = f_gga_c_pbe(dr, ds); break;
+                    }
+                    fv = f.v; fr = f.r; fs = f.s;
+                }
+                e += terms.c[t] * fv; vr += terms.c[t] * fr; vs += terms.c[t] * fs; vt += terms.c[t] * ft;
+            }
+        }
+        if (edens) edens[i] = e;
+        if (vrho) vrho[i] = vr;
+        if (vgrad) {
+            vgrad[i] = 2.0 * vs * gx;
+            vgrad[(size_t)n + i] = 2.0 * vs * gy;
+            vgrad[2 * (size_t)n + i] = 2.0 * vs * gz;
+        }
+        if (vtau) vtau[i] = vt;
+    }
+}
+
+}  // namespace dqc
+
+extern "C" int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d_vtau, const double *d_rho,
+                                const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
+                                int nterm, void *stream) {
+    using namespace dqc;
+    if (nterm < 0 || nterm > 8) { set_error("dqc_xc_eval_mgga: at most 8 functional terms"); return DQC_EINVAL; }
+    if (!d_grho || !d_tau) { set_error("dqc_xc_eval_mgga: needs the density gradient and tau"); return DQC_EINVAL; }
+    XcTerms t;
+    t.n = nterm;
+    for (int i = 0; i < nterm; i++) {
+        t.id[i] = ids[i];
+        t.c[i] = coefs[i];
+        switch (ids[i]) {
+        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: case DQC_XC_MGGA_X_SCAN: break;
+        default: set_error("dqc_xc_eval_mgga: unknown functional id"); return DQC_EINVAL;
+        }
+    }
+    if (n <= 0) return DQC_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xc_mgga_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+                       d_rho, d_grho, d_tau, n, t);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
 extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
                                const double *d_rho_u, const double *d_rho_d, const double *d_grho_u,
                                const double *d_grho_d, int n, const int *ids, const double *coefs, int nterm,

@@ -106,23 +106,29 @@ class HamiltonMI355:
     def setup_grid(self, grid, xc=None) -> None:
         self.xc = xc
         self.xcfamily = 1 if xc is None else xc.family
-        if self.xcfamily not in (1, 2):
-            raise NotImplementedError("meta-GGA grids are a 'next' row (SURVEY.md 8f4)")
+        if self.xcfamily not in (1, 2, 4):
+            raise RuntimeError("unknown xc family %s" % self.xcfamily)
         self.grid = grid
         assert grid.coord_type == "cart"
         self.rgrid = grid.get_rgrid().to(self.device)
         self.dvolume = grid.get_dvolume().to(self.device).contiguous()
-        deriv = 0 if self.xcfamily == 1 else 1
-        self._ao = lib.eval_gto(self._tab, self.rgrid, deriv)  # (ngrid, ld) or (4, ngrid, ld)
+        deriv = {1: 0, 2: 1, 4: 2}[self.xcfamily]
+        self._ao = lib.eval_gto(self._tab, self.rgrid, deriv)  # (ngrid, ld), (4, ngrid, ld) or (5, ngrid, ld)
         self.is_grid_set = True
         self.is_ao_set = True
-        self.is_grad_ao_set = deriv == 1
+        self.is_grad_ao_set = deriv >= 1
+        self.is_lapl_ao_set = deriv == 2
 
     @property
     def basis(self):
         """(ngrid, nao) AO values, the attribute name of the reference (hcgto.py:168)"""
         a = self._ao if self._ao.dim() == 2 else self._ao[0]
         return a[:, :self._nao_ao]
+
+    @property
+    def grad_basis(self):
+        """(3, ngrid, nao) AO gradients (hcgto.py:179)"""
+        return self._ao[1:4, :, :self._nao_ao]
 
     # ------------------------------------------------------------------ Fock components
     def get_nuclattr(self):
@@ -180,7 +186,7 @@ class HamiltonMI355:
     def get_vext(self, vext):
         if not self.is_ao_set:
             raise RuntimeError("Please call `setup_grid(grid, xc)` to call this function")
-        ao = self._ao if self._ao.dim() == 2 else self._ao[0].contiguous()
+        ao = self._ao if self._ao.dim() == 2 else self._ao[0]
         zero = None
         mat = self._batched1(lambda v: lib.grid_vxc(ao, self._nao_ao, self.dvolume, v.contiguous(), zero), vext)
         mat = self._convert2(mat[..., :self._nao_ao, :self._nao_ao])
@@ -260,16 +266,30 @@ class HamiltonMI355:
             raise RuntimeError("Please call `setup_grid(grid, xc)` first")
         dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
         dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
-        gga = self.xcfamily == 2
+        gga = self.xcfamily in (2, 4)
         if gga and not self.is_grad_ao_set:
             raise RuntimeError("Please call `setup_grid(grid, gradlevel>=1)` to calculate the density gradient")
         rho, grho = lib.grid_density(self._ao, self._nao_ao, dao, gga)
-        return ValGrad(value=rho, grad=grho)
+        if self.xcfamily != 4:
+            return ValGrad(value=rho, grad=grho)
+        # meta-GGA extras (hcgto.py:420-438): grad_grad = sum_d dphi_d D dphi_d, lapl_basis = phi D lapl(phi)
+        if not self.is_lapl_ao_set:
+            raise RuntimeError("Please call `setup_grid(grid, gradlevel>=2)` to calculate the density gradient")
+        gg = sum(lib.grid_density_pair(self._ao[d], self._ao[d], self._nao_ao, dao) for d in (1, 2, 3))
+        lb = lib.grid_density_pair(self._ao[0], self._ao[4], self._nao_ao, dao)
+        return ValGrad(value=rho, grad=grho, lapl=(lb + gg) * 2, kin=gg * 0.5)
 
     def _get_vxc_from_potinfo(self, potinfo: ValGrad):
-        vg = potinfo.grad if self.xcfamily == 2 else None
+        vg = potinfo.grad if self.xcfamily in (2, 4) else None
         vm = lib.grid_vxc(self._ao, self._nao_ao, self.dvolume, potinfo.value.contiguous(),
                           None if vg is None else vg.contiguous())
+        if self.xcfamily == 4:  # hcgto.py:473-489
+            lapl, kin = potinfo.lapl.contiguous(), potinfo.kin
+            if bool((lapl != 0).any()):
+                vm = vm + lib.grid_vxc_pair(self._ao[0], self._ao[4], self._nao_ao, self.dvolume, 2.0 * lapl)
+            lk = (2.0 * lapl + 0.5 * kin).contiguous()
+            for d in (1, 2, 3):
+                vm = vm + lib.grid_vxc_pair(self._ao[d], self._ao[d], self._nao_ao, self.dvolume, lk)
         mat = self._convert2(vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
 

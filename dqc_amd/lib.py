@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("DQC_AMD_LIB") or os.path.join(_HERE, "libdqc_amd.so")  # override: perf-bisection variants
 _lib = None
 
-XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130}
+XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130, "mgga_x_scan": 263}
 
 
 class DqcAmdError(RuntimeError):
@@ -53,6 +53,9 @@ def load():
     lib.dqc_grid_density.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_vp]
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_grid_density_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
+    lib.dqc_grid_vxc_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_vp]
     lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
     lib.dqc_probe_stream_read.argtypes = [c_dp, c_sz, c_dp, c_vp]
     lib.dqc_probe_mfma_f64.argtypes = [c_dp, c_int, c_vp]
@@ -137,10 +140,10 @@ def jk(tiles, dm_ao, work, with_k=True):
 
 
 def eval_gto(tab, rgrid, deriv):
-    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0] or (4, ngrid, ld) [deriv 1]"""
+    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0], (4, ngrid, ld) [deriv 1] or (5, ngrid, ld) [deriv 2: + laplacian]"""
     ngrid = rgrid.shape[0]
     ld = padded_nao(tab.nao)
-    shape = (ngrid, ld) if deriv == 0 else (4, ngrid, ld)
+    shape = (ngrid, ld) if deriv == 0 else ((4, ngrid, ld) if deriv == 1 else (5, ngrid, ld))
     out = torch.empty(shape, dtype=torch.float64, device=rgrid.device)
     _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), _stream()),
            "dqc_eval_gto")
@@ -194,6 +197,38 @@ def xc_eval_pol(terms, rho_u, rho_d, grho_u, grho_d, want_e=True, want_v=True):
     _check(load().dqc_xc_eval_pol(_ptr(e), _ptr(vu), _ptr(vd), _ptr(gu), _ptr(gd), _ptr(rho_u), _ptr(rho_d),
                                   _ptr(grho_u), _ptr(grho_d), n, ids, cfs, len(terms), _stream()), "dqc_xc_eval_pol")
     return e, (vu, vd), (gu, gd)
+
+
+def xc_eval_mgga(terms, rho, grho, tau, want_e=True, want_v=True):
+    """-> edens, vrho, vgrad (3,n), vtau"""
+    n = rho.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    e = torch.empty_like(rho) if want_e else None
+    v = torch.empty_like(rho) if want_v else None
+    vg = torch.empty((3, n), dtype=torch.float64, device=rho.device) if want_v else None
+    vt = torch.empty_like(rho) if want_v else None
+    _check(load().dqc_xc_eval_mgga(_ptr(e), _ptr(v), _ptr(vg), _ptr(vt), _ptr(rho), _ptr(grho), _ptr(tau), n, ids, cfs,
+                                   len(terms), _stream()), "dqc_xc_eval_mgga")
+    return e, v, vg, vt
+
+
+def grid_density_pair(ao_a, ao_b, nao, dm_pad):
+    """sum_ij a_gi D_ij b_gj on single-component (ngrid, ld) arrays"""
+    ngrid = ao_a.shape[0]
+    out = torch.empty(ngrid, dtype=torch.float64, device=ao_a.device)
+    _check(load().dqc_grid_density_pair(_ptr(out), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(dm_pad), _stream()),
+           "dqc_grid_density_pair")
+    return out
+
+
+def grid_vxc_pair(ao_a, ao_b, nao, w, v):
+    """sym( sum_g w_g v_g a_ga b_gb ) -> (ld, ld)"""
+    ngrid, ld = ao_a.shape
+    vm = torch.empty((ld, ld), dtype=torch.float64, device=ao_a.device)
+    _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), _stream()),
+           "dqc_grid_vxc_pair")
+    return vm
 
 
 def grid_vxc(ao, nao, w, vrho, vgrad):

@@ -11,7 +11,7 @@ import torch
 from . import lib
 from .utils.datastruct import ValGrad, SpinParam
 
-_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "gga_x_pbe": 2, "gga_c_pbe": 2}
+_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "mgga_x_scan": 4}
 
 
 class BaseXC:
@@ -61,11 +61,16 @@ class LibXC(BaseXC):
         return rho.contiguous(), (None if (grad is None or self.family == 1) else grad.contiguous())
 
     def get_edensityxc(self, densinfo):
+        if isinstance(densinfo, SpinParam) and self.family == 4:
+            raise NotImplementedError("spin-polarised meta-GGA is not implemented")
         if isinstance(densinfo, SpinParam):  # polarised (libxc.py:66-85 polarised branch)
             (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
             if not self.terms:
                 return torch.zeros_like(ru)
             return lib.xc_eval_pol(self.terms, ru, rd, gu, gd, want_e=True, want_v=False)[0]
+        if self.family == 4:  # meta-GGA: rho, grad, tau (ValGrad.kin); libxc.py:124-186 MGGA branch
+            return lib.xc_eval_mgga(self.terms, densinfo.value.contiguous(), densinfo.grad.contiguous(),
+                                    densinfo.kin.contiguous(), want_e=True, want_v=False)[0]
         rho, grad = self._flat(densinfo)
         if not self.terms:
             return torch.zeros_like(rho)
@@ -73,6 +78,8 @@ class LibXC(BaseXC):
         return e
 
     def get_vxc(self, densinfo):
+        if isinstance(densinfo, SpinParam) and self.family == 4:
+            raise NotImplementedError("spin-polarised meta-GGA is not implemented")
         if isinstance(densinfo, SpinParam):  # polarised (libxc.py:40-63 polarised branch)
             (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
             if not self.terms:
@@ -80,6 +87,10 @@ class LibXC(BaseXC):
                 return SpinParam(u=z(ru, gu), d=z(rd, gd))
             _, (vu, vd), (ggu, ggd) = lib.xc_eval_pol(self.terms, ru, rd, gu, gd, want_e=False, want_v=True)
             return SpinParam(u=ValGrad(value=vu, grad=ggu), d=ValGrad(value=vd, grad=ggd))
+        if self.family == 4:
+            _, v, vg, vt = lib.xc_eval_mgga(self.terms, densinfo.value.contiguous(), densinfo.grad.contiguous(),
+                                            densinfo.kin.contiguous(), want_e=False, want_v=True)
+            return ValGrad(value=v, grad=vg, lapl=torch.zeros_like(v), kin=vt)
         rho, grad = self._flat(densinfo)
         if not self.terms:
             return ValGrad(value=torch.zeros_like(rho), grad=None if grad is None else torch.zeros_like(grad))

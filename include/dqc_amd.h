@@ -72,7 +72,8 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
 /* ---- AO values on the grid -----------------------------------------------------------------
  * Replaces GTOval_sph / GTOval_ip_sph (dqc/hamilton/intor/gtoeval.py:196-239) with the
  * to_transpose=True layout of HamiltonCGTO.setup_grid (hcgto.py:168, :179).
- * deriv 0: d_out (ngrid, ld) = phi;  deriv 1: d_out (4, ngrid, ld) = phi, d/dx, d/dy, d/dz.
+ * deriv 0: d_out (ngrid, ld) = phi;  deriv 1: d_out (4, ngrid, ld) = phi, d/dx, d/dy, d/dz;
+ * deriv 2: d_out (5, ngrid, ld) = the same plus the laplacian (GTOval_lapl_sph, hcgto.py:183-186).
  * d_coords: (ngrid, 3).  ld = dqc_padded_nao(nao); padding columns are written as zero. */
 int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
                  int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);
@@ -92,6 +93,7 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
 #define DQC_XC_LDA_C_PW 12
 #define DQC_XC_GGA_X_PBE 101
 #define DQC_XC_GGA_C_PBE 130
+#define DQC_XC_MGGA_X_SCAN 263
 int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
                 const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
                 void *stream);
@@ -103,11 +105,25 @@ int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double 
                     const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
                     int n, const int *ids, const double *coefs, int nterm, void *stream);
 
+/* meta-GGA variant (CalcMGGALibXCUnpol, dqc/xc/libxc_wrapper.py; inputs rho, grad rho, tau -- the supported
+ * functionals do not depend on the laplacian, so vlapl = 0): adds d_vtau (n).  Terms may mix LDA/GGA ids with
+ * DQC_XC_MGGA_X_SCAN. */
+int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d_vtau, const double *d_rho,
+                     const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
+                     int nterm, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
 int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao,
                  const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream);
+
+/* "pair" forms used by the meta-GGA branches (hcgto.py:420-438, 473-489), both on single-component (ngrid, ld)
+ * arrays:  d_out_g = sum_ij a_gi D_ij b_gj   and   d_vmat = sym( sum_g w_g v_g a_ga b_gb ). */
+int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
+                          const double *d_dm, void *stream);
+int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
+                      const double *d_w, const double *d_v, void *stream);
 
 /* ---- micro-benchmarks used by bench.py to price the roofline on the box it runs on ---------- */
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream);

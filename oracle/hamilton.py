@@ -96,6 +96,8 @@ class Hamilton:
         self.basis_dvolume = self.basis * self.dvolume.unsqueeze(-1)
         if self.xcfamily >= 2:
             self.grad_basis = torch.as_tensor(natives.eval_gto(self.t, rgrid, 1)).transpose(-2, -1).contiguous()
+        if self.xcfamily == 4:  # hcgto.py:183-186
+            self.lapl_basis = torch.as_tensor(natives.eval_gto(self.t, rgrid, 2)).T.contiguous()
 
     # ---- Fock components (all in the orthogonalised basis) ----
     def _pack_dm(self, dm_ao):
@@ -141,6 +143,42 @@ class Hamilton:
                     gdens[d, ioff:iend] = torch.einsum("ri,ri->r", dmao, self.grad_basis[d, ioff:iend]) * 2
         return dens, gdens
 
+    def dm2densinfo_mgga(self, dm):
+        """value, grad, lapl, kin exactly as hcgto.py:420-438"""
+        dmdmt = self.unconvert_dm((dm + dm.T) * 0.5)
+        dens, gdens = self.dm2densinfo(dm)
+        ngrid = self.basis.shape[0]
+        lapl = torch.empty(ngrid, dtype=torch.float64)
+        kin = torch.empty(ngrid, dtype=torch.float64)
+        for basis, ioff, iend in chunkify(self.basis, 0, CHUNK_MEMORY // 8):
+            dmao = basis @ dmdmt
+            lapl_basis = torch.einsum("ri,ri->r", dmao, self.lapl_basis[ioff:iend])
+            gg = 0
+            for d in range(3):
+                gb = self.grad_basis[d, ioff:iend]
+                gg = gg + torch.einsum("ri,ri->r", gb @ dmdmt, gb)
+            lapl[ioff:iend] = (lapl_basis + gg) * 2
+            kin[ioff:iend] = gg * 0.5
+        return dens, gdens, lapl, kin
+
+    def vxc_from_potinfo_mgga(self, vrho, vgrad, vlapl, vkin):
+        """hcgto.py:445-495 with the MGGA terms (:473-489)"""
+        nao = self.basis.shape[-1]
+        mat = torch.zeros((nao, nao), dtype=torch.float64)
+        for basis, ioff, iend in chunkify(self.basis, 0, CHUNK_MEMORY // 8):
+            vb = vrho[ioff:iend].unsqueeze(-1) * basis
+            vg = vgrad[:, ioff:iend] * 2
+            for d in range(3):
+                vb += vg[d].unsqueeze(-1) * self.grad_basis[d, ioff:iend]
+            vb += 2 * vlapl[ioff:iend].unsqueeze(-1) * self.lapl_basis[ioff:iend]
+            mat += self.basis_dvolume[ioff:iend].T @ vb
+            lk = (2 * vlapl[ioff:iend] + 0.5 * vkin[ioff:iend]) * self.dvolume[ioff:iend]
+            for d in range(3):
+                gb = self.grad_basis[d, ioff:iend]
+                mat += gb.T @ (lk.unsqueeze(-1) * gb)
+        mat = self.convert2(mat)
+        return (mat + mat.T) * 0.5
+
     def vxc_from_potinfo(self, vrho, vgrad):
         nao = self.basis.shape[-1]
         mat = torch.zeros((nao, nao), dtype=torch.float64)
@@ -155,7 +193,17 @@ class Hamilton:
         mat = self.convert2(mat)
         return (mat + mat.T) * 0.5
 
+    def _mgga_eval(self, dm):
+        dens, gdens, lapl, kin = self.dm2densinfo_mgga(dm)
+        sig = torch.einsum("dr,dr->r", gdens, gdens)
+        e, vr, vs, vt = self.xc.compute_mgga(dens.numpy(), sig.numpy(), kin.numpy())
+        t = torch.as_tensor
+        return t(e), t(vr), 2.0 * t(vs).unsqueeze(0) * gdens, torch.zeros_like(dens), t(vt)
+
     def get_vxc(self, dm):
+        if self.xcfamily == 4:
+            _, vr, vg, vl, vt = self._mgga_eval(dm)
+            return self.vxc_from_potinfo_mgga(vr, vg, vl, vt)
         dens, gdens = self.dm2densinfo(dm)
         vr, vg = self.xc.get_vxc(dens.numpy(), None if gdens is None else gdens.numpy())
         return self.vxc_from_potinfo(torch.as_tensor(vr), None if vg is None else torch.as_tensor(vg))
@@ -171,6 +219,8 @@ class Hamilton:
         return 0.5 * torch.einsum("ij,ji->", self.get_exchange(dm), dm)
 
     def get_e_xc(self, dm):
+        if self.xcfamily == 4:
+            return torch.sum(self.dvolume * self._mgga_eval(dm)[0])
         dens, gdens = self.dm2densinfo(dm)
         e = self.xc.get_edensityxc(dens.numpy(), None if gdens is None else gdens.numpy())
         return torch.sum(self.dvolume * torch.as_tensor(e))

@@ -372,3 +372,96 @@ def compute_pol(xc, ru, rd, gu=None, gd=None):
     else:
         vgu = vgd = None
     return e, (vr[0], vr[1]), (vgu, vgd), vs
+
+
+# =====================================================================================================
+# meta-GGA: SCAN exchange (mgga_x_scan), unpolarised.  Closed form = scan_e_true of
+# dqc/test/test_xc.py:427-455 (Sun, Ruzsinszky, Perdew PRL 115, 036402); inputs rho, sigma, tau (the
+# functional does not depend on the laplacian: vlapl = 0).  Derivatives by dual arrays over (rho, sigma, tau).
+# Reference conventions (dqc/xc/libxc.py:124-242): outputs e = zk*rho, vrho, vsigma, vtau; the potential
+# handed to the Hamiltonian is ValGrad(value=vrho, grad=2 vsigma grad rho, lapl=vlapl, kin=vtau).
+# =====================================================================================================
+def _dexp(x):
+    """exp with the argument clipped at 50 (only ever active in the branch np.where discards)"""
+    c = Dual(np.minimum(x.v, 50.0), [np.where(x.v < 50.0, a, 0.0) for a in x.d])
+    return c.fn(np.exp, np.exp)
+
+
+def mgga_x_scan(rho, sigma, tau):
+    rho, sigma, tau = (np.asarray(a, dtype=np.float64) for a in (rho, sigma, tau))
+    mask = rho > DENS_THRESHOLD
+    r_ = np.where(mask, rho, 1.0)
+    s_ = np.where(mask, np.maximum(sigma, 1e-40), 1.0)
+    t_ = np.where(mask, np.maximum(tau, 1e-20), 1.0)
+    r, sg, ta = Dual.var(r_, 0, 3), Dual.var(s_, 1, 3), Dual.var(t_, 2, 3)
+    a1, c1x, c2x, dx = 4.9479, 0.667, 0.8, 1.24
+    mu_ak = 10.0 / 81
+    b2 = (5913 / 405000.0) ** 0.5
+    b1 = 511 / 13500.0 / (2 * b2)
+    b3, k1, h0 = 0.5, 0.065, 1.174
+    b4 = mu_ak ** 2 / k1 - 1606 / 18225.0 - b1 ** 2
+    kf2 = ((3 * np.pi ** 2) * r).pow(2.0 / 3)              # kf^2
+    s2 = sg / (4.0 * r * r * kf2)
+    tau_w = sg / (8.0 * r)
+    tau_unif = 0.3 * kf2 * r
+    alpha = (ta - tau_w) / tau_unif
+    oma = 1.0 - alpha
+    x = mu_ak * s2 * (1.0 + (b4 / mu_ak) * s2 * _dexp((-abs(b4) / mu_ak) * s2)) + \
+        (b1 * s2 + b2 * oma * _dexp((-b3) * oma * oma)).pow(2.0)
+    h1 = 1.0 + k1 * (1.0 - k1 / (k1 + x))
+    gs = 1.0 - _dexp((-a1) / s2.pow(0.25))                   # sqrt(s) = s2^(1/4)
+    # switching function: exp(-c1x a/(1-a)) for a < 1, -dx exp(c2x/(1-a)) for a > 1, 0 at a = 1
+    av = alpha.v
+    lo = av < 1.0
+    safe = np.where(np.abs(1.0 - av) < 1e-12, 0.5, av)       # dummy value where the branch is exactly zero
+    al = Dual(safe, alpha.d)
+    om = 1.0 - al
+    f_lo = _dexp((-c1x) * al / om)
+    f_hi = (-dx) * _dexp(c2x / om)
+    sel = lambda a, b: np.where(np.abs(1.0 - av) < 1e-12, 0.0, np.where(lo, a, b))  # noqa: E731
+    fa = Dual(sel(f_lo.v, f_hi.v), [sel(p, q) for p, q in zip(f_lo.d, f_hi.d)])
+    Fx = (h1 + fa * (h0 - h1)) * gs
+    ex = (-0.75 * (3.0 / np.pi) ** (1.0 / 3)) * r.pow(4.0 / 3)
+    e = ex * Fx
+    z = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+    return z(e.v), z(e.d[0]), z(e.d[1]), z(e.d[2])
+
+
+_FUNCS_MGGA = {"mgga_x_scan": mgga_x_scan}
+
+
+class XCM(XC):
+    """linear combination that may contain meta-GGA terms (family 4)"""
+
+    def __init__(self, terms):
+        self.terms = terms
+        fam = [4 if n in _FUNCS_MGGA else _FUNCS[n][0] for _, n in terms]
+        self.family = max([1] + fam)
+
+    def compute_mgga(self, rho, sigma, tau):
+        e, vr, vs, vt = (np.zeros_like(rho) for _ in range(4))
+        for c, n in self.terms:
+            if n in _FUNCS_MGGA:
+                ee, a, b, t = _FUNCS_MGGA[n](rho, sigma, tau)
+                vt += c * t
+            else:
+                ee, a, b = _FUNCS[n][1](rho, sigma)
+            e += c * ee
+            vr += c * a
+            vs += c * b
+        return e, vr, vs, vt
+
+
+_get_xc_plain = get_xc
+
+
+def get_xc(xcstr):  # noqa: F811  (extends the parser above with the meta-GGA names)
+    if xcstr and any(n in xcstr for n in _FUNCS_MGGA):
+        terms = []
+        for tok in xcstr.replace(" ", "").split("+"):
+            m = re.fullmatch(r"(?:([0-9.eE+-]+)\*)?([a-z0-9_]+)", tok)
+            if m is None or (m.group(2) not in _FUNCS and m.group(2) not in _FUNCS_MGGA):
+                raise ValueError("unsupported xc term: %s" % tok)
+            terms.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2)))
+        return XCM(terms)
+    return _get_xc_plain(xcstr)

@@ -162,9 +162,10 @@ def test_ao_gradient_finite_difference():
         assert np.abs(fd - g[d]).max() < 1e-7
 
 
-GOLDEN = ["h2o_sto3g_rhf", "h2o_ccpvdz_rhf", "h2o_ccpvdz_lda_sg3", "h2o_ccpvdz_pbe_sg3", "ch4_ccpvtz_pbe_sg2"]
+GOLDEN = ["h2o_sto3g_rhf", "h2o_ccpvdz_rhf", "h2o_ccpvdz_lda_sg3", "h2o_ccpvdz_pbe_sg3", "ch4_ccpvtz_pbe_sg2",
+          "h2o_ccpvdz_scan_sg2"]
 _CFG = {"sto3g": "sto-3g", "ccpvdz": "cc-pvdz", "ccpvtz": "cc-pvtz"}
-_XC = {"rhf": None, "lda": "lda_x+lda_c_pw", "pbe": "gga_x_pbe+gga_c_pbe"}
+_XC = {"rhf": None, "lda": "lda_x+lda_c_pw", "pbe": "gga_x_pbe+gga_c_pbe", "scan": "mgga_x_scan"}
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -198,6 +199,10 @@ def test_oracle_vs_reference_generated_golden(name, golden_dir):
             rho, grho = eng.h.dm2densinfo(dmo)
             idx = g["probe_idx"]
             assert np.allclose(rho.numpy()[idx], g["probe%d_rho" % k], rtol=1e-10, atol=1e-12)
+            if "probe%d_kin" % k in g.files:  # meta-GGA extras of hcgto.py:420-438
+                _, _, lapl, kin = eng.h.dm2densinfo_mgga(dmo)
+                assert np.allclose(kin.numpy()[idx], g["probe%d_kin" % k], rtol=1e-10, atol=1e-12)
+                assert np.allclose(lapl.numpy()[idx], g["probe%d_lapl" % k], rtol=1e-9, atol=1e-10)
 
 
 def test_rys_tables_sum_to_boys(golden_dir):
@@ -317,3 +322,46 @@ def test_oracle_vs_reference_generated_polarised_golden(name, golden_dir):
         assert np.abs((SX @ vu @ SX.T).numpy() - g["probe_vu_ao"]).max() < 1e-9
         assert np.abs((SX @ vd @ SX.T).numpy() - g["probe_vd_ao"]).max() < 1e-9
         assert abs(exc - float(g["probe_exc"])) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------
+# meta-GGA: SCAN exchange
+# ------------------------------------------------------------------------------------------------
+def test_scan_closed_form_and_derivatives():
+    """scan_e_true of dqc/test/test_xc.py:427-455, and finite-difference derivatives"""
+    rng = np.random.default_rng(1)
+    n = 200
+    rho = rng.uniform(0.05, 1.5, n)
+    gr = rng.standard_normal((3, n)) * rho
+    sig = (gr * gr).sum(0)
+    tau = sig / (8 * rho) + rng.uniform(0.0, 2.0, n) * 0.3 * (3 * np.pi ** 2 * rho) ** (2 / 3) * rho
+    kf = (3 * np.pi ** 2 * rho) ** (1 / 3)
+    ng = np.sqrt(sig)
+    s = ng / (2 * rho * kf)
+    al = (tau - ng ** 2 / (8 * rho)) / (0.3 * kf ** 2 * rho)
+    s2 = s * s
+    a1, c1x, c2x, dx, mu = 4.9479, 0.667, 0.8, 1.24, 10.0 / 81
+    b2 = (5913 / 405000.) ** 0.5
+    b1 = 511 / 13500 / (2 * b2)
+    b3, k1 = 0.5, 0.065
+    b4 = mu ** 2 / k1 - 1606 / 18225 - b1 ** 2
+    x = mu * s2 * (1 + (b4 * s2 / mu) * np.exp(-abs(b4) * s2 / mu)) + (b1 * s2 + b2 * (1 - al) * np.exp(-b3 * (1 - al) ** 2)) ** 2
+    h1 = 1 + k1 * (1 - k1 / (k1 + x))
+    gs = 1 - np.exp(-a1 / np.sqrt(s))
+    with np.errstate(all="ignore"):
+        fa = np.where(1 - al > 0, np.exp(-c1x * al / (1 - al)), 0) - np.where(al - 1 > 0, dx * np.exp(c2x / (1 - al)), 0)
+    ref = -0.75 * (3 / np.pi) ** (1 / 3) * rho ** (4 / 3) * (h1 + fa * (1.174 - h1)) * gs
+    e, vr, vs, vt = oxc.mgga_x_scan(rho, sig, tau)
+    assert np.allclose(e, ref, rtol=1e-13)
+    f = lambda a, b, c: oxc.mgga_x_scan(a, b, c)[0]  # noqa: E731
+    h = 1e-6
+    assert np.allclose((f(rho + h, sig, tau) - f(rho - h, sig, tau)) / (2 * h), vr, rtol=1e-6, atol=1e-8)
+    assert np.allclose((f(rho, sig + h, tau) - f(rho, sig - h, tau)) / (2 * h), vs, rtol=1e-6, atol=1e-8)
+    assert np.allclose((f(rho, sig, tau + h) - f(rho, sig, tau - h)) / (2 * h), vt, rtol=1e-6, atol=1e-8)
+
+
+def test_rks_scan_reference_literals():
+    """dqc/test/test_ks.py:58-63, 89-111: RKS mgga_x_scan / 6-311++G** / grid 4, atol 1.3e-3 (H2 is xfail there)"""
+    for sym, d, ref in [("Li", 5.0, -14.8687500), ("N", 2.0, -109.055074), ("C O", 2.0, -112.836255)]:
+        e, _ = oh.run_scf(_diatomic(sym, d), "6-311++G**", xc="mgga_x_scan", grid=4, maxiter=150)
+        assert abs(e - ref) < 1.3e-3, (sym, e, ref)

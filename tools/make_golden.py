@@ -53,6 +53,7 @@ CASES = {
     "ch4_ccpvtz_pbe_sg2": (([6, 1, 1, 1, 1], [[0, 0, 0], [1.186, 1.186, 1.186], [-1.186, -1.186, 1.186],
                                                [-1.186, 1.186, -1.186], [1.186, -1.186, -1.186]]),
                            "cc-pvtz", "gga_x_pbe+gga_c_pbe", "sg2"),
+    "h2o_ccpvdz_scan_sg2": (H2O, "cc-pvdz", "mgga_x_scan", "sg2"),
     "benzene_ccpvdz_rhf": (benzene(), "cc-pvdz", None, None),
     "benzene_ccpvdz_lda_sg3": (benzene(), "cc-pvdz", "lda_x+lda_c_pw", "sg3"),
 }
@@ -130,6 +131,9 @@ def run_case(name):
             out["probe%d_rho" % k] = dens.value.numpy()[idx]
             if dens.grad is not None:
                 out["probe%d_grho" % k] = dens.grad.numpy()[:, idx]
+            if dens.kin is not None:
+                out["probe%d_kin" % k] = dens.kin.numpy()[idx]
+                out["probe%d_lapl" % k] = dens.lapl.numpy()[idx]
     np.savez_compressed(os.path.join(GOLD, "ref_%s.npz" % name), **out)
     print("%-28s E = %.10f  (%.1f s)" % (name, e_tot, time.time() - t0), flush=True)
 

@@ -166,7 +166,7 @@ def _install_stubs():
         def __init__(self, name, spin):
             self.spin = spin  # the reference builds both; only the unpolarised one may be evaluated
             self.name = name
-            self._fam = _oxc._FUNCS[name][0]
+            self._fam = 4 if name in _oxc._FUNCS_MGGA else _oxc._FUNCS[name][0]
 
         def get_family(self):
             return self._fam
@@ -189,6 +189,14 @@ def _install_stubs():
                 return res
             rho = rho.reshape(-1)
             sigma = np.asarray(inp["sigma"]).reshape(-1) if "sigma" in inp else None
+            if self._fam == 4:  # meta-GGA: inputs rho, sigma, lapl, tau -> zk, vrho, vsigma, vlapl, vtau
+                e, vr, vs, vt = _oxc._FUNCS_MGGA[self.name](rho, sigma, np.asarray(inp["tau"]).reshape(-1))
+                if do_exc:
+                    res["zk"] = np.where(rho > _oxc.DENS_THRESHOLD, e / np.where(rho > 0, rho, 1), 0.0)[:, None]
+                if do_vxc:
+                    res.update({"vrho": vr[:, None], "vsigma": vs[:, None], "vlapl": np.zeros_like(vr)[:, None],
+                                "vtau": vt[:, None]})
+                return res
             e, vr, vs = _oxc._FUNCS[self.name][1](rho, sigma)
             if do_exc:
                 res["zk"] = np.where(rho > _oxc.DENS_THRESHOLD, e / np.where(rho > 0, rho, 1), 0.0)[:, None]
