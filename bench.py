@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--molecules-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--dense-dm", action="store_true",
+                    help="feed dm2scp an anonymous full density matrix (no ao_orb2dm factor): full-matrix density kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for self-tests")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="self-test only: map every rank to cuda:0 (exercise the N>1 code path on a 1-GPU box)")
@@ -71,7 +73,7 @@ def main():
 
     # ---------------- one-off setup (not timed as part of the metric) ----------------
     t0 = time.perf_counter()
-    engines, dms = [], []
+    engines, dms, orbs = [], [], []
     for i in mine:
         zs, pos = M.c5_molecule(i)
         mol = dqc_amd.Mol((zs, pos), basis="cc-pvdz", grid="sg3", device=dev)
@@ -79,21 +81,26 @@ def main():
         n = eng.shape[-1]
         # density of the core-Hamiltonian guess ("1e", reference scf_qccalc.py:88-91) after one SCF update
         dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64, device=dev)))
-        dm = eng.scp2dm(eng.dm2scp(dm))
+        orb = eng.scp2orb(eng.dm2scp(dm)).contiguous()  # occupied orbitals of the second SCF iterate
         engines.append(eng)
-        dms.append(dm)
+        orbs.append(orb)
+        dms.append(eng.hamilton.ao_orb2dm(orb, eng.orb_weight))
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     h0 = engines[0].hamilton
     nao, ngrid, ld = h0._nao_ao, h0.rgrid.shape[0], h0._ld
 
-    def step(record=None):
-        for eng, dm in zip(engines, dms):
-            d = dm.clone()  # a fresh tensor: defeats the J/K memoisation, every step recomputes everything
+    def step(record=None, dense_dm=False):
+        for eng, dm, orb in zip(engines, dms, orbs):
+            # a fresh density-matrix tensor every step (defeats the J/K memoisation: everything is recomputed).
+            # Default: D = ao_orb2dm(C_occ, n) exactly as scp2dm produces it in every SCF iteration (hf.py:105-113), so
+            # the Hamiltonian knows its rank-n_occ factor; --dense-dm hands over an anonymous full matrix instead.
+            d = dm.clone() if dense_dm else eng.hamilton.ao_orb2dm(orb, eng.orb_weight)
             if record is None:
                 eng.dm2scp(d)
             else:
                 h = eng.hamilton
+                fac = h._factor_of(d)
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
                 dmdmt = (d + d.transpose(-2, -1)) * 0.5
                 dao_n = h._unconvert_dm(dmdmt).contiguous()
@@ -104,7 +111,10 @@ def main():
                 J = (J + J.transpose(-2, -1)) * 0.5
                 dao = lib.pad_matrix(dao_n, h._ld)
                 ev[2].record()
-                rho, grho = lib.grid_density(h._ao, h._nao_ao, dao, True)
+                if fac is not None:
+                    rho, grho = lib.grid_density_lr(h._ao, h._nao_ao, fac, True)
+                else:
+                    rho, grho = lib.grid_density(h._ao, h._nao_ao, dao, True)
                 ev[3].record()
                 _, v, vg = lib.xc_eval(h.xc.terms, rho, grho, want_e=False, want_v=True)
                 ev[4].record()
@@ -115,8 +125,9 @@ def main():
                 ev[6].record()
                 record.append(ev)
 
+    dense = args.dense_dm
     for _ in range(args.warmup):
-        step()
+        step(dense_dm=dense)
 
     def barrier():
         if world > 1:
@@ -127,7 +138,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(dense_dm=dense)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -138,8 +149,19 @@ def main():
     # ---------------- per-kernel HIP-event timing over K more steps (same stream as the launches) ----------------
     rec = []
     for _ in range(args.steps):
-        step(rec)
+        step(rec, dense_dm=dense)
     torch.cuda.synchronize()
+    # the same K steps with an anonymous full density matrix (no factor): the rate a caller that bypasses ao_orb2dm gets
+    elapsed_other = None
+    if not dense:
+        step(dense_dm=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(dense_dm=True)
+        barrier()
+        elapsed_other = time.perf_counter() - t0
+    norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
     names = ["jk_tiles", "orth_transforms", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
     ktime = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
 
@@ -153,7 +175,8 @@ def main():
         }
         alg_flops = {
             # 2 G n^2 per GEMM pass (+ the row dots / Psi combination); J: 2 n^4 dense-equivalent
-            "grid_density": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
+            # density: Phi . D (full matrix) or the two chained rank-n_occ GEMMs Phi . L, (Phi L) . L^T (factor form)
+            "grid_density": (2.0 * ngrid * ld * ld if dense else 4.0 * ngrid * ld * norb_pad) + 2.0 * c * ngrid * nao,
             "grid_vxc": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
             "jk_tiles": 2.0 * float(nao) ** 4,
         }
@@ -196,6 +219,9 @@ def main():
                        "molecules_per_gpu": M_per, "global_batch": nmol, "nao": nao, "ngrid": ngrid,
                        "parallelism": "molecule-sharded x%d, no data-path collective" % world},
             "per_gpu_value": M_per * args.steps / elapsed,
+            "density_matrix_input": "full matrix (no factor)" if dense else
+                                    "ao_orb2dm(C_occ, n): rank-%d factor known to the Hamiltonian" % norb_pad,
+            "value_full_matrix_dm": None if elapsed_other is None else nmol * args.steps / elapsed_other,
             "setup_s_per_rank": setup_s,
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),

@@ -16,6 +16,8 @@ algebraically identical.
 """
 from typing import List, Optional
 
+import os
+
 import torch
 
 from . import lib
@@ -67,6 +69,10 @@ class HamiltonMI355:
         self.xcfamily = 1
         self._fuse_k = False
         self._jk_cache = None
+        self._dm_factor = None
+        self._w_checked = None
+        # DQC_AMD_DENSITY=dense forces the full-matrix density kernel (A/B timing, parity tests)
+        self._lowrank_density = os.environ.get("DQC_AMD_DENSITY", "lr") != "dense"
 
     # ------------------------------------------------------------------ properties
     @property
@@ -217,8 +223,37 @@ class HamiltonMI355:
 
     # ------------------------------------------------------------------ interface to dm
     def ao_orb2dm(self, orb, orb_weight):
+        """hcgto.py:272-281.  The factor L = orb sqrt(w) of the returned matrix is remembered (keyed on the identity
+        + in-place version of the result) so that the grid pass can use the rank-n_occ density kernel."""
         orb_w = orb * orb_weight.unsqueeze(-2)
-        return torch.matmul(orb, orb_w.transpose(-2, -1))
+        dm = torch.matmul(orb, orb_w.transpose(-2, -1))
+        self._dm_factor = None
+        if orb.dim() == 2 and self._lowrank_density and lib.padded_norb(orb.shape[-1]) > 0:
+            # occupations are >= 0 in every SCF caller; a negative weight simply disables the factor path
+            self._dm_factor = (dm, dm._version, orb, orb_weight)
+        return dm
+
+    def _weights_nonneg(self, w):
+        """occupations >= 0?  Checked ONCE per weight tensor (identity + version): the check reads the device, and a
+        device->host sync in every SCF iteration would drain the launch queue."""
+        c = self._w_checked
+        if c is None or c[0] is not w or c[1] != w._version:
+            self._w_checked = c = (w, w._version, not bool((w < 0).any()))
+        return c[2]
+
+    def _factor_of(self, dm):
+        """padded AO-basis factor pair of `dm` if it came out of ao_orb2dm unmodified, else None"""
+        c = self._dm_factor
+        if c is None or c[0] is not dm or c[1] != dm._version:
+            return None
+        if len(c) == 4:  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
+            _, _, orb, w = c
+            if not self._weights_nonneg(w):
+                self._dm_factor = None
+                return None
+            l_ao = self._orthozer @ (orb * torch.sqrt(w).unsqueeze(-2))
+            self._dm_factor = c = (dm, dm._version, lib.pad_factor(l_ao, self._ld))
+        return c[2]
 
     def aodm2dens(self, dm, xyz):
         """density at arbitrary points (hcgto.py:283-299)"""
@@ -264,11 +299,15 @@ class HamiltonMI355:
     def _dm2densinfo(self, dm) -> ValGrad:
         if not self.is_ao_set:
             raise RuntimeError("Please call `setup_grid(grid, xc)` first")
-        dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
-        dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
         gga = self.xcfamily in (2, 4)
         if gga and not self.is_grad_ao_set:
             raise RuntimeError("Please call `setup_grid(grid, gradlevel>=1)` to calculate the density gradient")
+        fac = self._factor_of(dm) if self.xcfamily != 4 else None
+        if fac is not None:  # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
+            rho, grho = lib.grid_density_lr(self._ao, self._nao_ao, fac, gga)
+            return ValGrad(value=rho, grad=grho)
+        dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
+        dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
         rho, grho = lib.grid_density(self._ao, self._nao_ao, dao, gga)
         if self.xcfamily != 4:
             return ValGrad(value=rho, grad=grho)
@@ -284,10 +323,10 @@ class HamiltonMI355:
         vm = lib.grid_vxc(self._ao, self._nao_ao, self.dvolume, potinfo.value.contiguous(),
                           None if vg is None else vg.contiguous())
         if self.xcfamily == 4:  # hcgto.py:473-489
-            lapl, kin = potinfo.lapl.contiguous(), potinfo.kin
-            if bool((lapl != 0).any()):
-                vm = vm + lib.grid_vxc_pair(self._ao[0], self._ao[4], self._nao_ao, self.dvolume, 2.0 * lapl)
-            lk = (2.0 * lapl + 0.5 * kin).contiguous()
+            lapl, kin = potinfo.lapl, potinfo.kin  # lapl None: no laplacian dependence (no device read to find out)
+            if lapl is not None:
+                vm = vm + lib.grid_vxc_pair(self._ao[0], self._ao[4], self._nao_ao, self.dvolume, (2.0 * lapl).contiguous())
+            lk = ((2.0 * lapl if lapl is not None else 0.0) + 0.5 * kin).contiguous()
             for d in (1, 2, 3):
                 vm = vm + lib.grid_vxc_pair(self._ao[d], self._ao[d], self._nao_ao, self.dvolume, lk)
         mat = self._convert2(vm[:self._nao_ao, :self._nao_ao])

@@ -54,6 +54,9 @@ def load():
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_padded_norb.argtypes = [c_int]
+    lib.dqc_padded_norb.restype = c_int
+    lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
     lib.dqc_grid_density_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_grid_vxc_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_vp]
     lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
@@ -167,6 +170,34 @@ def grid_density(ao, nao, dm_pad, gga):
     grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
     _check(load().dqc_grid_density(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(dm_pad), _stream()),
            "dqc_grid_density")
+    return rho, grho
+
+
+def padded_norb(norb):
+    """factor width the low-rank density kernel is instantiated for (0: too wide, use grid_density)"""
+    return int(load().dqc_padded_norb(int(norb)))
+
+
+def pad_factor(l_ao, ld):
+    """l_ao (nao, r) -> (orb (ld, rp), orbt (rp, ld)) zero padded, or None when r is too wide"""
+    nao, r = l_ao.shape
+    rp = padded_norb(r)
+    if rp == 0:
+        return None
+    orb = torch.zeros((ld, rp), dtype=torch.float64, device=l_ao.device)
+    orb[:nao, :r] = l_ao
+    return orb, orb.t().contiguous()
+
+
+def grid_density_lr(ao, nao, factor, gga):
+    """density of D = L L^T from the padded factor pair of `pad_factor` -> rho, grho (same as grid_density)"""
+    orb, orbt = factor
+    ncomp = 1 if ao.dim() == 2 else ao.shape[0]
+    ngrid = ao.shape[-2]
+    rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
+    grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
+    _check(load().dqc_grid_density_lr(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(orb), _ptr(orbt),
+                                      orb.shape[1], _stream()), "dqc_grid_density_lr")
     return rho, grho
 
 

@@ -10,6 +10,7 @@ Everything runs on the device; the self-consistent parameter is the Fock matrix 
 as in the reference.  The fixed-point solver is Pulay DIIS on the commutator [F, D] (any convergent mixer
 gives the same fixed point; only converged energies are compared).  Restricted closed-shell and
 unrestricted (UHF/UKS, SpinParam densities, stacked Fock matrices) are implemented."""
+import os
 from typing import Optional
 
 import torch
@@ -63,10 +64,14 @@ class _Engine:
                 _, evec = torch.linalg.eigh((f + f.transpose(-2, -1)) * 0.5)
                 out.append(self.hamilton.ao_orb2dm(evec[..., :n], w))
             return SpinParam(u=out[0], d=out[1])
+        return self.hamilton.ao_orb2dm(self.scp2orb(scp), self.orb_weight)
+
+    def scp2orb(self, scp):
+        """occupied orbitals of a (restricted) Fock matrix: the `diagonalize` step of hf.py:227-247"""
         fock = (scp + scp.transpose(-2, -1)) * 0.5
-        # generalised problem F C = S C e with S = identity in the orthogonalised basis (hf.py:227-247)
+        # generalised problem F C = S C e with S = identity in the orthogonalised basis
         _, evec = torch.linalg.eigh(fock)
-        return self.hamilton.ao_orb2dm(evec[..., :self.norb], self.orb_weight)
+        return evec[..., :self.norb]
 
     def scp2scp(self, scp):
         return self.dm2scp(self.scp2dm(scp))
@@ -120,6 +125,11 @@ class SCF_QCCalc:
         pol = eng.polarized
         fs, es = [], []
         fock = eng.dm2scp(dm)
+        # restricted engines replay the Fock build as one hipGraph (dqc_amd/graph.py); "graph": False runs it eagerly
+        graphed = None
+        if not pol and opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0"):
+            from .graph import GraphedFock
+            graphed = GraphedFock(eng)
         self.converged = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
@@ -150,8 +160,12 @@ class SCF_QCCalc:
                 fmix = (c.reshape((-1,) + (1,) * fock.dim()) * torch.stack(fs)).sum(0)
             else:
                 fmix = fock
-            dm = eng.scp2dm(fmix)
-            fock = eng.dm2scp(dm)
+            if graphed is not None:
+                fock = graphed(eng.scp2orb(fmix)).clone()  # static buffers of the graph: copy out
+                dm = graphed.density_matrix().clone()
+            else:
+                dm = eng.scp2dm(fmix)
+                fock = eng.dm2scp(dm)
         self._dm = dm
         self._fock = fock
         self._has_run = True

@@ -90,7 +90,8 @@ class LibXC(BaseXC):
         if self.family == 4:
             _, v, vg, vt = lib.xc_eval_mgga(self.terms, densinfo.value.contiguous(), densinfo.grad.contiguous(),
                                             densinfo.kin.contiguous(), want_e=False, want_v=True)
-            return ValGrad(value=v, grad=vg, lapl=torch.zeros_like(v), kin=vt)
+            # no functional of the kernel set depends on the laplacian (libxc returns vlapl = 0 for SCAN): lapl=None
+            return ValGrad(value=v, grad=vg, lapl=None, kin=vt)
         rho, grad = self._flat(densinfo)
         if not self.terms:
             return ValGrad(value=torch.zeros_like(rho), grad=None if grad is None else torch.zeros_like(grad))

@@ -118,6 +118,14 @@ int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d
 int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao,
                  const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream);
 
+/* density from the orbital factor: every SCF density matrix is D = C_occ diag(n) C_occ^T
+ * (HamiltonCGTO.ao_orb2dm, hcgto.py:272-281), i.e. D = L L^T with L = C_occ sqrt(n).  Same outputs as
+ * dqc_grid_density(D) at 2 r / nao of its GEMM flops.  d_orb (ld, norb_pad) = L in the AO basis, zero padded,
+ * d_orbt (norb_pad, ld) its transpose; norb_pad = dqc_padded_norb(r) (0: r too wide, use the dense entry point). */
+int dqc_padded_norb(int norb);
+int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
+                        const double *d_orb, const double *d_orbt, int norb_pad, void *stream);
+
 /* "pair" forms used by the meta-GGA branches (hcgto.py:420-438, 473-489), both on single-component (ngrid, ld)
  * arrays:  d_out_g = sum_ij a_gi D_ij b_gj   and   d_vmat = sym( sum_g w_g v_g a_ga b_gb ). */
 int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
