@@ -186,7 +186,9 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if tj["workload"] == {"nao": nao, "ngrid": ngrid, "xc": "gga"}:
-                traffic = tj["hbm_read_bytes_per_launch"]
+                traffic = dict(tj["hbm_read_bytes_per_launch"])
+                if not dense and "grid_density_lr" in traffic:  # the factor-form density kernel was profiled separately
+                    traffic["grid_density"] = traffic["grid_density_lr"]
         except Exception:
             pass
         mfma_ceiling = lib.probe_mfma_f64_tflops(dev)
