@@ -76,45 +76,67 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
     constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
     constexpr int A_SZ = DEN_BM * DEN_SA, B_SZ = DEN_KC * LSBP;
     constexpr int NB2 = (DEN_KC * LSB / 2 + DEN_NT - 1) / DEN_NT;  // double2 loads of the B chunk per thread
+    constexpr int NKK = DEN_KC / 4;
     double *sA = lds, *sB = lds + 2 * A_SZ;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int g0 = blockIdx.x * DEN_BM;
     const size_t cs = (size_t)ngrid * ld;
+    // all global addresses are (uniform 64-bit base) + (small 32-bit lane offset)
+    const double *aoblk = ao + (size_t)g0 * ld;    // this block's 64 rows of Phi
+    const double *aoeblk = aoe + (size_t)g0 * ld;
+    const int rmax = ngrid - 1 - g0;               // last valid block-local row
     // staging roles: A chunk = 64 rows x 16 doubles -> thread (row = tid/4, 4 doubles at seg = tid%4)
     const int arow = tid >> 2, aseg = (tid & 3) * 4;
-    const double *asrc = ao + (size_t)min(g0 + arow, ngrid - 1) * ld + aseg;
+    const int aoff = min(arow, rmax) * ld + aseg;
 
     double p[4][GGA ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
+    int roff[4];  // block-local element offsets of this lane's four accumulator rows
+#pragma unroll
+    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + lr;
 
     const int nk = ld / DEN_KC;
-    for (int jc = 0; jc < ntile; jc += NCT) {
-        const int nvalid = min(NCT, ntile - jc);
+    // every panel is a full one: the last panel is shifted back to end at ntile and the tiles it shares with its
+    // predecessor (tile index < jnew) get zero D columns, so nothing is counted twice and nothing is read past ld
+    for (int jnew = 0; jnew < ntile; jnew += NCT) {
+        const int jc = min(jnew, ntile - NCT);
         v4d acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) acc[ct] = v4d{0, 0, 0, 0};
-        double2 pa[2], pb[NB2];
-        auto prefetch = [&](int kc) {
-            const double *s = asrc + kc * DEN_KC;
-            pa[0] = *reinterpret_cast<const double2 *>(s);
-            pa[1] = *reinterpret_cast<const double2 *>(s + 2);
+        double2 pa0 = make_double2(0.0, 0.0), pa1 = pa0, pb[NB2];  // scalars: an array would be left in scratch
+        int boff[NB2];
+        bool bzero[NB2];
+#pragma unroll
+        for (int i = 0; i < NB2; i++) {
+            const int e = min((tid + i * DEN_NT) * 2, DEN_KC * LSB - 2);
+            const int row = e / LSB, col = e - row * LSB;
+            boff[i] = row * ld + jc * 16 + col;
+            bzero[i] = jc * 16 + col < jnew * 16;
+        }
+        // the next chunk's loads are issued in slices between the MFMA groups of the current one (waves issue in
+        // order: a wave that first pushes its whole prefetch through the address pipe starts its MFMAs late)
+        auto prefetch_part = [&](int kc, int part) {
+            if (part == 0) {
+                const double *s_ = aoblk + kc * DEN_KC + aoff;
+                pa0 = *reinterpret_cast<const double2 *>(s_);
+                pa1 = *reinterpret_cast<const double2 *>(s_ + 2);
+            }
+            const double *d_ = dm + (size_t)kc * DEN_KC * ld;
 #pragma unroll
             for (int i = 0; i < NB2; i++) {
-                const int e = (tid + i * DEN_NT) * 2;  // element of the (KC x LSB) panel
-                const int row = e / LSB, col = e - row * LSB;
-                pb[i] = (row < DEN_KC && jc * 16 + col < ld)
-                            ? *reinterpret_cast<const double2 *>(dm + (size_t)(kc * DEN_KC + row) * ld + jc * 16 + col)
-                            : make_double2(0.0, 0.0);
+                if (i % NKK != part) continue;
+                pb[i] = *reinterpret_cast<const double2 *>(d_ + boff[i]);
+                if (bzero[i]) pb[i] = make_double2(0.0, 0.0);
             }
         };
         auto stage = [&](int buf) {
             double *a = sA + buf * A_SZ + arow * DEN_SA + aseg;
-            *reinterpret_cast<double2 *>(a) = pa[0];
-            *reinterpret_cast<double2 *>(a + 2) = pa[1];
+            *reinterpret_cast<double2 *>(a) = pa0;
+            *reinterpret_cast<double2 *>(a + 2) = pa1;
 #pragma unroll
             for (int i = 0; i < NB2; i++) {
                 const int e = (tid + i * DEN_NT) * 2;
@@ -123,49 +145,35 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             }
         };
         __syncthreads();  // buffers free (previous column panel fully consumed)
-        prefetch(0);
+#pragma unroll
+        for (int part = 0; part < NKK; part++) prefetch_part(0, part);
         stage(0);
         __syncthreads();
         for (int kc = 0; kc < nk; kc++) {
             const int buf = kc & 1;
-            if (kc + 1 < nk) prefetch(kc + 1);  // global loads in flight during the MFMAs below
+            const bool more = kc + 1 < nk;
             const double *a = sA + buf * A_SZ + (wave * 16 + lr) * DEN_SA + lk;
             const double *b = sB + buf * B_SZ + lk * LSBP + lr;
 #pragma unroll
-            for (int kk = 0; kk < DEN_KC / 4; kk++) {
+            for (int kk = 0; kk < NKK; kk++) {
+                if (more) prefetch_part(kc + 1, kk);  // global loads in flight during the MFMAs
                 const double av = a[kk * 4];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ct++)  // straight-line: panels past ld hold zeros in LDS
+                for (int ct = 0; ct < NCT; ct++)
 #ifndef ABL_DEN_NO_MFMA
                     acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
 #else
                     acc[ct][0] += av * b[kk * 4 * LSBP + ct * 16];
 #endif
             }
-            if (kc + 1 < nk) stage(buf ^ 1);
+            if (more) stage(buf ^ 1);
             __syncthreads();
         }
         // epilogue: row dots with Phi (and its gradient) in the accumulator layout, straight from global
 #ifdef ABL_DEN_NO_EPI
         if (ngrid < 0)
 #endif
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = min(g0 + wave * 16 + lk + 4 * r, ngrid - 1);
-            const double *ap = (GGA ? ao : aoe) + (size_t)row * ld + jc * 16 + lr;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ct++) {
-                if (ct < nvalid) {
-                    const double v = acc[ct][r];
-                    p[r][0] += v * ap[ct * 16];
-                    if (GGA) {
-                        p[r][1] += v * ap[cs + ct * 16];
-                        p[r][2] += v * ap[2 * cs + ct * 16];
-                        p[r][3] += v * ap[3 * cs + ct * 16];
-                    }
-                }
-            }
-        }
+        rowdot_epilogue<NCT, GGA>(acc, p, GGA ? aoblk : aoeblk, aoblk, cs, roff, jc * 16);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -557,21 +565,30 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
     constexpr int TPR = 512 / KCH;       // threads per row
     const int prow = tid / TPR, pcol = tid % TPR;
     double2 raw[NL][GGA ? 4 : 2];  // LDA mode: [0] = phi (A operand), [1] = the array Psi is built from
-    double cf[GGA ? 4 : 1];
-    bool rowok = false;
-    auto prefetch = [&](int gc) {
+    double cf[GGA ? 4 : 1], wg = 0.0;  // RAW loads here; the products are formed in stage() so that prefetch() never
+    bool rowok = false;                // waits on memory (a wait here idles the matrix pipe at every chunk start)
+    // the next chunk's loads are issued in KCH/4 slices BETWEEN the MFMA groups of the current chunk: waves issue in
+    // order, and a wave that first has to push its whole 16 KB prefetch through the CU's address pipe (128 KB per chunk
+    // for the 8 waves) starts its MFMAs thousands of cycles late
+    const double *src = ao;
+    const double *srcb = aob;
+    auto prefetch_meta = [&](int gc) {
         const int g = gc + prow;
         rowok = g < ge;
         const int gg = rowok ? g : gs;
-        const double wg = rowok ? w[gg] : 0.0;
-        cf[0] = wg * vrho[gg];
+        wg = w[gg];
+        cf[0] = vrho[gg];
         if (GGA) {
 #pragma unroll
-            for (int d = 0; d < 3; d++) cf[d + 1] = 2.0 * wg * vgrad[(size_t)d * ngrid + gg];
+            for (int d = 0; d < 3; d++) cf[d + 1] = vgrad[(size_t)d * ngrid + gg];
         }
-        const double *src = ao + (size_t)gg * ld;
+        src = ao + (size_t)gg * ld;
+        srcb = aob + (size_t)gg * ld;
+    };
+    auto prefetch_cols = [&](int part) {
 #pragma unroll
         for (int i = 0; i < NL; i++) {
+            if (i % (KCH / 4) != part) continue;
             const int c2 = (pcol + i * TPR) * 2;
             const int cc = c2 < ld ? c2 : 0;
 #pragma unroll
@@ -581,10 +598,16 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 #else
                 raw[i][d] = make_double2(1e-3 * cc, 2e-3 * d);
 #endif
-            if (!GGA) raw[i][1] = *reinterpret_cast<const double2 *>(aob + (size_t)gg * ld + cc);
+            if (!GGA) raw[i][1] = *reinterpret_cast<const double2 *>(srcb + cc);
         }
     };
     auto stage = [&](int buf) {
+        const double ww = rowok ? wg : 0.0;
+        cf[0] *= ww;
+        if (GGA) {
+#pragma unroll
+            for (int d = 1; d < 4; d++) cf[d] *= 2.0 * ww;
+        }
 #pragma unroll
         for (int i = 0; i < NL; i++) {
             const int c2 = (pcol + i * TPR) * 2;
@@ -603,16 +626,19 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
         }
     };
 
-    prefetch(gs);
+    prefetch_meta(gs);
+#pragma unroll
+    for (int part = 0; part < KCH / 4; part++) prefetch_cols(part);
     stage(0);
     __syncthreads();
     int buf = 0;
     for (int gc = gs; gc < ge; gc += KCH) {
         const bool more = gc + KCH < ge;
-        if (more) prefetch(gc + KCH);
+        if (more) prefetch_meta(gc + KCH);
         const double *base = lds + buf * BUF;
-#pragma unroll 1
+#pragma unroll
         for (int kk = 0; kk < KCH / 4; kk++) {
+            if (more) prefetch_cols(kk);
             const int ko = kk * 4 * LS;
 #pragma unroll
             for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
