@@ -671,6 +671,159 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Vxc, wave-specialised variant (the default).  Measured on MI355X: a SIMD reaches the fp64 MFMA peak (one
+// 16x16x4 per 64.6 cycles, 78 TF chip-wide) only while TWO of its waves are issuing MFMAs; a single issuing wave
+// gets one per 140 cycles (36 TF).  In vxc_kernel every wave alternates MFMA work with loads, the Psi combination
+// and LDS writes, so for part of every chunk fewer than two waves per SIMD feed the matrix pipe.  Here a block is
+// 12 waves: waves 0-7 (two per SIMD) are CONSUMERS that do nothing but fragment reads + MFMAs; waves 8-11 (one per
+// SIMD) are PRODUCERS that load the next chunk's four AO components, form Psi and write the (Phi, Psi) chunk to the
+// other LDS buffer.  One s_barrier per chunk hands the buffers over.  Tile ownership, split-K over slabs, the
+// XCD-aware block decode and the atomic epilogue are those of vxc_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int VWS_PROD = 256;                 // producer threads (4 waves)
+constexpr int VWS_NT = 512 + VWS_PROD;        // threads per block
+
+template <int MAXT, int NLP, int KCH, bool GGA>
+__global__ __launch_bounds__(VWS_NT, 3) void vxc_ws_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
+                                                          int ngrid, int ld, const double *__restrict__ w,
+                                                          const double *__restrict__ vrho,
+                                                          const double *__restrict__ vgrad, int slab, int nsplit,
+                                                          int tiles_per_split, const double *__restrict__ aob) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int LS = ld;
+    const int BUF = 2 * KCH * LS;  // phi + psi
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t cs = (size_t)ngrid * ld;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * nsplit), rem = id - grp * 8 * nsplit;
+    const int split = rem / 8, sl = grp * 8 + (rem & 7);
+    const int gs = sl * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int nchunk = (ge - gs + KCH - 1) / KCH;
+
+    if (wave >= VXC_WAVES) {
+        // ------------------------------------------------------------------ producers
+        constexpr int TPR = VWS_PROD / KCH;  // threads per chunk row
+        const int pt = tid - 512;
+        const int prow = pt / TPR, pcol = pt % TPR;
+        double2 raw[NLP][GGA ? 4 : 2];
+        double cf[GGA ? 4 : 1], wg = 0.0;
+        bool rowok = false;
+        auto prefetch = [&](int c) {
+            const int g = gs + c * KCH + prow;
+            rowok = g < ge;
+            const int gg = rowok ? g : gs;
+            wg = w[gg];
+            cf[0] = vrho[gg];
+            if (GGA) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) cf[d + 1] = vgrad[(size_t)d * ngrid + gg];
+            }
+            const double *src = ao + (size_t)gg * ld;
+#pragma unroll
+            for (int i = 0; i < NLP; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                const int cc = c2 < ld ? c2 : 0;
+#pragma unroll
+                for (int d = 0; d < (GGA ? 4 : 1); d++)
+#ifndef ABL_VWS_NO_LOAD
+                    raw[i][d] = *reinterpret_cast<const double2 *>(src + d * cs + cc);
+#else
+                    raw[i][d] = make_double2(1e-3 * cc, 2e-3 * d);
+#endif
+                if (!GGA) raw[i][1] = *reinterpret_cast<const double2 *>(aob + (size_t)gg * ld + cc);
+            }
+        };
+        auto stage = [&](int buf) {
+            const double ww = rowok ? wg : 0.0;
+            cf[0] *= ww;
+            if (GGA) {
+#pragma unroll
+                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * ww;
+            }
+#pragma unroll
+            for (int i = 0; i < NLP; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                if (c2 < ld) {
+                    double2 ph = raw[i][0];
+                    const double2 pb = GGA ? ph : raw[i][1];
+#ifndef ABL_VWS_NO_COMBINE
+                    double2 ps = make_double2(cf[0] * pb.x, cf[0] * pb.y);
+                    if (GGA) {
+#pragma unroll
+                        for (int d = 1; d < 4; d++) { ps.x += cf[d] * raw[i][d].x; ps.y += cf[d] * raw[i][d].y; }
+                    }
+#else
+                    double2 ps = pb;
+                    if (GGA) {
+#pragma unroll
+                        for (int d = 1; d < 4; d++) {
+                            ps.x = __longlong_as_double(__double_as_longlong(ps.x) ^ __double_as_longlong(raw[i][d].x));
+                            ps.y = __longlong_as_double(__double_as_longlong(ps.y) ^ __double_as_longlong(raw[i][d].y));
+                        }
+                    }
+#endif
+                    if (!rowok) ph = make_double2(0.0, 0.0);
+                    *reinterpret_cast<double2 *>(lds + buf * BUF + prow * LS + c2) = ph;
+                    *reinterpret_cast<double2 *>(lds + buf * BUF + KCH * LS + prow * LS + c2) = ps;
+                }
+            }
+        };
+        prefetch(0);
+        stage(0);
+        if (nchunk > 1) prefetch(1);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c++) {
+            if (c + 1 < nchunk) stage((c + 1) & 1);      // loads were issued a whole chunk period ago
+            if (c + 2 < nchunk) prefetch(c + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int lr = lane & 15, lk = lane >> 4;
+    const int T = ld >> 4, ttot = T * T;
+    const int tc0 = split * tiles_per_split;
+    const int tc1 = min(tc0 + tiles_per_split, ttot);
+    const int per_wave = (tc1 - tc0 + VXC_WAVES - 1) / VXC_WAVES;
+    const int t0 = tc0 + wave * per_wave;
+    const int nt = max(0, min(per_wave, tc1 - t0));
+    v4d acc[MAXT];
+    unsigned offab[MAXT];  // LDS offsets of the A (low 16 bits) and B (high 16 bits) fragments
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        const int tid2 = min(t0 + t, ttot - 1);
+        offab[t] = (unsigned)(lk * LS + (tid2 / T) * 16 + lr) | ((unsigned)(KCH * LS + lk * LS + (tid2 % T) * 16 + lr) << 16);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        const double *base = lds + (c & 1) * BUF;
+#pragma unroll
+        for (int kk = 0; kk < KCH / 4; kk++) {
+            const int ko = kk * 4 * LS;
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
+                const double a = base[ko + (offab[t] & 0xffffu)];
+                const double b = base[ko + (offab[t] >> 16)];
+                acc[t] = mfma_f64(a, b, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (t < nt) {
+            const int tl = t0 + t;
+            const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Vxc, LDS-DMA variant: the four AO components of the next 8-point chunk are copied HBM -> LDS by
 // global_load_lds_dwordx4 (no staging VGPRs), so one block keeps ALL n x n output tiles in registers
 // (up to 22 per wave) and the slab is read from HBM exactly once.  Per chunk:
@@ -845,6 +998,37 @@ static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vma
                        nsplit, tps, aob);
 }
 
+template <int MAXT, int NLP, int KCH, bool GGA>
+static void launch_vxc_ws_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
+                               const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps,
+                               const double *aob) {
+    auto kern = vxc_ws_kernel<MAXT, NLP, KCH, GGA>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);
+}
+
+template <bool GGA>
+static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat,
+                         const double *ao, int ngrid, int ld, const double *w, const double *vrho, const double *vgrad,
+                         int slab, int nsplit, int tps, const double *aob) {
+#define DQC_VWS_CASE(N, L)                                                                                          \
+    if (maxt == N && nlp == L && kch == 16) {                                                                       \
+        launch_vxc_ws_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob); \
+        return 0;                                                                                                   \
+    }                                                                                                               \
+    if (maxt == N && nlp == L && kch == 8) {                                                                        \
+        launch_vxc_ws_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);  \
+        return 0;                                                                                                   \
+    }
+    DQC_VWS_CASE(2, 1) DQC_VWS_CASE(4, 1) DQC_VWS_CASE(8, 1) DQC_VWS_CASE(11, 1)
+    DQC_VWS_CASE(2, 2) DQC_VWS_CASE(4, 2) DQC_VWS_CASE(8, 2) DQC_VWS_CASE(11, 2)
+    DQC_VWS_CASE(2, 4) DQC_VWS_CASE(4, 4) DQC_VWS_CASE(8, 4) DQC_VWS_CASE(11, 4)
+    DQC_VWS_CASE(8, 7) DQC_VWS_CASE(11, 7) DQC_VWS_CASE(8, 8) DQC_VWS_CASE(11, 8)
+#undef DQC_VWS_CASE
+    set_error("vxc_ws: internal dispatch error");
+    return DQC_EINVAL;
+}
+
 template <bool GGA>
 static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                       int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
@@ -989,6 +1173,20 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
         const size_t shmem = sizeof(double) * 2 * 2 * kch * ld;
         dim3 grid(nslab * nsplit);
+        // default: wave-specialised kernel (8 MFMA waves + 4 producer waves); the producers hold a whole chunk in
+        // registers, which bounds ld; DQC_VXC_IMPL=reg selects the unspecialised kernel
+        const int tprp = VWS_PROD / kch;
+        const int nlpneed = (ld / 2 + tprp - 1) / tprp;
+        const int nlp = nlpneed <= 1 ? 1 : (nlpneed <= 2 ? 2 : (nlpneed <= 4 ? 4 : (nlpneed <= 7 ? 7 : 8)));
+        if (nlpneed <= 8 && !(impl_env && impl_env[0] == 'r')) {
+            int rc = gga ? launch_vxc_ws<true>(maxt, nlp, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob)
+                         : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob);
+            if (rc) return rc;
+            DQC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            DQC_CHECK_LAUNCH();
+            return DQC_OK;
+        }
         int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob)
                      : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob);
         if (rc) return rc;
