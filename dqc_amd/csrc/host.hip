@@ -104,9 +104,12 @@ __global__ void probe_read_kernel(const double2 *__restrict__ buf, size_t n2, do
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
-// fp64 MFMA issue-rate probe: 8 independent 16x16x4 accumulators per wave, `iters` rounds
+// fp64 MFMA issue-rate probe: 8 independent 16x16x4 accumulators per wave, `iters` rounds.
+// __launch_bounds__(256, 2) matters: with the default bounds the compiler keeps the accumulators in AGPRs and the
+// same loop runs at 47.7 TF instead of 77.8 TF (tools/ubench/mfma_probe2.hip); the product kernels are all built for
+// >= 2 waves per SIMD, i.e. the VGPR form.
 typedef double probe_v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void probe_mfma_kernel(double *out, int iters, double a0, double b0) {
+__global__ __launch_bounds__(256, 2) void probe_mfma_kernel(double *out, int iters, double a0, double b0) {
     probe_v4d acc[8];
     for (int i = 0; i < 8; i++) acc[i] = probe_v4d{0, 0, 0, 0};
     const double a = a0 + threadIdx.x * 1e-9, b = b0;
