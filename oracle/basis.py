@@ -137,3 +137,45 @@ def make_tables(moldesc, basis):
     else:  # list (per atom) of lists of (l, alphas, raw coeffs)
         shells = [[(l, np.asarray(a, float), wfnormalize(l, a, c)) for (l, a, c) in ab] for ab in basis]
     return Tables(zs, pos, shells)
+
+
+# ------------------------------------------------------------------------------------------------
+# density fitting: auxiliary basis + concatenated tables
+# ------------------------------------------------------------------------------------------------
+def even_tempered_aux(atomz, beta=2.5):
+    """A reproducible even-tempered auxiliary basis used by the DF parity tests and available in the product as
+    auxbasis="etb" (the reference's named JK-fit sets are external data that does not ship with it; DFMol accepts any
+    list of CGTOBasis, dqc/system/mol.py:193-198).  Uncontracted shells, exponents a0 * beta^k:
+        Z <= 2 :  s x 6 (a0 0.15), p x 3 (0.4), d x 1 (0.9)
+        Z  > 2 :  s x 9 (a0 0.15), p x 6 (0.25), d x 4 (0.35), f x 2 (0.6)
+    Returns a list of (angmom, alphas, raw coeffs)."""
+    if atomz <= 2:
+        spec = [(0, 6, 0.15), (1, 3, 0.4), (2, 1, 0.9)]
+    else:
+        spec = [(0, 9, 0.15), (1, 6, 0.25), (2, 4, 0.35), (3, 2, 0.6)]
+    out = []
+    for l, n, a0 in spec:
+        for k in range(n):
+            out.append((l, [a0 * beta ** k], [1.0]))
+    return out
+
+
+def make_tables_df(moldesc, basis, auxbasis="etb"):
+    """Concatenated tables in the layout LibcintWrapper.concatenate produces (lcintwrap.py:299-370): the atoms appear
+    twice (orbital parent, then auxiliary parent), shells = orbital shells followed by auxiliary shells.
+    Returns (tables, (s0, s1), (k0, k1))."""
+    zs, pos = parse_moldesc(moldesc)
+    if isinstance(basis, str):
+        orb = [loadbasis(int(z), basis) for z in zs]
+    else:
+        orb = [[(l, np.asarray(a, float), wfnormalize(l, a, c)) for (l, a, c) in ab] for ab in basis]
+    if isinstance(auxbasis, str):
+        if not auxbasis.startswith("etb"):
+            raise RuntimeError("auxiliary basis %s is not in the fixture set" % auxbasis)
+        beta = float(auxbasis.split(":")[1]) if ":" in auxbasis else 2.5
+        auxbasis = [even_tempered_aux(int(z), beta) for z in zs]
+    aux = [[(l, np.asarray(a, float), wfnormalize(l, a, c)) for (l, a, c) in ab] for ab in auxbasis]
+    n = len(zs)
+    t = Tables(list(zs) + list(zs), list(pos) + list(pos), orb + aux)
+    nsh_orb = sum(len(x) for x in orb)
+    return t, (0, nsh_orb), (nsh_orb, t.nbas)

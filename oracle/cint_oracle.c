@@ -576,6 +576,135 @@ void orc_int2e_s4(double *out, const int *atm, int natm, const int *bas, int nba
     free(pps); free(hb); free(npp); free(ao_loc);
 }
 
+/* ------------------------------------------------------------------ */
+/* 3-centre and 2-centre 2-electron integrals (density fitting).
+ * Reference call sites: dqc/df/dfmol.py:35-40 -> intor.coul2c / coul3c -> int2c2e("r12") / int3c2e("ar12")
+ * (dqc/hamilton/intor/molintor.py:36-72, 121-130), i.e. libcint's int2c2e_sph and int3c2e_sph.
+ * libcint evaluates (ij|k) as the 4-centre integral with the fourth function replaced by the unit
+ * s-function (exponent 0, value 1): here that function is an explicit shell with exponent 0 and
+ * coefficient sqrt(4 pi) (cancelling the l = 0 solid-harmonic factor 1/sqrt(4 pi)).
+ * `bas` is the concatenated shell table (LibcintWrapper.concatenate, lcintwrap.py:299-370); the orbital shells
+ * are [sh0, sh1) and the auxiliary shells [k0, k1). */
+static const double UNIT_EXP[1] = {0.0};
+static const double UNIT_COEF[1] = {3.5449077018110320546}; /* sqrt(4 pi) */
+
+static Shell unit_shell(const double *r)
+{
+    Shell u;
+    u.l = 0; u.nprim = 1; u.exps = UNIT_EXP; u.coefs = UNIT_COEF; u.r = r;
+    return u;
+}
+
+static int range_nao(const int *bas, int s0, int s1)
+{
+    int n = 0;
+    for (int i = s0; i < s1; i++) n += 2 * bas[i * BAS_SLOTS + ANG_OF] + 1;
+    return n;
+}
+
+/* out (nao, nao, naux) row-major */
+void orc_int3c2e(double *out, const int *atm, int natm, const int *bas, int nbas, const double *env,
+                 int sh0, int sh1, int k0, int k1)
+{
+    (void)natm; (void)nbas;
+    init_herm();
+    const int nsh = sh1 - sh0, nk = k1 - k0;
+    const size_t nao = range_nao(bas, sh0, sh1), naux = range_nao(bas, k0, k1);
+    int *loc = (int *)malloc(sizeof(int) * (nsh + 1)), *kloc = (int *)malloc(sizeof(int) * (nk + 1));
+    loc[0] = 0; kloc[0] = 0;
+    for (int i = 0; i < nsh; i++) loc[i + 1] = loc[i] + 2 * bas[(sh0 + i) * BAS_SLOTS + ANG_OF] + 1;
+    for (int i = 0; i < nk; i++) kloc[i + 1] = kloc[i] + 2 * bas[(k0 + i) * BAS_SLOTS + ANG_OF] + 1;
+    /* ket tables: (aux shell, unit) */
+    PrimPair **kp = (PrimPair **)calloc(nk, sizeof(PrimPair *));
+    double **kh = (double **)calloc(nk, sizeof(double *));
+    for (int k = 0; k < nk; k++) {
+        Shell C = get_shell(k0 + k, atm, bas, env), U = unit_shell(C.r);
+        kp[k] = (PrimPair *)malloc(sizeof(PrimPair) * C.nprim);
+        kh[k] = (double *)malloc(sizeof(double) * (size_t)C.nprim * NCART(C.l) * NHERM(C.l));
+        build_prim_pairs(C, U, kp[k], kh[k]);
+    }
+#pragma omp parallel
+    {
+        size_t wsz = (size_t)MAXCART * MAXCART * MAXCART * MAXCART;
+        double *work = (double *)malloc(sizeof(double) * (2 * wsz + (size_t)MAXHERM * MAXCART * MAXCART));
+        double *sph = (double *)malloc(sizeof(double) * wsz);
+#pragma omp for schedule(dynamic)
+        for (int ij = 0; ij < nsh * (nsh + 1) / 2; ij++) {
+            int i = (int)((sqrt(8.0 * ij + 1) - 1) / 2);
+            while (i * (i + 1) / 2 > ij) i--;
+            while ((i + 1) * (i + 2) / 2 <= ij) i++;
+            int j = ij - i * (i + 1) / 2;
+            Shell A = get_shell(sh0 + i, atm, bas, env), B = get_shell(sh0 + j, atm, bas, env);
+            int np = A.nprim * B.nprim, sa = 2 * A.l + 1, sb = 2 * B.l + 1;
+            PrimPair *bp = (PrimPair *)malloc(sizeof(PrimPair) * np);
+            double *bh = (double *)malloc(sizeof(double) * (size_t)np * NCART(A.l) * NCART(B.l) * NHERM(A.l + B.l));
+            build_prim_pairs(A, B, bp, bh);
+            for (int k = 0; k < nk; k++) {
+                Shell C = get_shell(k0 + k, atm, bas, env), U = unit_shell(C.r);
+                int sc = 2 * C.l + 1;
+                eri_quartet(A, B, C, U, bp, np, kp[k], C.nprim, sph, work);
+                for (int a = 0; a < sa; a++)
+                    for (int b = 0; b < sb; b++)
+                        for (int c = 0; c < sc; c++) {
+                            size_t ia = loc[i] + a, ib = loc[j] + b, ic = kloc[k] + c;
+                            double v = sph[(a * sb + b) * sc + c];
+                            out[(ia * nao + ib) * naux + ic] = v;
+                            out[(ib * nao + ia) * naux + ic] = v;
+                        }
+            }
+            free(bp); free(bh);
+        }
+        free(work); free(sph);
+    }
+    for (int k = 0; k < nk; k++) { free(kp[k]); free(kh[k]); }
+    free(kp); free(kh); free(loc); free(kloc);
+}
+
+/* out (naux, naux) row-major */
+void orc_int2c2e(double *out, const int *atm, int natm, const int *bas, int nbas, const double *env, int k0, int k1)
+{
+    (void)natm; (void)nbas;
+    init_herm();
+    const int nk = k1 - k0;
+    const size_t naux = range_nao(bas, k0, k1);
+    int *kloc = (int *)malloc(sizeof(int) * (nk + 1));
+    kloc[0] = 0;
+    for (int i = 0; i < nk; i++) kloc[i + 1] = kloc[i] + 2 * bas[(k0 + i) * BAS_SLOTS + ANG_OF] + 1;
+    PrimPair **kp = (PrimPair **)calloc(nk, sizeof(PrimPair *));
+    double **kh = (double **)calloc(nk, sizeof(double *));
+    for (int k = 0; k < nk; k++) {
+        Shell C = get_shell(k0 + k, atm, bas, env), U = unit_shell(C.r);
+        kp[k] = (PrimPair *)malloc(sizeof(PrimPair) * C.nprim);
+        kh[k] = (double *)malloc(sizeof(double) * (size_t)C.nprim * NCART(C.l) * NHERM(C.l));
+        build_prim_pairs(C, U, kp[k], kh[k]);
+    }
+#pragma omp parallel
+    {
+        size_t wsz = (size_t)MAXCART * MAXCART * MAXCART * MAXCART;
+        double *work = (double *)malloc(sizeof(double) * (2 * wsz + (size_t)MAXHERM * MAXCART * MAXCART));
+        double *sph = (double *)malloc(sizeof(double) * wsz);
+#pragma omp for schedule(dynamic)
+        for (int k = 0; k < nk; k++) {
+            Shell C = get_shell(k0 + k, atm, bas, env), UC = unit_shell(C.r);
+            int sc = 2 * C.l + 1;
+            for (int l = 0; l <= k; l++) {
+                Shell D = get_shell(k0 + l, atm, bas, env), UD = unit_shell(D.r);
+                int sd = 2 * D.l + 1;
+                eri_quartet(C, UC, D, UD, kp[k], C.nprim, kp[l], D.nprim, sph, work);
+                for (int c = 0; c < sc; c++)
+                    for (int d = 0; d < sd; d++) {
+                        size_t ic = kloc[k] + c, id = kloc[l] + d;
+                        out[ic * naux + id] = sph[c * sd + d];
+                        out[id * naux + ic] = sph[c * sd + d];
+                    }
+            }
+        }
+        free(work); free(sph);
+    }
+    for (int k = 0; k < nk; k++) { free(kp[k]); free(kh[k]); }
+    free(kp); free(kh); free(kloc);
+}
+
 /* fills4: expand packed (npair,npair) to dense (n,n,n,n); symmetry.py:55-64 */
 void orc_fills4(double *dense, const double *packed, int n)
 {

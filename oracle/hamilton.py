@@ -41,9 +41,11 @@ def chunkify(a, dim, maxnumel):
 class Hamilton:
     """Restatement of HamiltonCGTO for isolated molecules (no DF, no efield/vext)."""
 
-    def __init__(self, tables, orthozer=True, eri_mode="dense"):
+    def __init__(self, tables, orthozer=True, eri_mode="dense", df=None):
         self.t = tables
         self.eri_mode = eri_mode  # "dense": reference formulation; "s4": packed variant for big nao
+        # df = (concatenated tables, orbital shell range, auxiliary shell range): density-fitted J (dqc/df/dfmol.py)
+        self.df = df
         ovlp = torch.as_tensor(natives.int1e("ovlp", tables))
         if orthozer:
             ev, evec = torch.linalg.eigh(ovlp)
@@ -74,7 +76,13 @@ class Hamilton:
         self.olp_mat = self.convert2(olp)
         self.kinnucl_mat = self.convert2(kin + nuc)
         self.nucl_mat = self.convert2(nuc)
-        if self.eri_mode == "dense":
+        if self.df is not None:  # DFMol.build, dfmol.py:24-58 (method "coulomb")
+            tc, orb_range, aux_range = self.df
+            self.j2c = torch.as_tensor(natives.int2c2e(tc, aux_range))            # (nxao, nxao)
+            self.j3c = torch.as_tensor(natives.int3c2e(tc, orb_range, aux_range))  # (nao, nao, nxao)
+            self.inv_j2c = torch.inverse(self.j2c)
+            self.df_el_mat = torch.matmul(self.j3c, self.inv_j2c)                  # (nao, nao, nxao)
+        elif self.eri_mode == "dense":
             el = torch.as_tensor(natives.int2e(t))
             X = self.X
             # orbconverter.convert4 (hcgto.py:132), done as four successive contractions
@@ -109,6 +117,12 @@ class Hamilton:
         return d, iu
 
     def get_elrep(self, dm):
+        if self.df is not None:  # DFMol.get_elrep, dfmol.py:60-79 (precomputed el_mat branch)
+            dao = self.unconvert_dm(dm)
+            df_coeffs = torch.einsum("ij,ijk->k", dao, self.df_el_mat)
+            mat = torch.einsum("k,ijk->ij", df_coeffs, self.j3c)
+            mat = (mat + mat.T) * 0.5
+            return self.convert2(mat)
         if self.eri_mode == "dense":
             mat = torch.einsum("ij,ijkl->kl", dm, self.el_mat)
         else:  # packed-s4 variant (same numbers, different storage)
@@ -124,6 +138,8 @@ class Hamilton:
 
     def get_exchange(self, dm):
         """returns -K/2 (hcgto.py:234)"""
+        if self.df is not None:  # hcgto.py:229-230
+            raise RuntimeError("Exact exchange cannot be computed with density fitting")
         assert self.eri_mode == "dense"
         mat = -0.5 * torch.einsum("il,ijkl->ijk", dm, self.el_mat).sum(dim=-3)
         return (mat + mat.T) * 0.5
@@ -241,11 +257,11 @@ def nuclei_energy(zs, pos):
 class Engine:
     """RHF (xc=None) / RKS engine: dm2scp, scp2dm, dm2energy as in hf.py / ks.py."""
 
-    def __init__(self, tables, xc=None, grid="sg3", hf=None, eri_mode="dense"):
+    def __init__(self, tables, xc=None, grid="sg3", hf=None, eri_mode="dense", df=None):
         self.t = tables
         self.is_hf = (xc is None) if hf is None else hf
         self.xc = None if self.is_hf else (oxc.get_xc(xc) if isinstance(xc, str) else xc)
-        self.h = Hamilton(tables, eri_mode=eri_mode).build()
+        self.h = Hamilton(tables, eri_mode=eri_mode, df=df).build()
         if not self.is_hf:
             rgrid, dvol = ogrid.get_predefined_grid(grid, tables.atomzs, tables.atompos)
             self.h.setup_grid(rgrid, dvol, self.xc)
@@ -317,9 +333,10 @@ class Engine:
         return self.dm2energy(self.dm)
 
 
-def run_scf(moldesc, basis, xc=None, grid="sg3", **kw):
+def run_scf(moldesc, basis, xc=None, grid="sg3", auxbasis=None, **kw):
     t = obasis.make_tables(moldesc, basis)
-    eng = Engine(t, xc=xc, grid=grid)
+    df = obasis.make_tables_df(moldesc, basis, auxbasis) if auxbasis is not None else None
+    eng = Engine(t, xc=xc, grid=grid, df=df)
     e = eng.run(**kw)
     return e, eng
 

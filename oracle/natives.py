@@ -69,6 +69,25 @@ def int2e(t):
     return fills4(int2e_s4(t), t.nao)
 
 
+def int3c2e(tc, orb_range, aux_range):
+    """(ij|k) over the concatenated tables `tc`: orbital shells [s0, s1), auxiliary shells [k0, k1) -> (nao, nao, naux)"""
+    (s0, s1), (k0, k1) = orb_range, aux_range
+    nao = int(tc.ao_loc[s1] - tc.ao_loc[s0])
+    naux = int(tc.ao_loc[k1] - tc.ao_loc[k0])
+    out = np.zeros((nao, nao, naux))
+    lib().orc_int3c2e(_p(out), *_tab(tc), *(ctypes.c_int(int(v)) for v in (s0, s1, k0, k1)))
+    return out
+
+
+def int2c2e(tc, aux_range):
+    """(k|l) over auxiliary shells [k0, k1) of the concatenated tables -> (naux, naux)"""
+    k0, k1 = aux_range
+    naux = int(tc.ao_loc[k1] - tc.ao_loc[k0])
+    out = np.zeros((naux, naux))
+    lib().orc_int2c2e(_p(out), *_tab(tc), ctypes.c_int(int(k0)), ctypes.c_int(int(k1)))
+    return out
+
+
 def eval_gto(t, rgrid, deriv=0):
     """deriv 0: (nao, ngrid); 1: (3, nao, ngrid); 2: laplacian (nao, ngrid)"""
     rgrid = np.ascontiguousarray(rgrid, dtype=np.float64)

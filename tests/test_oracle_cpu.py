@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import basis as ob, natives as nat, grid as og, xc as oxc, hamilton as oh
 from tests import molecules as M
@@ -365,3 +366,68 @@ def test_rks_scan_reference_literals():
     for sym, d, ref in [("Li", 5.0, -14.8687500), ("N", 2.0, -109.055074), ("C O", 2.0, -112.836255)]:
         e, _ = oh.run_scf(_diatomic(sym, d), "6-311++G**", xc="mgga_x_scan", grid=4, maxiter=150)
         assert abs(e - ref) < 1.3e-3, (sym, e, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# density fitting: 2c2e / 3c2e integrals and the DFMol restatement
+# ------------------------------------------------------------------------------------------------
+def test_int2c2e_closed_form_and_limits():
+    """(s_a|s_b) = 2 pi^2.5 / (a b sqrt(a+b)) F0(a b R^2 / (a+b)) for unit-coefficient s primitives (times the
+    1/(4 pi) of the two l = 0 solid harmonics and the wfnormalize factors); the unit-function construction equals the
+    4-centre integral with a vanishing-exponent partner"""
+    from math import erf, pi, sqrt
+    a, b, R = 0.9, 0.35, 1.7
+    aux = [[(0, [a], [1.0])], [(0, [b], [1.0])]]
+    t, orb, ax = ob.make_tables_df(([1, 1], [[0, 0, 0], [0, 0, R]]), "sto-3g", aux)
+    j2 = nat.int2c2e(t, ax)
+    na, nb = ob.wfnormalize(0, [a], [1.0])[0], ob.wfnormalize(0, [b], [1.0])[0]
+    T = a * b / (a + b) * R * R
+    f0 = 0.5 * sqrt(pi / T) * erf(sqrt(T))
+    ref = 2 * pi ** 2.5 / (a * b * sqrt(a + b)) * f0 * na * nb / (4 * pi)
+    assert abs(j2[0, 1] - ref) < 1e-13 and abs(j2[0, 1] - j2[1, 0]) < 1e-15
+    ref_aa = 2 * pi ** 2.5 / (a * a * sqrt(2 * a)) * na * na / (4 * pi)
+    assert abs(j2[0, 0] - ref_aa) < 1e-13
+    # (ij|k) against the 4-centre code with an almost-constant fourth function: eps -> 0, value sqrt(4 pi) / sqrt(4 pi) = 1
+    mol = ([8, 1], [[0, 0, 0], [0.3, 1.2, -0.4]])
+    auxd = [ob.even_tempered_aux(8)[i] for i in (0, 9, 15, 19)]  # one s, p, d, f shell
+    tc, orbr, auxr = ob.make_tables_df(mol, "3-21G", [auxd, []])
+    j3 = nat.int3c2e(tc, orbr, auxr)
+    eps = 1e-9
+    shells = [[(l, al, c) for (l, al, c) in ob.loadbasis(8, "3-21G")] + [(l, np.asarray(al, float), ob.wfnormalize(l, al, c)) for (l, al, c) in auxd] +
+              [(0, np.array([eps]), np.array([3.5449077018110318]))], ob.loadbasis(1, "3-21G")]
+    t4 = ob.Tables(mol[0], mol[1], shells)
+    eri = nat.int2e(t4)
+    no = len(ob.loadbasis(8, "3-21G"))
+    nao_o = sum(2 * l + 1 for (l, _, _) in ob.loadbasis(8, "3-21G"))
+    naux = j3.shape[-1]
+    u = nao_o + naux                       # AO index of the quasi-unit function
+    idx_o = list(range(nao_o)) + list(range(u + 1, t4.nao))  # oxygen AOs, then hydrogen AOs
+    ref3 = eri[np.ix_(idx_o, idx_o, range(nao_o, nao_o + naux), [u])][..., 0]
+    assert np.abs(j3 - ref3).max() < 1e-7 * np.abs(j3).max()
+
+
+def test_df_restatement_vs_reference_generated_golden(golden_dir):
+    GOLD = golden_dir
+    """oracle DF-J / DF-KS engine vs the reference's own DFMol + KS code run through the harness"""
+    for name, basis, xc in [("h2o_ccpvdz_pbe_sg2_etb", "cc-pvdz", "gga_x_pbe+gga_c_pbe"),
+                            ("ch4_ccpvtz_lda_sg2_etb", "cc-pvtz", "lda_x+lda_c_pw")]:
+        g = np.load(os.path.join(GOLD, "refdf_%s.npz" % name))
+        mol = (g["atomzs"].tolist(), g["atompos"].tolist())
+        tc, orb, aux = ob.make_tables_df(mol, basis, "etb")
+        j2, j3 = nat.int2c2e(tc, aux), nat.int3c2e(tc, orb, aux)
+        assert j2.shape[0] == int(g["naux"])
+        assert np.allclose(np.diag(j2), g["j2c_diag"], rtol=1e-12) and np.allclose(j2[0], g["j2c_row0"], rtol=1e-12, atol=1e-14)
+        pi = g["j3c_probe_idx"]
+        assert np.allclose(j3[pi[0], pi[1], pi[2]], g["j3c_probe"], rtol=1e-12, atol=1e-14)
+        assert np.allclose(j3.sum(-1), g["j3c_sum_k"], rtol=1e-11, atol=1e-12)
+        e, eng = oh.run_scf(mol, basis, xc=xc, grid="sg2", auxbasis="etb")
+        assert abs(e - float(g["e_tot"])) < 1e-8
+        S = nat.int1e("ovlp", eng.t)
+        X = eng.h.X.numpy()
+        for k in range(2):
+            Dao = g["probe%d_dm_ao" % k]
+            dmo = torch.as_tensor(X.T @ S @ Dao @ S @ X)
+            J = (S @ X) @ eng.h.get_elrep(dmo).numpy() @ (S @ X).T
+            assert np.allclose(J, g["probe%d_J_ao" % k], rtol=1e-10, atol=1e-11)
+        with pytest.raises(RuntimeError):
+            eng.h.get_exchange(dmo)

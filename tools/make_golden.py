@@ -138,6 +138,53 @@ def run_case(name):
     print("%-28s E = %.10f  (%.1f s)" % (name, e_tot, time.time() - t0), flush=True)
 
 
+# density-fitted cases: (moldesc, basis, xc, grid, auxbasis) through the reference's own
+# Mol.densityfit -> DFMol (dqc/system/mol.py:170-204, dqc/df/dfmol.py) with the even-tempered test auxiliary basis
+CASES_DF = {
+    "h2o_ccpvdz_pbe_sg2_etb": (H2O, "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2", "etb"),
+    "ch4_ccpvtz_lda_sg2_etb": (CASES["ch4_ccpvtz_pbe_sg2"][0], "cc-pvtz", "lda_x+lda_c_pw", "sg2", "etb"),
+}
+
+
+def run_case_df(name):
+    from dqc.utils.datastruct import CGTOBasis
+    moldesc, basis, xc, grid, auxname = CASES_DF[name]
+    t0 = time.time()
+    mol = rh.ref_mol(moldesc, basis, grid=grid)
+    aux = [[CGTOBasis(angmom=l, alphas=torch.tensor(a, dtype=torch.float64), coeffs=torch.tensor(c, dtype=torch.float64))
+            for (l, a, c) in obasis.even_tempered_aux(int(z))] for z in moldesc[0]]
+    mol.densityfit(method="coulomb", auxbasis=aux)
+    qc = dqc.KS(mol, xc=xc)
+    qc.run()
+    eng = qc._engine
+    dm = qc.aodm()
+    hamilt = mol.get_hamiltonian()
+    X = hamilt._orthozer._orthozer.detach()
+    tabs = obasis.make_tables(moldesc, basis)
+    S = torch.as_tensor(natives.int1e("ovlp", tabs))
+    SX = S @ X
+    to_ao = lambda m: (SX @ m @ SX.T).numpy()  # noqa: E731
+    df = hamilt.df
+    j2c, j3c = df.j2c.numpy(), df.j3c.numpy()
+    rng = np.random.default_rng(4)
+    pi = rng.integers(0, j3c.shape[0], 64), rng.integers(0, j3c.shape[1], 64), rng.integers(0, j3c.shape[2], 64)
+    out = {"atomzs": np.array(moldesc[0]), "atompos": np.array(moldesc[1], dtype=float), "e_tot": float(qc.energy()),
+           "e_elrep": float(hamilt.get_e_elrep(dm)), "dm_conv_ao": (X @ dm @ X.T).numpy(),
+           "fock_conv_ao": to_ao(eng.dm2scp(dm)), "naux": j2c.shape[0],
+           "j2c_diag": np.diag(j2c).copy(), "j2c_row0": j2c[0].copy(), "j2c_fro": np.linalg.norm(j2c),
+           "j3c_fro": np.linalg.norm(j3c), "j3c_probe_idx": np.stack(pi), "j3c_probe": j3c[pi],
+           "j3c_sum_k": j3c.sum(-1)}
+    nel = int(sum(moldesc[0]))
+    XtS = SX.T
+    for k in range(2):
+        Dao = seeded_dm_ao(tabs.nao, nel, S.numpy(), 4321 + k)
+        dmo = XtS @ torch.as_tensor(Dao) @ XtS.T
+        out["probe%d_dm_ao" % k] = Dao
+        out["probe%d_J_ao" % k] = to_ao(hamilt.get_elrep(dmo).fullmatrix())
+    np.savez_compressed(os.path.join(GOLD, "refdf_%s.npz" % name), **out)
+    print("%-28s E = %.10f  naux %d (%.1f s)" % (name, out["e_tot"], j2c.shape[0], time.time() - t0), flush=True)
+
+
 def run_case_pol(name):
     """UHF / UKS through the reference's own polarised engine code (SpinParam plumbing of hf.py / ks.py / hcgto.py)"""
     from dqc.utils.datastruct import SpinParam
@@ -214,5 +261,5 @@ def write_kats():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     write_kats()
-    for c in (sys.argv[1:] or SMALL + list(CASES_POL)):
-        (run_case_pol if c in CASES_POL else run_case)(c)
+    for c in (sys.argv[1:] or SMALL + list(CASES_POL) + list(CASES_DF)):
+        (run_case_pol if c in CASES_POL else (run_case_df if c in CASES_DF else run_case))(c)

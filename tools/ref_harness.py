@@ -233,9 +233,26 @@ def _intor_init(self, int_nmgr, wrappers):
     self.int_type = int_nmgr.int_type
 
 
+class _TC:  # adapter for concatenated wrappers (LibcintWrapper.concatenate): tables + ao_loc
+    def __init__(self, w):
+        self.atm, self.bas, self.env = w.atm_bas_env
+        self.natm, self.nbas = self.atm.shape[0], self.bas.shape[0]
+        loc = [0]
+        for b in self.bas:
+            loc.append(loc[-1] + 2 * int(b[1]) + 1)
+        self.ao_loc = loc
+
+
 def _calc(self):
     w = self.wrappers[0]
     name = self.int_nmgr.get_intgl_name(w.spherical)
+    if name.startswith("int2c2e"):  # coul2c(auxbw): dfmol.py:35
+        assert self.wrappers[0].shell_idxs == self.wrappers[1].shell_idxs
+        return torch.as_tensor(_nat.int2c2e(_TC(w), w.shell_idxs), dtype=w.dtype)
+    if name.startswith("int3c2e"):  # coul3c(basisw, basisw, auxbw): dfmol.py:37-38
+        w0, w1, w2 = self.wrappers
+        assert w0.shell_idxs == w1.shell_idxs
+        return torch.as_tensor(_nat.int3c2e(_TC(w0), w0.shell_idxs, w2.shell_idxs), dtype=w.dtype)
     assert all(ww is w for ww in self.wrappers), "harness: full-range integrals only"
     assert w.shell_idxs == (0, w.atm_bas_env[1].shape[0])
     t = _T(w)
