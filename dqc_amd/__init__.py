@@ -1,7 +1,7 @@
 """dqc_amd -- MI355X (gfx950) native SCF Fock-build engine behind DQC's Hamiltonian API.
 
 Public names mirror the reference's top-level API (dqc/__init__.py:1-3)."""
-from .utils.datastruct import CGTOBasis, AtomCGTOBasis, SpinParam, ValGrad  # noqa: F401
+from .utils.datastruct import CGTOBasis, AtomCGTOBasis, SpinParam, ValGrad, DensityFitInfo  # noqa: F401
 from .basis import loadbasis, parse_moldesc  # noqa: F401
 from .xc import get_xc, BaseXC, LibXC  # noqa: F401
 from .hamilton import HamiltonMI355  # noqa: F401

@@ -114,6 +114,28 @@ def make_atombases(atomzs, atompos, basis) -> List[AtomCGTOBasis]:
     return out
 
 
+def even_tempered_aux(atomz: int, beta: float = 2.5, dtype=torch.float64) -> List[CGTOBasis]:
+    """Built-in even-tempered auxiliary basis, auxbasis="etb[:beta]": uncontracted shells with exponents a0 beta^k
+        Z <= 2 :  s x 6 (a0 0.15), p x 3 (0.4), d x 1 (0.9)
+        Z  > 2 :  s x 9 (a0 0.15), p x 6 (0.25), d x 4 (0.35), f x 2 (0.6)
+    DFMol takes any list of CGTOBasis (dqc/system/mol.py:193-198); this one needs no external data."""
+    spec = [(0, 6, 0.15), (1, 3, 0.4), (2, 1, 0.9)] if atomz <= 2 else [(0, 9, 0.15), (1, 6, 0.25), (2, 4, 0.35), (3, 2, 0.6)]
+    out = []
+    for l, n, a0 in spec:
+        for k in range(n):
+            b = CGTOBasis(angmom=l, alphas=torch.tensor([a0 * beta ** k], dtype=dtype), coeffs=torch.tensor([1.0], dtype=dtype))
+            b.wfnormalize_()
+            out.append(b)
+    return out
+
+
+def make_aux_atombases(atomzs, atompos, auxbasis) -> List[AtomCGTOBasis]:
+    if isinstance(auxbasis, str) and auxbasis.lower().startswith("etb"):
+        beta = float(auxbasis.split(":")[1]) if ":" in auxbasis else 2.5
+        auxbasis = [even_tempered_aux(int(z), beta) for z in atomzs]
+    return make_atombases(atomzs, atompos, auxbasis)
+
+
 def make_tables(atombases: List[AtomCGTOBasis]):
     """libcint-style (atm, bas, env) numpy tables, the layout of LibcintWrapper
     (dqc/hamilton/intor/lcintwrap.py:37-86): 20 pad doubles, then per atom xyz+0 followed by that atom's

@@ -1,0 +1,141 @@
+// df.hip -- 2-centre and 3-centre 2-electron integrals for density fitting.
+// Replaces  intor.coul2c(auxbw) = int2c2e_sph  and  intor.coul3c(basisw, basisw, auxbw) = int3c2e_sph
+// (reference call sites dqc/df/dfmol.py:35-40, dqc/hamilton/intor/molintor.py:36-72, 121-130, 624-665).
+//
+// libcint evaluates (ij|k) and (k|l) as 4-centre integrals whose missing functions are the unit s-function.  The
+// same construction is used here: one extra shell with exponent 0 and coefficient sqrt(4 pi) (cancelling the l = 0
+// solid-harmonic factor) is appended to the shell table, the ket "pair" list is (auxiliary shell, unit), and the
+// Rys shell-quartet kernel of eri_core.hpp runs unchanged in its 3C / 2C output modes: <LA,LB,LC,0> and <LA,0,LC,0>.
+#include "eri_core.hpp"
+
+namespace dqc {
+
+struct DfSetup {
+    Basis b;
+    HostPairs orb, aux;
+    DevPool pool;
+    DevShells ds;
+    DevPairs dorb{nullptr, nullptr, nullptr}, daux{nullptr, nullptr, nullptr};
+    EriOut og{0, 0, 0, 0};
+};
+
+static int df_setup(DfSetup &s, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, int sh0,
+                    int sh1, int k0, int k1, bool need_orb, hipStream_t st, const char *who) {
+    int rc = parse_basis(s.b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    if (sh0 < 0 || sh1 > nbas || sh0 > sh1 || k0 < 0 || k1 > nbas || k0 > k1) {
+        set_error(std::string(who) + ": shell ranges outside the table");
+        return DQC_EINVAL;
+    }
+    for (int i = 0; i < nbas; i++) {
+        const bool used = (need_orb && i >= sh0 && i < sh1) || (i >= k0 && i < k1);
+        if (used && s.b.shells[i].l > ERI_LMAX) {
+            set_error(std::string(who) + ": shells above f are not supported");
+            return DQC_EINVAL;
+        }
+    }
+    auto ao_of = [&](int sh) { return sh < nbas ? s.b.shells[sh].ao_off : s.b.nao; };
+    s.og.ao0 = ao_of(sh0);
+    s.og.nao = ao_of(sh1) - ao_of(sh0);
+    s.og.aux0 = ao_of(k0);
+    s.og.naux = ao_of(k1) - ao_of(k0);
+    // the unit shell
+    HostShell u;
+    u.atom = 0; u.l = 0; u.nprim = 1; u.ao_off = s.b.nao; u.prim_off = (int)s.b.exps.size();
+    u.r[0] = u.r[1] = u.r[2] = 0.0;
+    s.b.exps.push_back(0.0);
+    s.b.coefs.push_back(3.5449077018110320546);  // sqrt(4 pi)
+    s.b.shells.push_back(u);
+    const int unit = nbas;
+    if (need_orb) build_pairs(s.b, s.orb, sh0, sh1);
+    build_pairs(s.b, s.aux, k0, k1, unit);
+    if ((rc = upload_shells(s.ds, s.b, s.pool, st))) { set_error(std::string(who) + ": device upload failed"); return rc; }
+    auto up = [&](HostPairs &hp, DevPairs &dp) {
+        int *d_sh = nullptr, *d_off = nullptr;
+        double *d_pp = nullptr;
+        int r;
+        if ((r = s.pool.upload(&d_sh, hp.sh, st)) || (r = s.pool.upload(&d_off, hp.pp_off, st)) ||
+            (r = s.pool.upload(&d_pp, hp.pp, st)))
+            return r;
+        dp = DevPairs{d_sh, d_off, d_pp};
+        return 0;
+    };
+    if (need_orb && (rc = up(s.orb, s.dorb))) { set_error(std::string(who) + ": device upload failed"); return rc; }
+    if ((rc = up(s.aux, s.daux))) { set_error(std::string(who) + ": device upload failed"); return rc; }
+    return 0;
+}
+
+template <int LA, int LB, int LC, int MODE>
+static int launch_df_class(double *out, const DfSetup &s, hipStream_t st) {
+    using Cfg = EriCfg<LA, LB, LC, 0>;
+    const HostPairs &hb = MODE == ERI_OUT_3C ? s.orb : s.aux;
+    const DevPairs &db = MODE == ERI_OUT_3C ? s.dorb : s.daux;
+    const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2;
+    const int nb = hb.cls_count[cb], nk = s.aux.cls_count[ck];
+    if (nb == 0 || nk == 0) return 0;
+    const long long ntask = (long long)nb * nk;
+    const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
+    auto kern = eri_kernel<LA, LB, LC, 0, MODE>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, out, s.ds, db, s.daux, hb.cls_start[cb],
+                       nb, s.aux.cls_start[ck], nk, 0, ntask, s.og);
+    DQC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int LC>
+static int launch_3c_ket(double *out, const DfSetup &s, hipStream_t st) {
+    int rc;
+#define DQC_3C(LA, LB) \
+    if ((rc = launch_df_class<LA, LB, LC, ERI_OUT_3C>(out, s, st))) return rc;
+    DQC_3C(0, 0) DQC_3C(1, 0) DQC_3C(1, 1) DQC_3C(2, 0) DQC_3C(2, 1) DQC_3C(2, 2) DQC_3C(3, 0) DQC_3C(3, 1) DQC_3C(3, 2)
+    DQC_3C(3, 3)
+#undef DQC_3C
+    return 0;
+}
+
+template <int LC>
+static int launch_2c_ket(double *out, const DfSetup &s, hipStream_t st) {
+    int rc;
+#define DQC_2C(LA) \
+    if ((rc = launch_df_class<LA, 0, LC, ERI_OUT_2C>(out, s, st))) return rc;
+    DQC_2C(0) DQC_2C(1) DQC_2C(2) DQC_2C(3)
+#undef DQC_2C
+    return 0;
+}
+
+}  // namespace dqc
+
+extern "C" {
+
+int dqc_int3c2e(double *d_out, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, int sh0,
+                int sh1, int k0, int k1, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    DfSetup s;
+    int rc = df_setup(s, atm, natm, bas, nbas, env, nenv, sh0, sh1, k0, k1, true, st, "dqc_int3c2e");
+    if (rc) return rc;
+    if (s.og.nao == 0 || s.og.naux == 0) return DQC_OK;
+    if ((rc = launch_3c_ket<0>(d_out, s, st)) || (rc = launch_3c_ket<1>(d_out, s, st)) ||
+        (rc = launch_3c_ket<2>(d_out, s, st)) || (rc = launch_3c_ket<3>(d_out, s, st)))
+        return rc;
+    DQC_HIP(hipStreamSynchronize(st));
+    return DQC_OK;
+}
+
+int dqc_int2c2e(double *d_out, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, int k0,
+                int k1, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    DfSetup s;
+    int rc = df_setup(s, atm, natm, bas, nbas, env, nenv, 0, 0, k0, k1, false, st, "dqc_int2c2e");
+    if (rc) return rc;
+    if (s.og.naux == 0) return DQC_OK;
+    if ((rc = launch_2c_ket<0>(d_out, s, st)) || (rc = launch_2c_ket<1>(d_out, s, st)) ||
+        (rc = launch_2c_ket<2>(d_out, s, st)) || (rc = launch_2c_ket<3>(d_out, s, st)))
+        return rc;
+    DQC_HIP(hipStreamSynchronize(st));
+    return DQC_OK;
+}
+
+}  // extern "C"

@@ -15,267 +15,9 @@
 //     scattered straight into the 8-fold-unique TILE storage the J/K kernels stream (no nao^4 tensor).
 //   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
 //   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
-#include <algorithm>
-
-#include "common.hpp"
+#include "eri_core.hpp"
 
 namespace dqc {
-
-constexpr int ERI_LMAX = 3;
-
-struct DevPairs {
-    const int *sh;       // (npair, 2): first shell has the higher (or equal) l
-    const int *pp_off;   // (npair+1)
-    const double *pp;    // (npp, 5): p, Px, Py, Pz, ca*cb*Kab
-};
-
-__host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
-
-DQC_DEV void tile_put(double *__restrict__ tiles, int i, int j, int k, int l, double v) {
-    const int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
-    if (I < J || K < L) return;
-    const int IJ = I * (I + 1) / 2 + J, KL = K * (K + 1) / 2 + L;
-    if (IJ < KL) return;
-    const size_t T = (size_t)IJ * (IJ + 1) / 2 + KL;
-    tiles[T * DQC_TILE_SZ + ((((i & 7) * 8 + (j & 7)) * 8 + (k & 7)) * 8 + (l & 7))] = v;
-}
-
-template <int LA, int LB, int LC, int LD>
-struct EriCfg {
-    static constexpr int NR = (LA + LB + LC + LD) / 2 + 1;
-    static constexpr int NCA = c_ncart(LA), NCB = c_ncart(LB), NCC = c_ncart(LC), NCD = c_ncart(LD);
-    static constexpr int SA = 2 * LA + 1, SB = 2 * LB + 1, SC = 2 * LC + 1, SD = 2 * LD + 1;
-    static constexpr int NOUT = NCA * NCB * NCC * NCD;
-    static constexpr int G1 = (LA + 1) * (LB + 1) * (LC + 1) * (LD + 1);
-    static constexpr int TPQ = NOUT <= 9 ? 1 : (NOUT <= 81 ? 4 : (NOUT <= 324 ? 16 : (NOUT <= 1296 ? 64 : 256)));
-    static constexpr int QPB = 256 / TPQ;
-    static constexpr int NPT = (NOUT + TPQ - 1) / TPQ;
-    static constexpr int GSZ = 3 * NR * G1;
-    static constexpr int BUF1 = SA * NCB * NCC * NCD;
-    static constexpr int REG0 = GSZ > NOUT + BUF1 ? GSZ : NOUT + BUF1;
-    static constexpr int REGION = REG0 | 1;  // odd stride: conflict-free when every lane owns a region
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)REGION * QPB;
-};
-
-template <int LA, int LB, int LC, int LD>
-__global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, DevShells sh, DevPairs prs, int b0,
-                                                  int nb, int k0, int nk, int same, long long ntask) {
-    using Cfg = EriCfg<LA, LB, LC, LD>;
-    constexpr int NR = Cfg::NR, TPQ = Cfg::TPQ, QPB = Cfg::QPB, NPT = Cfg::NPT, G1 = Cfg::G1, NOUT = Cfg::NOUT;
-    constexpr int NMAX = LA + LB, MMAX = LC + LD;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ int s_maxq;
-
-    const int tid = threadIdx.x;
-    const int q = tid / TPQ, s = tid % TPQ;  // quartet slot in the block, lane inside the quartet group
-    double *reg = lds + (size_t)q * Cfg::REGION;
-
-    long long task = (long long)blockIdx.x * QPB + q;
-    const bool active = task < ntask;
-    if (!active) task = ntask - 1;
-    int ib, ik;
-    if (same) {
-        long long r = (long long)((sqrt(8.0 * (double)task + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > task) r--;
-        while ((r + 1) * (r + 2) / 2 <= task) r++;
-        ib = (int)r;
-        ik = (int)(task - r * (r + 1) / 2);
-    } else {
-        ib = (int)(task / nk);
-        ik = (int)(task % nk);
-    }
-    ib += b0;
-    ik += k0;
-    const int ish = prs.sh[2 * ib], jsh = prs.sh[2 * ib + 1], ksh = prs.sh[2 * ik], lsh = prs.sh[2 * ik + 1];
-    double A[3], Cc[3], AB[3], CD[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-        A[d] = sh.xyz[ish * 3 + d];
-        AB[d] = A[d] - sh.xyz[jsh * 3 + d];
-        Cc[d] = sh.xyz[ksh * 3 + d];
-        CD[d] = Cc[d] - sh.xyz[lsh * 3 + d];
-    }
-    const int pb0 = prs.pp_off[ib], nbp = prs.pp_off[ib + 1] - pb0;
-    const int pk0 = prs.pp_off[ik], nkp = prs.pp_off[ik + 1] - pk0;
-    const int nq = active ? nbp * nkp : 0;
-
-    int maxq = nq;
-    if (TPQ > 1) {  // block-uniform trip count so that the barriers below are legal
-        if (tid == 0) s_maxq = 0;
-        __syncthreads();
-        atomicMax(&s_maxq, nq);
-        __syncthreads();
-        maxq = s_maxq;
-    }
-
-    // output ownership: lane s owns Cartesian outputs n = s + TPQ*m
-    int oidx[NPT];
-    double acc[NPT];
-#pragma unroll
-    for (int m = 0; m < NPT; m++) {
-        acc[m] = 0.0;
-        int n = s + TPQ * m;
-        if (n >= NOUT) n = NOUT - 1;
-        const int cd = n % Cfg::NCD, cc = (n / Cfg::NCD) % Cfg::NCC, cb = (n / (Cfg::NCD * Cfg::NCC)) % Cfg::NCB,
-                  ca = n / (Cfg::NCD * Cfg::NCC * Cfg::NCB);
-        int ax, ay, az, bx, by, bz, cx, cy, cz, dx, dy, dz;
-        cart_pow(LA, ca, ax, ay, az);
-        cart_pow(LB, cb, bx, by, bz);
-        cart_pow(LC, cc, cx, cy, cz);
-        cart_pow(LD, cd, dx, dy, dz);
-        const int ixx = ((ax * (LB + 1) + bx) * (LC + 1) + cx) * (LD + 1) + dx;
-        const int iyy = ((ay * (LB + 1) + by) * (LC + 1) + cy) * (LD + 1) + dy;
-        const int izz = ((az * (LB + 1) + bz) * (LC + 1) + cz) * (LD + 1) + dz;
-        oidx[m] = ixx | (iyy << 10) | (izz << 20);
-    }
-
-    for (int iq = 0; iq < maxq; iq++) {
-        const bool on = iq < nq;
-        // ---------------- phase A: 2D integrals for every (direction, root) ----------------
-        if (on) {
-            const int ipb = iq / nkp, ipk = iq - ipb * nkp;
-            const double *pb = prs.pp + (size_t)(pb0 + ipb) * 5, *pk = prs.pp + (size_t)(pk0 + ipk) * 5;
-            const double p = pb[0], qq = pk[0];
-            const double P[3] = {pb[1], pb[2], pb[3]}, Q[3] = {pk[1], pk[2], pk[3]};
-            const double pq = p + qq, rho = p * qq / pq;
-            const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
-            const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
-            const double pref = pb[4] * pk[4] * 34.986836655249725 / (p * qq * sqrt(pq));  // 2 pi^(5/2)
-            for (int item = s; item < 3 * NR; item += TPQ) {
-                const int d = item / NR, r = item - d * NR;
-                double u, w;
-                rys_root1<NR>(X, r, u, w);
-                const double b00 = 0.5 * u / pq;
-                const double b10 = 0.5 * (1.0 - u * qq / pq) / p;
-                const double b01 = 0.5 * (1.0 - u * p / pq) / qq;
-                const double c00 = (P[d] - A[d]) - u * qq / pq * PQ[d];
-                const double c0p = (Q[d] - Cc[d]) + u * p / pq * PQ[d];
-                // vertical recurrence g[n][m], n <= NMAX, m <= MMAX
-                double g[NMAX + 1][MMAX + 1];
-                g[0][0] = (d == 2) ? w * pref : 1.0;
-#pragma unroll
-                for (int n = 0; n < NMAX; n++) g[n + 1][0] = c00 * g[n][0] + (n ? n * b10 * g[n - 1][0] : 0.0);
-#pragma unroll
-                for (int m = 0; m < MMAX; m++)
-#pragma unroll
-                    for (int n = 0; n <= NMAX; n++)
-                        g[n][m + 1] = c0p * g[n][m] + (m ? m * b01 * g[n][m - 1] : 0.0) + (n ? n * b00 * g[n - 1][m] : 0.0);
-                // horizontal recurrence on the bra, in place: h[i][j][m]
-                double h[NMAX + 1][LB + 1][MMAX + 1];
-#pragma unroll
-                for (int i = 0; i <= NMAX; i++)
-#pragma unroll
-                    for (int m = 0; m <= MMAX; m++) h[i][0][m] = g[i][m];
-#pragma unroll
-                for (int j = 1; j <= LB; j++)
-#pragma unroll
-                    for (int i = 0; i <= NMAX - j; i++)
-#pragma unroll
-                        for (int m = 0; m <= MMAX; m++) h[i][j][m] = h[i + 1][j - 1][m] + AB[d] * h[i][j - 1][m];
-                // horizontal recurrence on the ket and store
-                double *G = reg + (size_t)(d * NR + r) * G1;
-#pragma unroll
-                for (int i = 0; i <= LA; i++)
-#pragma unroll
-                    for (int j = 0; j <= LB; j++) {
-                        double kk[MMAX + 1][LD + 1];
-#pragma unroll
-                        for (int m = 0; m <= MMAX; m++) kk[m][0] = h[i][j][m];
-#pragma unroll
-                        for (int l = 1; l <= LD; l++)
-#pragma unroll
-                            for (int m = 0; m <= MMAX - l; m++) kk[m][l] = kk[m + 1][l - 1] + CD[d] * kk[m][l - 1];
-#pragma unroll
-                        for (int k = 0; k <= LC; k++)
-#pragma unroll
-                            for (int l = 0; l <= LD; l++) G[((i * (LB + 1) + j) * (LC + 1) + k) * (LD + 1) + l] = kk[k][l];
-                    }
-            }
-        }
-        if (TPQ > 1) __syncthreads();
-        // ---------------- phase B: accumulate the Cartesian outputs ----------------
-        if (on) {
-#pragma unroll
-            for (int m = 0; m < NPT; m++) {
-                const int ixx = oidx[m] & 1023, iyy = (oidx[m] >> 10) & 1023, izz = oidx[m] >> 20;
-                double v = 0.0;
-#pragma unroll
-                for (int r = 0; r < NR; r++)
-                    v += reg[r * G1 + ixx] * reg[(NR + r) * G1 + iyy] * reg[(2 * NR + r) * G1 + izz];
-                acc[m] += v;
-            }
-        }
-        if (TPQ > 1) __syncthreads();
-    }
-
-    // ---------------- phase C: Cartesian -> solid harmonics (LDS), scatter to tiles ----------------
-    double *buf0 = reg, *buf1 = reg + NOUT;
-#pragma unroll
-    for (int m = 0; m < NPT; m++) {
-        const int n = s + TPQ * m;
-        if (n < NOUT) buf0[n] = acc[m];
-    }
-    if (TPQ > 1) __syncthreads();
-    {
-        // index a: buf0[ca][rest] -> buf1[ma][rest]
-        constexpr int R0 = Cfg::NCB * Cfg::NCC * Cfg::NCD;
-        const double *C = C2S + C2S_OFF[LA];
-        for (int e = s; e < Cfg::SA * R0; e += TPQ) {
-            const int ma = e / R0, rest = e - ma * R0;
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCA; c++) v += C[ma * Cfg::NCA + c] * buf0[c * R0 + rest];
-            buf1[e] = v;
-        }
-    }
-    if (TPQ > 1) __syncthreads();
-    {
-        // index b: buf1[ma][cb][rest] -> buf0[ma][mb][rest]
-        constexpr int R1 = Cfg::NCC * Cfg::NCD;
-        const double *C = C2S + C2S_OFF[LB];
-        for (int e = s; e < Cfg::SA * Cfg::SB * R1; e += TPQ) {
-            const int rest = e % R1, mb = (e / R1) % Cfg::SB, ma = e / (R1 * Cfg::SB);
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCB; c++) v += C[mb * Cfg::NCB + c] * buf1[(ma * Cfg::NCB + c) * R1 + rest];
-            buf0[e] = v;
-        }
-    }
-    if (TPQ > 1) __syncthreads();
-    {
-        // index c: buf0[mab][cc][cd] -> buf1[mab][mc][cd]
-        const double *C = C2S + C2S_OFF[LC];
-        for (int e = s; e < Cfg::SA * Cfg::SB * Cfg::SC * Cfg::NCD; e += TPQ) {
-            const int cd = e % Cfg::NCD, mc = (e / Cfg::NCD) % Cfg::SC, mab = e / (Cfg::NCD * Cfg::SC);
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCC; c++) v += C[mc * Cfg::NCC + c] * buf0[(mab * Cfg::NCC + c) * Cfg::NCD + cd];
-            buf1[e] = v;
-        }
-    }
-    if (TPQ > 1) __syncthreads();
-    if (active) {
-        // index d and scatter: value (ma, mb, mc, md) -> all block-canonical images
-        const double *C = C2S + C2S_OFF[LD];
-        const int ai = sh.ao_off[ish], aj = sh.ao_off[jsh], ak = sh.ao_off[ksh], al = sh.ao_off[lsh];
-        for (int e = s; e < Cfg::SA * Cfg::SB * Cfg::SC * Cfg::SD; e += TPQ) {
-            const int md = e % Cfg::SD, mabc = e / Cfg::SD;
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCD; c++) v += C[md * Cfg::NCD + c] * buf1[mabc * Cfg::NCD + c];
-            const int mc = mabc % Cfg::SC, mb = (mabc / Cfg::SC) % Cfg::SB, ma = mabc / (Cfg::SC * Cfg::SB);
-            const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
-            tile_put(tiles, i, j, k, l, v);
-            tile_put(tiles, j, i, k, l, v);
-            tile_put(tiles, i, j, l, k, v);
-            tile_put(tiles, j, i, l, k, v);
-            tile_put(tiles, k, l, i, j, v);
-            tile_put(tiles, l, k, i, j, v);
-            tile_put(tiles, k, l, j, i, v);
-            tile_put(tiles, l, k, j, i, v);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // expansion of the tile storage to the reference's dense tensor (tests / tiny systems)
@@ -295,58 +37,8 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
 }
 
 // ---------------------------------------------------------------------------------------------
-// host: pair tables and class dispatch
+// class dispatch
 // ---------------------------------------------------------------------------------------------
-struct HostPairs {
-    std::vector<int> sh, pp_off;
-    std::vector<double> pp;
-    int cls_start[16], cls_count[16];  // class c(la,lb) = la(la+1)/2+lb
-};
-
-static void build_pairs(const Basis &b, HostPairs &hp) {
-    const int nsh = (int)b.shells.size();
-    struct P { int a, b, cls, npp; std::vector<double> pp; };
-    std::vector<P> all;
-    all.reserve((size_t)nsh * (nsh + 1) / 2);
-    for (int i = 0; i < nsh; i++)
-        for (int j = 0; j <= i; j++) {
-            int a = i, c = j;
-            if (b.shells[c].l > b.shells[a].l) std::swap(a, c);
-            const HostShell &A = b.shells[a], &B = b.shells[c];
-            P pr;
-            pr.a = a; pr.b = c; pr.cls = A.l * (A.l + 1) / 2 + B.l;
-            double ab2 = 0;
-            for (int d = 0; d < 3; d++) ab2 += (A.r[d] - B.r[d]) * (A.r[d] - B.r[d]);
-            for (int ip = 0; ip < A.nprim; ip++)
-                for (int jp = 0; jp < B.nprim; jp++) {
-                    const double ea = b.exps[A.prim_off + ip], eb = b.exps[B.prim_off + jp], p = ea + eb;
-                    const double arg = ea * eb / p * ab2;
-                    if (arg > 100.0) continue;  // exp(-100) ~ 4e-44: numerically zero contribution
-                    const double K = std::exp(-arg);
-                    pr.pp.push_back(p);
-                    for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
-                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K);
-                }
-            pr.npp = (int)pr.pp.size() / 5;
-            all.push_back(std::move(pr));
-        }
-    std::stable_sort(all.begin(), all.end(), [](const P &x, const P &y) {
-        if (x.cls != y.cls) return x.cls < y.cls;
-        return x.npp > y.npp;
-    });
-    for (int c = 0; c < 16; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
-    hp.pp_off.push_back(0);
-    for (size_t n = 0; n < all.size(); n++) {
-        const P &pr = all[n];
-        if (hp.cls_count[pr.cls] == 0) hp.cls_start[pr.cls] = (int)n;
-        hp.cls_count[pr.cls]++;
-        hp.sh.push_back(pr.a);
-        hp.sh.push_back(pr.b);
-        hp.pp.insert(hp.pp.end(), pr.pp.begin(), pr.pp.end());
-        hp.pp_off.push_back((int)hp.pp.size() / 5);
-    }
-}
-
 template <int LA, int LB, int LC, int LD>
 static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
@@ -356,10 +48,10 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     const int same = cb == ck;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
     const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
-    (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
-                       hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask);
+    hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
+                       dp, hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask, EriOut{0, 0, 0, 0});
     DQC_CHECK_LAUNCH();
     return 0;
 }

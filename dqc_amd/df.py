@@ -1,0 +1,81 @@
+"""Density-fitted Coulomb operator: the MI355X counterpart of the reference's DFMol (dqc/df/dfmol.py:12-101).
+
+    build():      j2c = (k|l)  [dqc_int2c2e],  j3c = (ij|k)  [dqc_int3c2e]  over the concatenated orbital + auxiliary
+                  shell tables (LibcintWrapper.concatenate, lcintwrap.py:299-370); Cholesky factor of j2c
+    get_elrep():  c = j2c^-1 (j3c^T vec D_ao),  J_ao = j3c c,  J = X^T J_ao X      (dfmol.py:60-79)
+
+The reference precomputes inv(j2c) and el_mat = j3c inv(j2c) (a second (nao, nao, naux) tensor); here the fit
+coefficients come from a Cholesky solve, which is the same linear system without the extra tensor or the explicit
+inverse.  The two contractions are matrix-vector products over j3c viewed as (nao^2, naux) -- plain library GEMV
+(rocBLAS through torch), HBM-bound at 2 x 8 nao^2 naux bytes per Fock build (0.76 GB for a 20-atom cc-pVDZ molecule
+with ~1100 auxiliary functions, against 2.0 GB for the exact-J tile stream).  `method="overlap"` is not implemented in
+the reference either (dfmol.py:41-45).
+"""
+from typing import List
+
+import torch
+
+from . import lib
+from .basis import make_tables
+from .linop import LinearOperator
+from .utils.datastruct import AtomCGTOBasis, DensityFitInfo
+
+
+class DFMI355:
+    def __init__(self, dfinfo: DensityFitInfo, atombases: List[AtomCGTOBasis], orthozer: torch.Tensor, device):
+        self.dfinfo = dfinfo
+        self._atombases = atombases
+        self._orthozer = orthozer
+        self.device = device
+        self._is_built = False
+        if dfinfo.method not in ("coulomb", "overlap"):
+            raise RuntimeError("Unknown density fitting method: %s" % dfinfo.method)
+
+    def build(self):
+        if self.dfinfo.method == "overlap":  # dfmol.py:41-45
+            raise NotImplementedError("Density fitting with overlap minimization is not implemented")
+        # concatenated tables: atoms of the orbital parent, then of the auxiliary parent; shells likewise
+        atm, bas, env, _ = make_tables(list(self._atombases) + list(self.dfinfo.auxbases))
+        tab = lib.Tables(atm, bas, env)
+        nsh_orb = sum(len(ab.bases) for ab in self._atombases)
+        orb_range, aux_range = (0, nsh_orb), (nsh_orb, tab.nbas)
+        self._j2c = lib.int2c2e(tab, aux_range, self.device)             # (nxao, nxao)
+        self._j3c = lib.int3c2e(tab, orb_range, aux_range, self.device)  # (nao, nao, nxao)
+        self._chol = torch.linalg.cholesky(self._j2c)
+        self._is_built = True
+        return self
+
+    def get_elrep(self, dm: torch.Tensor) -> LinearOperator:
+        if not self._is_built:
+            raise RuntimeError("Please call `build()` before `get_elrep`")
+        X = self._orthozer
+        nao, _, naux = self._j3c.shape
+        j3 = self._j3c.reshape(nao * nao, naux)
+
+        def one(d):
+            dao = X @ d @ X.transpose(-2, -1)
+            t = j3.transpose(0, 1) @ dao.reshape(-1, 1)              # (naux, 1)
+            c = torch.cholesky_solve(t, self._chol)                   # fit coefficients, dfmol.py:70-73
+            mat = (j3 @ c).reshape(nao, nao)                          # dfmol.py:75
+            mat = (mat + mat.transpose(-2, -1)) * 0.5
+            return X.transpose(-2, -1) @ mat @ X
+
+        if dm.dim() == 2:
+            mat = one(dm)
+        else:
+            bshape = dm.shape[:-2]
+            mat = torch.stack([one(d) for d in dm.reshape(-1, *dm.shape[-2:])]).reshape(*bshape, X.shape[-1], X.shape[-1])
+        return LinearOperator.m(mat, is_hermitian=True)
+
+    @property
+    def j2c(self) -> torch.Tensor:
+        return self._j2c
+
+    @property
+    def j3c(self) -> torch.Tensor:
+        return self._j3c
+
+    def getparamnames(self, methodname: str, prefix: str = "") -> List[str]:
+        if methodname == "get_elrep":
+            return [prefix + "_chol", prefix + "_j3c", prefix + "_orthozer"]
+        raise KeyError("getparamnames has no %s method" % methodname)

@@ -33,8 +33,7 @@ class HamiltonMI355:
                  aoparamzer: str = "qr", device="cuda"):
         if not spherical:
             raise NotImplementedError("only spherical AOs (the reference default) are implemented on MI355X")
-        if df is not None:
-            raise NotImplementedError("density fitting is a 'next' row (SURVEY.md 8f2), not in this build")
+        self._dfoptions = df
         if efield is not None:
             raise NotImplementedError("electric-field integrals are outside the MI355X hot path")
         if aoparamzer not in ("qr", "matexp"):
@@ -60,6 +59,11 @@ class HamiltonMI355:
             self._orthozer = evec[:, acc] * ev[acc] ** (-0.5)
         else:
             self._orthozer = torch.eye(self._nao_ao, dtype=self.dtype, device=self.device)
+        if df is None:
+            self._df = None
+        else:  # hcgto.py:60-64
+            from .df import DFMI355
+            self._df = DFMI355(df, atombases, self._orthozer, self.device)
         self._vext = vext
         self.is_grid_set = False
         self.is_ao_set = False
@@ -85,7 +89,7 @@ class HamiltonMI355:
 
     @property
     def df(self):
-        return None
+        return self._df
 
     # ------------------------------------------------------------------ orbital converter
     def _convert2(self, mat):
@@ -102,8 +106,11 @@ class HamiltonMI355:
         self.olp_mat = self._convert2(self._ovlp_ao)
         self.kinnucl_mat = self._convert2(kin + nuc)
         self.nucl_mat = self._convert2(nuc)
-        self._tiles = lib.eri_tiles(tab, dev)
-        self._jkwork = lib.jk_workspace(self._nao_ao, dev)
+        if self._df is None:
+            self._tiles = lib.eri_tiles(tab, dev)
+            self._jkwork = lib.jk_workspace(self._nao_ao, dev)
+        else:  # hcgto.py:133-135
+            self._df.build()
         self.is_built = True
         if self._vext is not None:
             self.kinnucl_mat = self.kinnucl_mat + self.get_vext(self._vext).fullmatrix()
@@ -176,11 +183,15 @@ class HamiltonMI355:
     def get_elrep(self, dm):
         if not self.is_built:
             raise RuntimeError("Please call `build()` before `get_elrep`")
+        if self._df is not None:  # hcgto.py:212-214
+            return self._df.get_elrep(dm)
         mat = self._batched(lambda d: self._jk_orth(d, False)[0], dm)
         return LinearOperator.m(mat, is_hermitian=True)
 
     def get_exchange(self, dm):
         """returns -K/2 (hcgto.py:234); SpinParam input uses K(2 D_sigma) per spin (hcgto.py:238-241)"""
+        if self._df is not None:  # hcgto.py:229-230
+            raise RuntimeError("Exact exchange cannot be computed with density fitting")
         if isinstance(dm, SpinParam):
             return SpinParam(u=self.get_exchange(2 * dm.u), d=self.get_exchange(2 * dm.d))
         if not self.is_built:

@@ -47,6 +47,8 @@ def load():
     tab = [ip, c_int, ip, c_int, dp, c_int]
     lib.dqc_int1e.argtypes = [c_int, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
+    lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
+    lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
     lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
@@ -120,6 +122,28 @@ def eri_tiles(tab, device):
     tiles = torch.empty(ntile * 4096, dtype=torch.float64, device=device)
     _check(load().dqc_eri_fill_tiles(_ptr(tiles), *tab.args(), _stream()), "dqc_eri_fill_tiles")
     return tiles
+
+
+def _range_nao(tab, s0, s1):
+    return int(sum(2 * int(b[1]) + 1 for b in tab.bas[s0:s1]))
+
+
+def int3c2e(tab, orb_range, aux_range, device):
+    """(ij|k) over concatenated tables: orbital shells [s0, s1), auxiliary shells [k0, k1) -> (nao, nao, naux)"""
+    (s0, s1), (k0, k1) = orb_range, aux_range
+    nao, naux = _range_nao(tab, s0, s1), _range_nao(tab, k0, k1)
+    out = torch.zeros((nao, nao, naux), dtype=torch.float64, device=device)
+    _check(load().dqc_int3c2e(_ptr(out), *tab.args(), s0, s1, k0, k1, _stream()), "dqc_int3c2e")
+    return out
+
+
+def int2c2e(tab, aux_range, device):
+    """(k|l) over the auxiliary shells [k0, k1) of concatenated tables -> (naux, naux)"""
+    k0, k1 = aux_range
+    naux = _range_nao(tab, k0, k1)
+    out = torch.zeros((naux, naux), dtype=torch.float64, device=device)
+    _check(load().dqc_int2c2e(_ptr(out), *tab.args(), k0, k1, _stream()), "dqc_int2c2e")
+    return out
 
 
 def eri_dense(tiles, nao):

@@ -31,6 +31,8 @@ class Mol:
         self._nelecs = nelecs
         self._nup = (int(round(nelecs)) + spin) // 2
         self._ndn = (int(round(nelecs)) - spin) // 2
+        self._efield, self._vext = efield, vext
+        self._orthogonalize_basis, self._aoparamzer = orthogonalize_basis, ao_parameterizer
         self._hamilton = HamiltonMI355(self._atombases, spherical=True, efield=efield, vext=vext,
                                        orthozer=orthogonalize_basis, aoparamzer=ao_parameterizer,
                                        device=self._device)
@@ -57,7 +59,22 @@ class Mol:
         return self._nelecs
 
     def densityfit(self, method=None, auxbasis=None):
-        raise NotImplementedError("density fitting is a 'next' row (SURVEY.md 8f2)")
+        """dqc/system/mol.py:170-204: switch the Hamiltonian to the density-fitted Coulomb operator.
+        auxbasis: list (per atom) of lists of CGTOBasis, a basis name shipped under dqc_amd/data/basis, or "etb[:beta]"
+        (the built-in even-tempered set, dqc_amd.basis.even_tempered_aux).  The reference's default "cc-pvtz-jkfit"
+        and the other named JK-fit sets are external data (basis_set_exchange) that is not available offline."""
+        from .basis import make_aux_atombases
+        from .utils.datastruct import DensityFitInfo
+        if method is None:
+            method = "coulomb"
+        if auxbasis is None:
+            auxbasis = "cc-pvtz-jkfit"
+        auxbases = make_aux_atombases(self._atomzs, self._atompos, auxbasis)
+        df = DensityFitInfo(method=method, auxbases=auxbases)
+        self._hamilton = HamiltonMI355(self._atombases, spherical=True, df=df, efield=self._efield, vext=self._vext,
+                                       orthozer=self._orthogonalize_basis, aoparamzer=self._aoparamzer,
+                                       device=self._device)
+        return self
 
     def get_hamiltonian(self):
         return self._hamilton

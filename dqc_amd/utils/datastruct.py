@@ -44,6 +44,13 @@ class AtomCGTOBasis:
 
 
 @dataclass
+class DensityFitInfo:
+    """dqc/utils/datastruct.py:73-76"""
+    method: str
+    auxbases: List[AtomCGTOBasis]
+
+
+@dataclass
 class SpinParam(Generic[T]):
     u: T
     d: T

@@ -112,6 +112,17 @@ int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d
                      const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
                      int nterm, void *stream);
 
+/* ---- density-fitting integrals  (DFMol.build, dqc/df/dfmol.py:24-58) --------------------------
+ * intor.coul2c(auxbw) = int2c2e_sph and intor.coul3c(basisw, basisw, auxbw) = int3c2e_sph
+ * (dqc/hamilton/intor/molintor.py:36-72, 121-130).  atm/bas/env are the CONCATENATED host tables of
+ * LibcintWrapper.concatenate (dqc/hamilton/intor/lcintwrap.py:299-370): orbital shells [sh0, sh1), auxiliary
+ * shells [k0, k1) -- the `shell_idxs` of the two sub-wrappers.  Outputs are row-major device arrays:
+ * d_j3c (nao, nao, naux) and d_j2c (naux, naux).  Shells up to f. */
+int dqc_int3c2e(double *d_j3c, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
+                int sh0, int sh1, int k0, int k1, void *stream);
+int dqc_int2c2e(double *d_j2c, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
+                int k0, int k1, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
