@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--molecules-per-gpu", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--df", default=None, metavar="AUXBASIS",
+                    help="density-fitted Coulomb operator (Mol.densityfit, e.g. --df etb) instead of the exact-J tile stream; "
+                         "a different formulation, labelled as such in config")
     ap.add_argument("--dense-dm", action="store_true",
                     help="feed dm2scp an anonymous full density matrix (no ao_orb2dm factor): full-matrix density kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for self-tests")
@@ -77,6 +80,8 @@ def main():
     for i in mine:
         zs, pos = M.c5_molecule(i)
         mol = dqc_amd.Mol((zs, pos), basis="cc-pvdz", grid="sg3", device=dev)
+        if args.df:
+            mol.densityfit(method="coulomb", auxbasis=args.df)
         eng = dqc_amd.KS(mol, xc="gga_x_pbe+gga_c_pbe")._engine
         n = eng.shape[-1]
         # density of the core-Hamiltonian guess ("1e", reference scf_qccalc.py:88-91) after one SCF update
@@ -105,8 +110,11 @@ def main():
                 dmdmt = (d + d.transpose(-2, -1)) * 0.5
                 dao_n = h._unconvert_dm(dmdmt).contiguous()
                 ev[0].record()
-                Jao, _ = lib.jk(h._tiles, dao_n, h._jkwork, False)   # the same calls get_elrep / get_vxc make,
-                ev[1].record()                                       # unrolled so each kernel gets its own events
+                if h.df is None:
+                    Jao, _ = lib.jk(h._tiles, dao_n, h._jkwork, False)   # the same calls get_elrep / get_vxc make,
+                else:                                                    # unrolled so each kernel gets its own events
+                    Jao = lib.df_coulomb(h.df.j3c, h.df._inv_j2c, dao_n, h.df._work)
+                ev[1].record()
                 J = h._convert2(Jao)
                 J = (J + J.transpose(-2, -1)) * 0.5
                 dao = lib.pad_matrix(dao_n, h._ld)
@@ -173,6 +181,9 @@ def main():
             "grid_vxc": 8.0 * c * ngrid * nao + 8.0 * ngrid * 5 + 8.0 * nao * nao,
             "jk_tiles": float(nao) ** 4 + 3 * 8.0 * nao * nao,
         }
+        if args.df:  # two passes over the i >= j rows of j3c (dqc_df_coulomb) + inv_j2c
+            naux = int(h0.df.j2c.shape[0])
+            alg_bytes["jk_tiles"] = 2 * 4.0 * nao * (nao + 1) * naux + 8.0 * naux * naux + 2 * 8.0 * nao * nao
         alg_flops = {
             # 2 G n^2 per GEMM pass (+ the row dots / Psi combination); J: 2 n^4 dense-equivalent
             # density: Phi . D (full matrix) or the two chained rank-n_occ GEMMs Phi . L, (Phi L) . L^T (factor form)
@@ -218,6 +229,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C5: %d x 20-atom vitamin-C-like organics (nao 208, 353400 grid pts) RKS PBE/cc-pVDZ sg3, "
                                    "%d per GPU" % (nmol, M_per),
+                       "coulomb": ("density-fitted J, auxbasis %s (naux %d)" % (args.df, int(h0.df.j2c.shape[0]))) if args.df
+                                  else "exact J from stored ERI tiles",
                        "molecules_per_gpu": M_per, "global_batch": nmol, "nao": nao, "ngrid": ngrid,
                        "parallelism": "molecule-sharded x%d, no data-path collective" % world},
             "per_gpu_value": M_per * args.steps / elapsed,

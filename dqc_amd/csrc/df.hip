@@ -104,6 +104,77 @@ static int launch_2c_ket(double *out, const DfSetup &s, hipStream_t st) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// density-fitted Coulomb matrix from the stored integrals (DFMol.get_elrep, dfmol.py:60-79):
+//     t_k = sum_ij D_ij (ij|k),   c = (k|l)^-1 t,   J_ij = sum_k (ij|k) c_k
+// Both passes stream j3c once; (ij|k) = (ji|k), so only the rows i >= j of the (nao, nao, naux) array are read
+// (half the bytes) and D enters as (D_ij + D_ji)(1 - delta_ij / 2).  HBM-bound: 2 x 4 nao (nao+1) naux bytes.
+// ---------------------------------------------------------------------------------------------
+DQC_DEV void tri_decode(long long q, int &i, int &j) {
+    long long r = (long long)((sqrt(8.0 * (double)q + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > q) r--;
+    while ((r + 1) * (r + 2) / 2 <= q) r++;
+    i = (int)r;
+    j = (int)(q - r * (r + 1) / 2);
+}
+
+constexpr int DF_ROWS = 32;  // triangular rows per block in the first pass
+
+__global__ __launch_bounds__(256) void df_rhs_kernel(double *__restrict__ t, const double *__restrict__ j3c,
+                                                     const double *__restrict__ dm, int nao, int naux, long long npair) {
+    __shared__ double sw[DF_ROWS];
+    __shared__ long long soff[DF_ROWS];
+    const long long q0 = (long long)blockIdx.x * DF_ROWS;
+    if (threadIdx.x < DF_ROWS) {
+        const long long q = q0 + threadIdx.x;
+        double wgt = 0.0;
+        long long off = 0;
+        if (q < npair) {
+            int i, j;
+            tri_decode(q, i, j);
+            wgt = (dm[(size_t)i * nao + j] + dm[(size_t)j * nao + i]) * (i == j ? 0.5 : 1.0);
+            off = ((long long)i * nao + j) * naux;
+        }
+        sw[threadIdx.x] = wgt;
+        soff[threadIdx.x] = off;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < naux; k += 256) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < DF_ROWS; r++) acc += sw[r] * j3c[soff[r] + k];
+        atomicAdd(&t[k], acc);
+    }
+}
+
+// y = A x for a small dense (n, n) matrix: one wave per row
+__global__ __launch_bounds__(256) void df_matvec_kernel(double *__restrict__ y, const double *__restrict__ a,
+                                                        const double *__restrict__ x, int n) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double acc = 0.0;
+    for (int k = lane; k < n; k += 64) acc += a[(size_t)row * n + k] * x[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) y[row] = acc;
+}
+
+__global__ __launch_bounds__(256) void df_j_kernel(double *__restrict__ jmat, const double *__restrict__ j3c,
+                                                   const double *__restrict__ c, int nao, int naux, long long npair) {
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= npair) return;
+    int i, j;
+    tri_decode(q, i, j);
+    const double *row = j3c + ((size_t)i * nao + j) * naux;
+    double acc = 0.0;
+    for (int k = lane; k < naux; k += 64) acc += row[k] * c[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) {
+        jmat[(size_t)i * nao + j] = acc;
+        jmat[(size_t)j * nao + i] = acc;
+    }
+}
+
 }  // namespace dqc
 
 extern "C" {
@@ -135,6 +206,26 @@ int dqc_int2c2e(double *d_out, const int *atm, int natm, const int *bas, int nba
         (rc = launch_2c_ket<2>(d_out, s, st)) || (rc = launch_2c_ket<3>(d_out, s, st)))
         return rc;
     DQC_HIP(hipStreamSynchronize(st));
+    return DQC_OK;
+}
+
+int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, const double *d_dm_ao, int nao, int naux,
+                   double *d_work, void *stream) {
+    // d_work: 2 * naux doubles (t, c); d_j (nao, nao) is overwritten.  Enqueues only.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (nao <= 0) return DQC_OK;
+    if (naux <= 0) { DQC_HIP(hipMemsetAsync(d_j, 0, sizeof(double) * (size_t)nao * nao, st)); return DQC_OK; }
+    const long long npair = (long long)nao * (nao + 1) / 2;
+    double *t = d_work, *c = d_work + naux;
+    DQC_HIP(hipMemsetAsync(t, 0, sizeof(double) * naux, st));
+    hipLaunchKernelGGL(df_rhs_kernel, dim3((unsigned)((npair + DF_ROWS - 1) / DF_ROWS)), dim3(256), 0, st, t, d_j3c, d_dm_ao,
+                       nao, naux, npair);
+    DQC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_matvec_kernel, dim3((unsigned)((naux + 3) / 4)), dim3(256), 0, st, c, d_inv_j2c, t, naux);
+    DQC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(df_j_kernel, dim3((unsigned)((npair + 3) / 4)), dim3(256), 0, st, d_j, d_j3c, c, nao, naux, npair);
+    DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
 

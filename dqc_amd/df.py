@@ -4,9 +4,8 @@
                   shell tables (LibcintWrapper.concatenate, lcintwrap.py:299-370); Cholesky factor of j2c
     get_elrep():  c = j2c^-1 (j3c^T vec D_ao),  J_ao = j3c c,  J = X^T J_ao X      (dfmol.py:60-79)
 
-The reference precomputes inv(j2c) and el_mat = j3c inv(j2c) (a second (nao, nao, naux) tensor); here the fit
-coefficients come from a Cholesky solve, which is the same linear system without the extra tensor or the explicit
-inverse.  The two contractions are matrix-vector products over j3c viewed as (nao^2, naux) -- plain library GEMV
+The reference precomputes inv(j2c) and el_mat = j3c inv(j2c) (a second (nao, nao, naux) tensor); here only inv(j2c)
+is kept (its "low memory" branch, dfmol.py:71-73) -- the same numbers without the extra tensor.  The two contractions are matrix-vector products over j3c viewed as (nao^2, naux) -- plain library GEMV
 (rocBLAS through torch), HBM-bound at 2 x 8 nao^2 naux bytes per Fock build (0.76 GB for a 20-atom cc-pVDZ molecule
 with ~1100 auxiliary functions, against 2.0 GB for the exact-J tile stream).  `method="overlap"` is not implemented in
 the reference either (dfmol.py:41-45).
@@ -41,7 +40,10 @@ class DFMI355:
         orb_range, aux_range = (0, nsh_orb), (nsh_orb, tab.nbas)
         self._j2c = lib.int2c2e(tab, aux_range, self.device)             # (nxao, nxao)
         self._j3c = lib.int3c2e(tab, orb_range, aux_range, self.device)  # (nao, nao, nxao)
-        self._chol = torch.linalg.cholesky(self._j2c)
+        # inverse of the SPD metric through its Cholesky factor (the reference: torch.inverse(j2c), dfmol.py:49); a
+        # plain matrix, so that the per-iteration path is two GEMVs and one small GEMV -- all hipGraph-capturable
+        self._inv_j2c = torch.cholesky_inverse(torch.linalg.cholesky(self._j2c)).contiguous()
+        self._work = torch.empty(2 * self._j2c.shape[0], dtype=torch.float64, device=self.device)
         self._is_built = True
         return self
 
@@ -49,14 +51,10 @@ class DFMI355:
         if not self._is_built:
             raise RuntimeError("Please call `build()` before `get_elrep`")
         X = self._orthozer
-        nao, _, naux = self._j3c.shape
-        j3 = self._j3c.reshape(nao * nao, naux)
 
         def one(d):
-            dao = X @ d @ X.transpose(-2, -1)
-            t = j3.transpose(0, 1) @ dao.reshape(-1, 1)              # (naux, 1)
-            c = torch.cholesky_solve(t, self._chol)                   # fit coefficients, dfmol.py:70-73
-            mat = (j3 @ c).reshape(nao, nao)                          # dfmol.py:75
+            dao = (X @ d @ X.transpose(-2, -1)).contiguous()
+            mat = lib.df_coulomb(self._j3c, self._inv_j2c, dao, self._work)   # dfmol.py:66-75, one fused pass pair
             mat = (mat + mat.transpose(-2, -1)) * 0.5
             return X.transpose(-2, -1) @ mat @ X
 
@@ -77,5 +75,5 @@ class DFMI355:
 
     def getparamnames(self, methodname: str, prefix: str = "") -> List[str]:
         if methodname == "get_elrep":
-            return [prefix + "_chol", prefix + "_j3c", prefix + "_orthozer"]
+            return [prefix + "_inv_j2c", prefix + "_j3c", prefix + "_orthozer"]
         raise KeyError("getparamnames has no %s method" % methodname)

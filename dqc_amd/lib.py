@@ -49,6 +49,7 @@ def load():
     lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
     lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
+    lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
     lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
@@ -143,6 +144,17 @@ def int2c2e(tab, aux_range, device):
     naux = _range_nao(tab, k0, k1)
     out = torch.zeros((naux, naux), dtype=torch.float64, device=device)
     _check(load().dqc_int2c2e(_ptr(out), *tab.args(), k0, k1, _stream()), "dqc_int2c2e")
+    return out
+
+
+def df_coulomb(j3c, inv_j2c, dm_ao, work=None):
+    """J_ao (nao, nao) = sum_k (ij|k) [inv_j2c (kl|D)]_k from the stored DF integrals; dm_ao (nao, nao) contiguous"""
+    nao, _, naux = j3c.shape
+    if work is None:
+        work = torch.empty(2 * naux, dtype=torch.float64, device=j3c.device)
+    out = torch.empty((nao, nao), dtype=torch.float64, device=j3c.device)
+    _check(load().dqc_df_coulomb(_ptr(out), _ptr(j3c), _ptr(inv_j2c), _ptr(dm_ao), nao, naux, _ptr(work), _stream()),
+           "dqc_df_coulomb")
     return out
 
 

@@ -123,6 +123,12 @@ int dqc_int3c2e(double *d_j3c, const int *atm, int natm, const int *bas, int nba
 int dqc_int2c2e(double *d_j2c, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
                 int k0, int k1, void *stream);
 
+/* density-fitted Coulomb matrix (DFMol.get_elrep, dfmol.py:60-79), AO basis:
+ *   t_k = sum_ij D_ij (ij|k),  c = inv_j2c t,  J_ij = sum_k (ij|k) c_k.
+ * d_j (nao, nao) is overwritten; d_work holds 2 * naux doubles.  Only enqueues on `stream`. */
+int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, const double *d_dm_ao, int nao,
+                   int naux, double *d_work, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
