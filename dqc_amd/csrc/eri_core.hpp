@@ -47,14 +47,33 @@ struct EriCfg {
 //   ERI_OUT_TILES : (ij|kl) scattered into the blocked-s8 tile storage (all 8 images)
 //   ERI_OUT_3C    : (ij|k)  with the ket pair = (auxiliary shell, unit function) -> out[(i, j), k] and [(j, i), k]
 //   ERI_OUT_2C    : (k|l)   bra and ket pairs = (auxiliary shell, unit function) -> out[k, l]
-enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2 };
+//   ERI_OUT_GRAD  : nuclear-gradient contraction (grad.hip).  The first shell of the bra pair is the "up" (l+1,
+//                   coefficients 2 alpha c) or "down" (l-1) companion of an orbital shell a, so the Cartesian block IS
+//                   the derivative d/dA of (a b|c d); it is contracted on the fly with Cartesian density matrices,
+//                   sum [jfac D_ab D_cd - k (D_ac D_bd + D_ad D_bc)], and added to the gradient of a's atom
+enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3 };
 
 struct EriOut {
     int nao;      // orbital AOs (3C: leading dimensions)
     int naux;     // auxiliary AOs (3C / 2C: fastest dimension)
     int ao0;      // AO offset of the first orbital shell
     int aux0;     // AO offset of the first auxiliary shell
+    // ---- GRAD mode
+    const double *dcart = nullptr;  // (ncart, ncart) Cartesian-basis density matrix
+    int ncart = 0;
+    const int *cao = nullptr;       // Cartesian AO offset of every ORIGINAL shell
+    const int *sh_atom = nullptr;   // atom of every original shell
+    double *gpart = nullptr;        // (nslot, natm, 3) partial gradients (spread to keep atomics apart)
+    int nslot = 1, natm = 0, norig = 0;
+    int dirn = 0;                   // +1: first bra shell is an "up" companion, -1: "down"
+    double kscale = 0.0;            // weight of the exchange-type products (1: HF, 0: pure J)
 };
+
+// index of the Cartesian component (lx, ly, lz) of shell l (inverse of cart_pow)
+DQC_DEV int cart_index(int l, int lx, int lz) {
+    const int row = l - lx;
+    return row * (row + 1) / 2 + lz;
+}
 
 template <int LA, int LB, int LC, int LD, int MODE>
 __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, DevShells sh, DevPairs prs, DevPairs prk,
@@ -207,6 +226,65 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         if (TPQ > 1) __syncthreads();
     }
 
+    if constexpr (MODE == ERI_OUT_GRAD) {
+        // ---------------- gradient contraction straight from the Cartesian accumulators ----------------
+        const int a = ish % og.norig;             // original shell behind the up / down companion
+        const int la = LA - og.dirn;
+        const int ca0 = og.cao[a], cb0 = og.cao[jsh], cc0 = og.cao[ksh], cd0 = og.cao[lsh];
+        const bool same_cd = ksh == lsh;
+        const double jfac = same_cd ? 2.0 : 4.0;
+        const double *D = og.dcart;
+        const size_t nc = og.ncart;
+        double g[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < NPT; m++) {
+            const int n = s + TPQ * m;
+            if (n < NOUT && active) {
+                const int cd = n % Cfg::NCD, cc = (n / Cfg::NCD) % Cfg::NCC, cb = (n / (Cfg::NCD * Cfg::NCC)) % Cfg::NCB,
+                          cu = n / (Cfg::NCD * Cfg::NCC * Cfg::NCB);
+                int u[3];
+                cart_pow(LA, cu, u[0], u[1], u[2]);
+                const size_t ib = cb0 + cb, ic = cc0 + cc, id = cd0 + cd;
+                const double dcd = D[ic * nc + id], dbd = D[ib * nc + id], dbc = D[ib * nc + ic];
+#pragma unroll
+                for (int dir = 0; dir < 3; dir++) {
+                    int o[3] = {u[0], u[1], u[2]};
+                    double coef;
+                    if (og.dirn > 0) {
+                        if (o[dir] == 0) continue;
+                        o[dir]--;
+                        coef = 1.0;
+                    } else {
+                        coef = -(o[dir] + 1.0);
+                        o[dir]++;
+                    }
+                    const size_t ia = ca0 + cart_index(la, o[0], o[2]);
+                    const double f = jfac * D[ia * nc + ib] * dcd -
+                                     og.kscale * (D[ia * nc + ic] * dbd + (same_cd ? 0.0 : D[ia * nc + id] * dbc));
+                    g[dir] += coef * acc[m] * f;
+                }
+            }
+        }
+        // reduce over the TPQ lanes of the quartet, one atomic per direction
+        constexpr int WRED = TPQ < 64 ? TPQ : 64;
+#pragma unroll
+        for (int dir = 0; dir < 3; dir++)
+#pragma unroll
+            for (int o = WRED / 2; o > 0; o >>= 1) g[dir] += __shfl_xor(g[dir], o);
+        double *gp = og.gpart + ((size_t)(blockIdx.x % og.nslot) * og.natm + og.sh_atom[a]) * 3;
+        if (TPQ <= 64) {
+            if (s == 0 && active)
+                for (int dir = 0; dir < 3; dir++) atomicAdd(&gp[dir], g[dir]);
+        } else {  // the whole block is one quartet: combine the four waves through LDS
+            __syncthreads();
+            if ((tid & 63) == 0)
+                for (int dir = 0; dir < 3; dir++) lds[(tid >> 6) * 3 + dir] = g[dir];
+            __syncthreads();
+            if (tid == 0 && active)
+                for (int dir = 0; dir < 3; dir++) atomicAdd(&gp[dir], lds[dir] + lds[3 + dir] + lds[6 + dir] + lds[9 + dir]);
+        }
+        return;
+    }
     // ---------------- phase C: Cartesian -> solid harmonics (LDS), scatter to tiles ----------------
     double *buf0 = reg, *buf1 = reg + NOUT;
 #pragma unroll
@@ -290,7 +368,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 struct HostPairs {
     std::vector<int> sh, pp_off;
     std::vector<double> pp;
-    int cls_start[16], cls_count[16];  // class c(la,lb) = la(la+1)/2+lb
+    int cls_start[32], cls_count[32];  // class c(la,lb) = la(la+1)/2+lb  (grad.hip: la*8+lb... see there)
 };
 
 // shell pairs (i >= j) of the shells [s0, s1); unit >= 0: instead the "pairs" (i, unit shell) used by the 2- and
@@ -326,7 +404,7 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
         if (x.cls != y.cls) return x.cls < y.cls;
         return x.npp > y.npp;
     });
-    for (int c = 0; c < 16; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
+    for (int c = 0; c < 32; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
     hp.pp_off.push_back(0);
     for (size_t n = 0; n < all.size(); n++) {
         const P &pr = all[n];

@@ -1,0 +1,115 @@
+"""Nuclear gradient dE/dR of a converged restricted SCF energy.
+
+The reference obtains it by `torch.autograd.grad(energy, atompos)` through its "ip" derivative integrals
+(dqc/hamilton/intor/molintor.py:463-500, gtoeval.py:173-193) and the implicit-function backward of the SCF fixed point
+(dqc/qccalc/scf_qccalc.py:63-67, 109-113; its tests: test_hf.py:78-111, test_ks.py:114-137).  At the fixed point the
+same derivative is the Hellmann-Feynman + Pulay expression -- no response equations:
+
+    dE/dR_A = sum D dh/dR_A - sum W dS/dR_A                 one-electron terms      -> dqc_int1e_grad
+            + sum (d_A a b|c d) [2 D_ab D_cd - k D_ac D_bd]  two-electron term       -> dqc_eri_grad (k = 1 HF, 0 KS)
+            + dE_xc/dR_A                                      LDA, INCLUDING the grid response
+            + dE_nn/dR_A
+
+The XC part differentiates the discretised functional E_xc = sum_g w_g(R) e(rho(r_g(R))) exactly, as the reference's
+autograd does: (i) Becke-weight derivative (torch autograd through dqc_amd.grid's own weight code, e_g held fixed),
+(ii) grid points riding on their parent atom: + sum_{g in A} w_g v_g grad rho(r_g), (iii) basis-function centres:
+- 2 sum_g w_g v_g sum_{mu in A} grad phi_mu (D phi)_mu.  GGA / meta-GGA gradients need AO second derivatives and are
+not built yet; neither are unrestricted or density-fitted gradients.
+"""
+import torch
+
+from . import lib
+from .grid import get_predefined_grid
+
+
+def nuclear_gradient(qc) -> torch.Tensor:
+    """qc: a converged dqc_amd.HF / dqc_amd.KS (restricted).  Returns dE/dR, shape (natm, 3), Hartree / Bohr."""
+    eng = qc._engine
+    if eng.polarized:
+        raise NotImplementedError("nuclear gradients of unrestricted calculations are not built yet")
+    h = eng.hamilton
+    if h.df is not None:
+        raise NotImplementedError("nuclear gradients with density fitting are not built yet")
+    if eng.is_ks and h.xcfamily != 1:
+        raise NotImplementedError("nuclear gradients are built for HF and LDA functionals (GGA needs AO second derivatives)")
+    mol = eng.get_system()
+    dev = h.device
+    X = h._orthozer
+    dm, fock = qc._dm, qc._fock
+    fock = (fock + fock.transpose(-2, -1)) * 0.5
+    eps, C = torch.linalg.eigh(fock)
+    n = eng.norb
+    Cocc = C[:, :n]
+    w_orth = (Cocc * (eng.orb_weight * eps[:n]).unsqueeze(0)) @ Cocc.T      # energy-weighted density
+    d_ao = X @ dm @ X.T
+    w_ao = X @ w_orth @ X.T
+    d_ao = (d_ao + d_ao.T) * 0.5
+    T = lib.cart2sph_matrix(h._tab, dev)                                        # (nao, ncart)
+    dcart = (T.T @ d_ao @ T).contiguous()
+    wcart = (T.T @ w_ao @ T).contiguous()
+    natm = len(mol.atomzs)
+    grad = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
+    lib.int1e_grad(grad, dcart, wcart, h._tab, h._zs)
+    lib.eri_grad(grad, dcart, 0.0 if eng.is_ks else 1.0, h._tab)
+    if eng.is_ks:
+        grad = grad + _xc_lda_gradient(eng, d_ao)
+    return grad + _nuclei_gradient(mol).to(dev)
+
+
+def _nuclei_gradient(mol):
+    z = mol.atomzs.to(torch.float64).cpu()
+    pos = mol.atompos.to(torch.float64).cpu()
+    d = pos.unsqueeze(1) - pos.unsqueeze(0)                 # R_A - R_B
+    r = d.norm(dim=-1) + torch.eye(len(z), dtype=torch.float64)
+    f = (z.unsqueeze(1) * z.unsqueeze(0)) / r ** 3
+    f = f - torch.diag(torch.diag(f))
+    return -(f.unsqueeze(-1) * d).sum(1)
+
+
+def _xc_lda_gradient(eng, d_ao):
+    h = eng.hamilton
+    mol = eng.get_system()
+    dev = h.device
+    nao, ld = h._nao_ao, h._ld
+    ao = h._ao if h._ao.dim() == 2 else h._ao[0]
+    # AO gradients on the grid (the Hamiltonian of an LDA run only holds the values)
+    aod = lib.eval_gto(h._tab, h.rgrid, 1)                                    # (4, ngrid, ld)
+    dpad = lib.pad_matrix(d_ao, ld)
+    rho, grho = lib.grid_density(aod, nao, dpad, True)
+    edens, vrho, _ = lib.xc_eval(h.xc.terms, rho, None, want_e=True, want_v=True)
+    wv = h.dvolume * vrho
+    natm = len(mol.atomzs)
+    # (ii) grid points ride on their parent atom
+    owner = _grid_owner(mol, h.rgrid.shape[0], dev)
+    g = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
+    g.index_add_(0, owner, (wv.unsqueeze(0) * grho).T.contiguous())
+    # (iii) basis-function centres: -2 sum_g w v sum_{mu in A} dphi_mu (D phi)_mu
+    m = (aod[0] @ dpad) * wv.unsqueeze(-1)                                    # (ngrid, ld)
+    per_ao = torch.stack([(aod[d + 1] * m).sum(0) for d in range(3)], dim=-1)[:nao]   # (nao, 3)
+    ao_atom = _ao_owner(h, dev)
+    g.index_add_(0, ao_atom, -2.0 * per_ao)
+    # (i) Becke-weight derivative, energy density held fixed
+    pos = mol.atompos.to(dtype=torch.float64, device=dev).clone().requires_grad_(True)
+    grid = get_predefined_grid(mol._grid_inp, mol.atomzs.tolist(), pos, dtype=torch.float64, device=dev)
+    loss = (grid.get_dvolume() * edens.detach()).sum()
+    g = g + torch.autograd.grad(loss, pos)[0]
+    del ao
+    return g
+
+
+def _grid_owner(mol, ngrid, dev):
+    """parent atom of every grid point: the atomic grids are concatenated atom by atom (dqc_amd.grid.get_grid)"""
+    from .grid import get_predefined_grid as gpg
+    sizes = []
+    for z in mol.atomzs.tolist():
+        one = gpg(mol._grid_inp, [z], torch.zeros((1, 3), dtype=torch.float64), dtype=torch.float64, device="cpu")
+        sizes.append(one.get_rgrid().shape[0])
+    assert sum(sizes) == ngrid
+    return torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+
+
+def _ao_owner(h, dev):
+    out = []
+    for b in h._tab.bas:
+        out.extend([int(b[0])] * (2 * int(b[1]) + 1))
+    return torch.tensor(out, device=dev)

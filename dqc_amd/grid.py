@@ -184,6 +184,12 @@ def _atom_grid(atz, nr, prec, integrator, tf, truncate, radii_list):
     return np.concatenate([p[0] for p in parts], 0), np.concatenate([p[1] for p in parts], 0)
 
 
+# Becke cell functions are dropped where mu >= 0.74 (dqc/grid/multiatoms_scheme.py: the reference's sparsification);
+# the cut makes E(R) piecewise smooth with ~1e-4-relative weight jumps, which finite-difference checks of the
+# nuclear gradient can see -- tools/gpu_grad_check.py raises it to disable the cut for such checks
+_BECKE_CUT = 0.74
+
+
 def _becke_weights(rgrids, atompos, atomradii, ratom_adjust):
     """Becke partition weights, atom by atom like the reference (bounds the temporaries to
     natoms^2 x ngrid_atom)."""
@@ -202,7 +208,7 @@ def _becke_weights(rgrids, atompos, atomradii, ratom_adjust):
         rg = torch.norm(xyz - atompos.unsqueeze(1), dim=-1)      # (natoms, ng)
         mu = (rg - rg.unsqueeze(1)) / ratoms.unsqueeze(-1)        # mu[i,j,g] = (r_j - r_i)/R_ij
         mu = mu + (-aij) * (mu * mu - 1)
-        keep = torch.all(mu < 0.74, dim=0)                        # (natoms, ng): columns that survive
+        keep = torch.all(mu < _BECKE_CUT, dim=0)                  # (natoms, ng): columns that survive
         f = mu
         for _ in range(3):
             f = -0.5 * (f * (f * f - 3))

@@ -49,6 +49,10 @@ def load():
     lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
     lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
+    lib.dqc_ncart.argtypes = [ip, c_int]
+    lib.dqc_cart2sph_matrix.argtypes = [dp, ip, c_int]
+    lib.dqc_int1e_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [dp, c_vp]
+    lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double] + tab + [c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
@@ -156,6 +160,32 @@ def df_coulomb(j3c, inv_j2c, dm_ao, work=None):
     _check(load().dqc_df_coulomb(_ptr(out), _ptr(j3c), _ptr(inv_j2c), _ptr(dm_ao), nao, naux, _ptr(work), _stream()),
            "dqc_df_coulomb")
     return out
+
+
+def cart2sph_matrix(tab, device):
+    """T (nao, ncart) block diagonal, chi_m = sum_c T[m, c] g_c (solid harmonics of the Cartesian Gaussians)"""
+    ip = ctypes.POINTER(ctypes.c_int)
+    ncart = int(load().dqc_ncart(tab.bas.ctypes.data_as(ip), tab.nbas))
+    out = np.zeros((tab.nao, ncart))
+    _check(load().dqc_cart2sph_matrix(out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), tab.bas.ctypes.data_as(ip), tab.nbas),
+           "dqc_cart2sph_matrix")
+    return torch.as_tensor(out, device=device)
+
+
+def int1e_grad(grad, dcart, wcart, tab, zs=None):
+    """grad (natm, 3) += one-electron derivative terms; dcart / wcart (ncart, ncart) contiguous device tensors"""
+    zp = None
+    if zs is not None:
+        zs = np.ascontiguousarray(zs, dtype=np.float64)
+        zp = zs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    _check(load().dqc_int1e_grad(_ptr(grad), _ptr(dcart), _ptr(wcart), *tab.args(), zp, _stream()), "dqc_int1e_grad")
+    return grad
+
+
+def eri_grad(grad, dcart, kscale, tab):
+    """grad (natm, 3) += two-electron derivative term  sum (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]"""
+    _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(kscale), *tab.args(), _stream()), "dqc_eri_grad")
+    return grad
 
 
 def eri_dense(tiles, nao):

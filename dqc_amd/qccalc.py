@@ -179,6 +179,13 @@ class SCF_QCCalc:
         assert self._has_run
         return self._dm
 
+    def nuclear_gradient(self):
+        """dE/dR (natm, 3) of the converged energy -- what the reference gets from torch.autograd.grad(energy, atompos)
+        (test_hf.py:78-111, test_ks.py:114-137); restricted HF and LDA (dqc_amd/gradient.py)"""
+        assert self._has_run
+        from .gradient import nuclear_gradient
+        return nuclear_gradient(self)
+
     def dm2energy(self, dm):
         return self._engine.dm2energy(dm)
 

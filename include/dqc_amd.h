@@ -129,6 +129,23 @@ int dqc_int2c2e(double *d_j2c, const int *atm, int natm, const int *bas, int nba
 int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, const double *d_dm_ao, int nao,
                    int naux, double *d_work, void *stream);
 
+/* ---- nuclear gradients of the SCF energy   ------------------------------------
+ * The reference differentiates through its "ip" derivative integrals (molintor.py:463-500) and the implicit-function
+ * backward of the SCF fixed point (scf_qccalc.py:63-67, 109-113); at convergence that is
+ *   dE/dR_A = sum D dh - sum W dS + (2e derivative term) + dE_xc + dE_nn,
+ * and these two entry points return the integral-derivative terms contracted with the densities (no derivative
+ * tensor is stored).  Densities are in the CARTESIAN AO basis: D_cart = T^T D_ao T with T = dqc_cart2sph_matrix
+ * (HOST array (nao, ncart), ncart = dqc_ncart).  Both ADD into d_grad (natm, 3) and synchronise the stream.
+ *   dqc_int1e_grad: 2 sum_{a in A} sum_b [D_ab (d_A a|T+V|b) - W_ab (d_A a|b)]  + Hellmann-Feynman term of every nucleus
+ *   dqc_eri_grad  : sum_{a in A} sum_bcd (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]   (kscale 1: HF, 0: pure J)
+ * Shells up to d (dqc_eri_grad) / f (dqc_int1e_grad). */
+int dqc_ncart(const int *bas, int nbas);
+int dqc_cart2sph_matrix(double *h_out, const int *bas, int nbas);
+int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart, const int *atm, int natm,
+                   const int *bas, int nbas, const double *env, int nenv, const double *zs, void *stream);
+int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int *atm, int natm, const int *bas,
+                 int nbas, const double *env, int nenv, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */

@@ -207,6 +207,11 @@ def atom_grid(atz, nr, prec, integrator, tf, truncate, radii_list):
 
 
 # ---------------- Becke ----------------
+
+# the reference drops Becke cell functions where mu >= 0.74 (multiatoms_grid.py sparsification); E(R) is then only
+# piecewise smooth, so finite-difference gradient checks raise the cut to switch the sparsification off
+BECKE_CUT = 0.74
+
 def becke_weights(rgrids, atompos, atomradii, ratom_adjust="becke"):
     """dqc/grid/multiatoms_grid.py:173-273 (same operation order, incl. the mu<0.74
     sparsification and the 1e-12 epsilon)."""
@@ -228,7 +233,7 @@ def becke_weights(rgrids, atompos, atomradii, ratom_adjust="becke"):
         mu2 *= (-aij)
         mu2 += mu
         mu = mu2
-        nnz = np.all(mu < 0.74, axis=0)  # (natoms, ng)
+        nnz = np.all(mu < BECKE_CUT, axis=0)  # (natoms, ng)
         f = mu[:, nnz]  # (natoms, nnz_col)
         for _ in range(3):
             f2 = f.copy()

@@ -439,3 +439,22 @@ def run_scf_pol(moldesc, basis, spin, xc=None, grid="sg3", **kw):
     t = obasis.make_tables(moldesc, basis)
     eng = EnginePol(t, spin, xc=xc, grid=grid)
     return eng.run(**kw), eng
+
+
+def nuclear_gradient_fd(moldesc, basis, xc=None, grid="sg3", h=1e-3, **kw):
+    """dE/dR by central finite differences of the (pinned) oracle SCF energy: by construction what the reference's
+    autograd returns (its own gradient tests are gradcheck against finite differences, test_hf.py:82-111,
+    test_ks.py:117-137).  Small molecules only: 6 natm SCF runs."""
+    zs, pos = obasis.parse_moldesc(moldesc)
+    pos = np.array(pos, dtype=np.float64)
+    kw.setdefault("tol", 1e-11)
+    g = np.zeros_like(pos)
+    for a in range(len(zs)):
+        for d in range(3):
+            e = []
+            for sgn in (+1, -1):
+                p = pos.copy()
+                p[a, d] += sgn * h
+                e.append(run_scf((list(zs), p.tolist()), basis, xc=xc, grid=grid, **kw)[0])
+            g[a, d] = (e[0] - e[1]) / (2 * h)
+    return g

@@ -176,3 +176,27 @@ def test_run_sharded_world_size_2_gloo():
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs), outs
+
+
+def test_cart2sph_matrix_host_function():
+    """dqc_cart2sph_matrix (host-side, no GPU): block-diagonal solid-harmonic matrix == the oracle's per-shell tables"""
+    import ctypes
+    from oracle import basis as ob, natives as nat
+    from dqc_amd import lib
+    from tests import molecules as M
+    t = ob.make_tables(M.CH4, "cc-pvtz")
+    tab = lib.Tables(t.atm, t.bas, t.env)
+    L = lib.load()
+    ip = ctypes.POINTER(ctypes.c_int)
+    ncart = L.dqc_ncart(tab.bas.ctypes.data_as(ip), tab.nbas)
+    assert ncart == sum((int(b[1]) + 1) * (int(b[1]) + 2) // 2 for b in tab.bas)
+    out = np.zeros((tab.nao, ncart))
+    assert L.dqc_cart2sph_matrix(out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), tab.bas.ctypes.data_as(ip), tab.nbas) == 0
+    ao = co = 0
+    for b in tab.bas:
+        l = int(b[1])
+        ns, nc = 2 * l + 1, (l + 1) * (l + 2) // 2
+        assert np.allclose(out[ao:ao + ns, co:co + nc], nat.cart2sph(l), rtol=1e-14)
+        out[ao:ao + ns, co:co + nc] = 0
+        ao, co = ao + ns, co + nc
+    assert np.abs(out).max() == 0.0
