@@ -10,12 +10,13 @@
 
 namespace dqc {
 
-constexpr int GTO_CW = 16;  // columns staged per flush
-
+// DERIV: 0 phi | 1 + gradient (4 components) | 2 + laplacian (5) | 3 + the six second derivatives xx xy xz yy yz zz (10,
+// used by the GGA nuclear gradient)
 template <int DERIV>
 __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, const double *__restrict__ coords,
                                                        int ngrid, int nao, int ld, DevShells sh) {
-    constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : 5);  // phi | + gradient | + laplacian
+    constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : (DERIV == 2 ? 5 : 10));
+    constexpr int GTO_CW = DERIV == 3 ? 8 : 16;  // columns staged per flush (the 10-component tile must fit 64 KB)
     __shared__ double tile[1][NC][64][GTO_CW + 1];
     constexpr int wave = 0;
     const int lane = threadIdx.x;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
         const double *C = C2S + C2S_OFF[l];
         for (int m = 0; m < ns; m++) {
             double v = 0, vx = 0, vy = 0, vz = 0, vl = 0;
+            double hxx = 0, hxy = 0, hxz = 0, hyy = 0, hyz = 0, hzz = 0;
             int c = 0;
             for (int lx = l; lx >= 0; lx--)
                 for (int ly = l - lx; ly >= 0; ly--, c++) {
@@ -79,6 +81,22 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
                         const double dzz = (lz >= 2 ? lz * (lz - 1) * zp[lz - 2] : 0.0) * e0 + (2 * lz + 1) * zp[lz] * e1 + zp[lz + 2] * e2;
                         vl += cf * (dxx * yp[ly] * zp[lz] + xp[lx] * dyy * zp[lz] + xp[lx] * yp[ly] * dzz);
                     }
+                    if (DERIV == 3) {
+                        const double dxx = (lx >= 2 ? lx * (lx - 1) * xp[lx - 2] : 0.0) * e0 + (2 * lx + 1) * xp[lx] * e1 + xp[lx + 2] * e2;
+                        const double dyy = (ly >= 2 ? ly * (ly - 1) * yp[ly - 2] : 0.0) * e0 + (2 * ly + 1) * yp[ly] * e1 + yp[ly + 2] * e2;
+                        const double dzz = (lz >= 2 ? lz * (lz - 1) * zp[lz - 2] : 0.0) * e0 + (2 * lz + 1) * zp[lz] * e1 + zp[lz + 2] * e2;
+                        // d2/dxdy [x^i y^j R(r^2)] = i j x^(i-1) y^(j-1) R + (i x^(i-1) y^(j+1) + j x^(i+1) y^(j-1)) R1 + x^(i+1) y^(j+1) R2
+                        const double xm = lx ? lx * xp[lx - 1] : 0.0, ym = ly ? ly * yp[ly - 1] : 0.0, zm = lz ? lz * zp[lz - 1] : 0.0;
+                        const double dxy = xm * ym * e0 + (xm * yp[ly + 1] + ym * xp[lx + 1]) * e1 + xp[lx + 1] * yp[ly + 1] * e2;
+                        const double dxz = xm * zm * e0 + (xm * zp[lz + 1] + zm * xp[lx + 1]) * e1 + xp[lx + 1] * zp[lz + 1] * e2;
+                        const double dyz = ym * zm * e0 + (ym * zp[lz + 1] + zm * yp[ly + 1]) * e1 + yp[ly + 1] * zp[lz + 1] * e2;
+                        hxx += cf * dxx * yp[ly] * zp[lz];
+                        hyy += cf * xp[lx] * dyy * zp[lz];
+                        hzz += cf * xp[lx] * yp[ly] * dzz;
+                        hxy += cf * dxy * zp[lz];
+                        hxz += cf * dxz * yp[ly];
+                        hyz += cf * dyz * xp[lx];
+                    }
                 }
             tile[wave][0][lane][nfill] = v;
             if (DERIV) {
@@ -87,6 +105,14 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
                 tile[wave][3][lane][nfill] = vz;
             }
             if (DERIV == 2) tile[wave][4][lane][nfill] = vl;
+            if (DERIV == 3) {
+                tile[wave][4][lane][nfill] = hxx;
+                tile[wave][5][lane][nfill] = hxy;
+                tile[wave][6][lane][nfill] = hxz;
+                tile[wave][7][lane][nfill] = hyy;
+                tile[wave][8][lane][nfill] = hyz;
+                tile[wave][9][lane][nfill] = hzz;
+            }
             nfill++;
             if (nfill == GTO_CW) {
                 flush(GTO_CW);
@@ -113,7 +139,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
 extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
                             int natm, const int *bas, int nbas, const double *env, int nenv, void *stream) {
     using namespace dqc;
-    if (deriv < 0 || deriv > 2) { set_error("dqc_eval_gto: deriv must be 0, 1 or 2"); return DQC_EINVAL; }
+    if (deriv < 0 || deriv > 3) { set_error("dqc_eval_gto: deriv must be 0, 1, 2 or 3"); return DQC_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
@@ -128,8 +154,10 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
             hipLaunchKernelGGL(eval_gto_kernel<0>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
         else if (deriv == 1)
             hipLaunchKernelGGL(eval_gto_kernel<1>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
-        else
+        else if (deriv == 2)
             hipLaunchKernelGGL(eval_gto_kernel<2>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+        else
+            hipLaunchKernelGGL(eval_gto_kernel<3>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
         DQC_CHECK_LAUNCH();
     }
     DQC_HIP(hipStreamSynchronize(st));  // the shell tables are freed on return

@@ -7,14 +7,14 @@ same derivative is the Hellmann-Feynman + Pulay expression -- no response equati
 
     dE/dR_A = sum D dh/dR_A - sum W dS/dR_A                 one-electron terms      -> dqc_int1e_grad
             + sum (d_A a b|c d) [2 D_ab D_cd - k D_ac D_bd]  two-electron term       -> dqc_eri_grad (k = 1 HF, 0 KS)
-            + dE_xc/dR_A                                      LDA, INCLUDING the grid response
+            + dE_xc/dR_A                                      LDA and GGA, INCLUDING the grid response
             + dE_nn/dR_A
 
 The XC part differentiates the discretised functional E_xc = sum_g w_g(R) e(rho(r_g(R))) exactly, as the reference's
 autograd does: (i) Becke-weight derivative (torch autograd through dqc_amd.grid's own weight code, e_g held fixed),
 (ii) grid points riding on their parent atom: + sum_{g in A} w_g v_g grad rho(r_g), (iii) basis-function centres:
-- 2 sum_g w_g v_g sum_{mu in A} grad phi_mu (D phi)_mu.  GGA / meta-GGA gradients need AO second derivatives and are
-not built yet; neither are unrestricted or density-fitted gradients.
+- 2 sum_g w_g v_g sum_{mu in A} grad phi_mu (D phi)_mu (LDA; the GGA forms with AO second derivatives are in
+_xc_gga_gradient).  Meta-GGA, unrestricted and density-fitted gradients are not built yet.
 """
 import torch
 
@@ -30,8 +30,8 @@ def nuclear_gradient(qc) -> torch.Tensor:
     h = eng.hamilton
     if h.df is not None:
         raise NotImplementedError("nuclear gradients with density fitting are not built yet")
-    if eng.is_ks and h.xcfamily != 1:
-        raise NotImplementedError("nuclear gradients are built for HF and LDA functionals (GGA needs AO second derivatives)")
+    if eng.is_ks and h.xcfamily not in (1, 2):
+        raise NotImplementedError("nuclear gradients are built for HF, LDA and GGA functionals (not meta-GGA)")
     mol = eng.get_system()
     dev = h.device
     X = h._orthozer
@@ -52,7 +52,7 @@ def nuclear_gradient(qc) -> torch.Tensor:
     lib.int1e_grad(grad, dcart, wcart, h._tab, h._zs)
     lib.eri_grad(grad, dcart, 0.0 if eng.is_ks else 1.0, h._tab)
     if eng.is_ks:
-        grad = grad + _xc_lda_gradient(eng, d_ao)
+        grad = grad + (_xc_lda_gradient(eng, d_ao) if h.xcfamily == 1 else _xc_gga_gradient(eng, d_ao))
     return grad + _nuclei_gradient(mol).to(dev)
 
 
@@ -95,6 +95,46 @@ def _xc_lda_gradient(eng, d_ao):
     g = g + torch.autograd.grad(loss, pos)[0]
     del ao
     return g
+
+
+_HESS = ((4, 5, 6), (5, 7, 8), (6, 8, 9))  # component of d2/(d i d j) in the deriv-3 AO array
+
+
+def _xc_gga_gradient(eng, d_ao):
+    """GGA: with b = Phi D, c_i = d_i Phi D, u = 2 v_sigma grad rho (the `vgrad` of dqc_xc_eval), S_j = sum_i u_i d_i d_j Phi
+        (ii)  grid points riding on atom A:  sum_{g in A} w [v_rho d_j rho + 2 sum_mu (b S_j + c_j (u . grad phi))]
+        (iii) centres of the AOs on A:       -2 sum_g w sum_{mu in A} [d_j phi (v_rho b + u . c) + b S_j]
+    plus (i) the Becke-weight derivative; (ii) + (iii) summed over atoms cancel identically."""
+    h = eng.hamilton
+    mol = eng.get_system()
+    dev = h.device
+    nao, ld = h._nao_ao, h._ld
+    ao = lib.eval_gto(h._tab, h.rgrid, 3)                                      # (10, ngrid, ld)
+    dpad = lib.pad_matrix(d_ao, ld)
+    rho, grho = lib.grid_density(ao[:4], nao, dpad, True)
+    edens, vrho, u = lib.xc_eval(h.xc.terms, rho, grho, want_e=True, want_v=True)
+    w = h.dvolume
+    natm = len(mol.atomzs)
+    b = ao[0] @ dpad                                                           # (ngrid, ld)
+    c = [ao[1 + i] @ dpad for i in range(3)]
+    t1 = vrho.unsqueeze(-1) * b + sum(u[i].unsqueeze(-1) * c[i] for i in range(3))
+    ugphi = sum(u[i].unsqueeze(-1) * ao[1 + i] for i in range(3))              # u . grad phi
+    owner = _grid_owner(mol, h.rgrid.shape[0], dev)
+    ao_atom = _ao_owner(h, dev)
+    g = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
+    q = torch.empty((h.rgrid.shape[0], 3), dtype=torch.float64, device=dev)
+    per_ao = torch.empty((nao, 3), dtype=torch.float64, device=dev)
+    for j in range(3):
+        s_j = sum(u[i].unsqueeze(-1) * ao[_HESS[i][j]] for i in range(3))      # (ngrid, ld)
+        bs = b * s_j
+        q[:, j] = w * (vrho * grho[j] + 2.0 * (bs.sum(1) + (c[j] * ugphi).sum(1)))
+        per_ao[:, j] = ((ao[1 + j] * t1 + bs) * w.unsqueeze(-1)).sum(0)[:nao]
+    g.index_add_(0, owner, q)
+    g.index_add_(0, ao_atom, -2.0 * per_ao)
+    pos = mol.atompos.to(dtype=torch.float64, device=dev).clone().requires_grad_(True)
+    grid = get_predefined_grid(mol._grid_inp, mol.atomzs.tolist(), pos, dtype=torch.float64, device=dev)
+    loss = (grid.get_dvolume() * edens.detach()).sum()
+    return g + torch.autograd.grad(loss, pos)[0]
 
 
 def _grid_owner(mol, ngrid, dev):

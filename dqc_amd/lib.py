@@ -209,10 +209,11 @@ def jk(tiles, dm_ao, work, with_k=True):
 
 
 def eval_gto(tab, rgrid, deriv):
-    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0], (4, ngrid, ld) [deriv 1] or (5, ngrid, ld) [deriv 2: + laplacian]"""
+    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0], (4, ngrid, ld) [deriv 1], (5, ngrid, ld) [deriv 2: + laplacian]
+    or (10, ngrid, ld) [deriv 3: + xx xy xz yy yz zz]"""
     ngrid = rgrid.shape[0]
     ld = padded_nao(tab.nao)
-    shape = (ngrid, ld) if deriv == 0 else ((4, ngrid, ld) if deriv == 1 else (5, ngrid, ld))
+    shape = (ngrid, ld) if deriv == 0 else ({1: 4, 2: 5, 3: 10}[deriv], ngrid, ld)
     out = torch.empty(shape, dtype=torch.float64, device=rgrid.device)
     _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), _stream()),
            "dqc_eval_gto")

@@ -74,6 +74,8 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
  * to_transpose=True layout of HamiltonCGTO.setup_grid (hcgto.py:168, :179).
  * deriv 0: d_out (ngrid, ld) = phi;  deriv 1: d_out (4, ngrid, ld) = phi, d/dx, d/dy, d/dz;
  * deriv 2: d_out (5, ngrid, ld) = the same plus the laplacian (GTOval_lapl_sph, hcgto.py:183-186).
+ * deriv 3: d_out (10, ngrid, ld) = phi, gradient, then d2/dxx, dxy, dxz, dyy, dyz, dzz (GTOval_sph_deriv2 order without
+ *          the duplicates; used by the GGA nuclear gradient).
  * d_coords: (ngrid, 3).  ld = dqc_padded_nao(nao); padding columns are written as zero. */
 int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
                  int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);

@@ -6,7 +6,7 @@ import dqc_amd
 from tests import molecules as M
 print = functools.partial(print, flush=True)
 dev = torch.device("cuda:0")
-for xc in ("lda_x+lda_c_pw", None):
+for xc in ("gga_x_pbe+gga_c_pbe", "lda_x+lda_c_pw", None):
     m = dqc_amd.Mol(M.c5_molecule(0), basis="cc-pvdz", grid="sg3", device=dev)
     t0 = time.perf_counter()
     qc = (dqc_amd.KS(m, xc=xc) if xc else dqc_amd.HF(m)).run()
@@ -16,4 +16,4 @@ for xc in ("lda_x+lda_c_pw", None):
     g = qc.nuclear_gradient()
     torch.cuda.synchronize(); t3 = time.perf_counter()
     print("%s: E = %.8f  niter %d  SCF incl. setup %.2f s   gradient %.3f s (warm %.3f s)   max |g| %.4f  |sum g| %.1e" %
-          ("RKS-LDA" if xc else "RHF", float(qc.energy()), qc.niter, t1 - t0, t2 - t1, t3 - t2, float(g.abs().max()), float(g.sum(0).abs().max())))
+          (("RKS " + xc) if xc else "RHF", float(qc.energy()), qc.niter, t1 - t0, t2 - t1, t3 - t2, float(g.abs().max()), float(g.sum(0).abs().max())))
