@@ -238,33 +238,35 @@ class HamiltonMI355:
         + in-place version of the result) so that the grid pass can use the rank-n_occ density kernel."""
         orb_w = orb * orb_weight.unsqueeze(-2)
         dm = torch.matmul(orb, orb_w.transpose(-2, -1))
-        self._dm_factor = None
         if orb.dim() == 2 and self._lowrank_density and lib.padded_norb(orb.shape[-1]) > 0:
-            # occupations are >= 0 in every SCF caller; a negative weight simply disables the factor path
-            self._dm_factor = (dm, dm._version, orb, orb_weight)
+            # occupations are >= 0 in every SCF caller; a negative weight simply disables the factor path.
+            # Two entries are kept: the spin-up and spin-down matrices of an unrestricted iteration.
+            self._dm_factor = ([[dm, dm._version, orb, orb_weight]] + (self._dm_factor or []))[:2]
         return dm
 
     def _weights_nonneg(self, w):
         """occupations >= 0?  Checked ONCE per weight tensor (identity + version): the check reads the device, and a
         device->host sync in every SCF iteration would drain the launch queue."""
-        c = self._w_checked
-        if c is None or c[0] is not w or c[1] != w._version:
-            self._w_checked = c = (w, w._version, not bool((w < 0).any()))
-        return c[2]
+        for c in self._w_checked or []:
+            if c[0] is w and c[1] == w._version:
+                return c[2]
+        ok = not bool((w < 0).any())
+        self._w_checked = ([(w, w._version, ok)] + (self._w_checked or []))[:2]
+        return ok
 
     def _factor_of(self, dm):
         """padded AO-basis factor pair of `dm` if it came out of ao_orb2dm unmodified, else None"""
-        c = self._dm_factor
-        if c is None or c[0] is not dm or c[1] != dm._version:
-            return None
-        if len(c) == 4:  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
-            _, _, orb, w = c
-            if not self._weights_nonneg(w):
-                self._dm_factor = None
-                return None
-            l_ao = self._orthozer @ (orb * torch.sqrt(w).unsqueeze(-2))
-            self._dm_factor = c = (dm, dm._version, lib.pad_factor(l_ao, self._ld))
-        return c[2]
+        for c in self._dm_factor or []:
+            if c[0] is dm and c[1] == dm._version:
+                if len(c) == 4:  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
+                    orb, w = c[2], c[3]
+                    if not self._weights_nonneg(w):
+                        self._dm_factor.remove(c)
+                        return None
+                    l_ao = self._orthozer @ (orb * torch.sqrt(w).unsqueeze(-2))
+                    c[2:] = [lib.pad_factor(l_ao, self._ld)]
+                return c[2]
+        return None
 
     def aodm2dens(self, dm, xyz):
         """density at arbitrary points (hcgto.py:283-299)"""
