@@ -170,6 +170,29 @@ def main():
         barrier()
         elapsed_other = time.perf_counter() - t0
     norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
+    # SURVEY.md 8(d) metric (ii): the full SCF iteration F -> eigh -> ao_orb2dm -> dm2scp (scp2scp), same K steps
+    focks = [eng.dm2scp(eng.hamilton.ao_orb2dm(orb, eng.orb_weight)) for eng, orb in zip(engines, orbs)]
+    for eng, f in zip(engines, focks):
+        eng.scp2scp(f)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for eng, f in zip(engines, focks):
+            eng.scp2scp(f)
+    barrier()
+    elapsed_full_eigh = time.perf_counter() - t0
+    # the same with the eigensolver-free step: purification + Fock build replayed as one hipGraph (dqc_amd/graph.py)
+    from dqc_amd.graph import GraphedSCFStep
+    steps_g = [GraphedSCFStep(eng) for eng in engines]
+    for st, f in zip(steps_g, focks):
+        st(f)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for st, f in zip(steps_g, focks):
+            st(f)
+    barrier()
+    elapsed_full = time.perf_counter() - t0
     names = ["jk_tiles", "orth_transforms", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
     ktime = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
 
@@ -237,6 +260,10 @@ def main():
             "density_matrix_input": "full matrix (no factor)" if dense else
                                     "ao_orb2dm(C_occ, n): rank-%d factor known to the Hamiltonian" % norb_pad,
             "value_full_matrix_dm": None if elapsed_other is None else nmol * args.steps / elapsed_other,
+            # SURVEY 8(d) metric (ii), rank 0's clock: F -> D -> F'.  "purify": GEMM-only projector + Fock build in one
+            # hipGraph; "eigh": torch.linalg.eigh (rocSOLVER) + ao_orb2dm + eager Fock build
+            "full_scf_iterations_per_s": nmol * args.steps / elapsed_full,
+            "full_scf_iterations_per_s_eigh": nmol * args.steps / elapsed_full_eigh,
             "setup_s_per_rank": setup_s,
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),

@@ -54,3 +54,52 @@ class GraphedFock:
     def density_matrix(self):
         """the D of the last replay (static buffer)"""
         return self.dm
+
+
+class GraphedSCFStep:
+    """hipGraph of one whole restricted SCF step  F_in -> D = n P(F_in) -> F_out = dm2scp(D)  with the occupied-space
+    projector from GEMM-only purification (dqc_amd/purify.py) instead of an eigendecomposition: no rocSOLVER call,
+    no host decision, one graph launch per iteration.  Needs uniform occupations (closed shell).
+
+        step = GraphedSCFStep(engine);  fock, dm, err = step(f_in)     # static buffers, valid until the next call
+    `err` (0-dim device tensor) is the idempotency + trace error of the projector; the caller checks it at the point
+    where it synchronises anyway and falls back to the eigh path when purification did not converge."""
+
+    def __init__(self, engine, warmup: int = 1):
+        if engine.polarized:
+            raise NotImplementedError("GraphedSCFStep covers the restricted engines")
+        w = engine.orb_weight
+        if not bool((w == w[0]).all()):
+            raise NotImplementedError("purification needs uniform occupations")
+        self.engine = engine
+        self.occ = float(w[0])
+        n = engine.shape[-1]
+        self.f_in = torch.zeros((n, n), dtype=engine.dtype, device=engine.device)
+        idx = torch.arange(n, device=engine.device)
+        self.f_in[idx, idx] = idx.to(engine.dtype)  # any matrix with a gap at n_occ
+        s = torch.cuda.Stream(device=engine.device)
+        s.wait_stream(torch.cuda.current_stream(engine.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(engine.device).wait_stream(s)
+        torch.cuda.synchronize(engine.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.fock, self.dm, self.err = self._body()
+        h = engine.hamilton
+        h._jk_cache = None
+        h._dm_factor = None
+
+    def _body(self):
+        from .purify import projector_from_fock
+        f = (self.f_in + self.f_in.transpose(-2, -1)) * 0.5
+        p, err = projector_from_fock(f, self.engine.norb)
+        dm = p * self.occ
+        return self.engine.dm2scp(dm), dm, err
+
+    def __call__(self, f_in):
+        if f_in is not self.f_in:
+            self.f_in.copy_(f_in)
+        self.graph.replay()
+        return self.fock, self.dm, self.err

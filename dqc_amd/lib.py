@@ -53,6 +53,7 @@ def load():
     lib.dqc_cart2sph_matrix.argtypes = [dp, ip, c_int]
     lib.dqc_int1e_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double] + tab + [c_vp]
+    lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
@@ -186,6 +187,13 @@ def eri_grad(grad, dcart, kscale, tab):
     """grad (natm, 3) += two-electron derivative term  sum (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]"""
     _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(kscale), *tab.args(), _stream()), "dqc_eri_grad")
     return grad
+
+
+def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
+    """in-place TC2 purification of the zero-padded (ld, ld) matrix x_pad (spectrum in [0, 1]); state: 2 (iters + 2)"""
+    _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
+                                 _stream()), "dqc_purify_tc2")
+    return x_pad
 
 
 def eri_dense(tiles, nao):

@@ -1,0 +1,53 @@
+"""Eigensolver-free occupied-space projector: trace-correcting purification (TC2, Niklasson 2002) by GEMMs.
+
+On MI355X the Fock build of a 20-atom molecule takes 1.9 ms while `torch.linalg.eigh` (rocSOLVER) of the 208 x 208
+Fock matrix takes 4.7 ms: diagonalisation, not the integrals, bounds the SCF iteration.  The SCF step only needs the
+density matrix D = n * P, P the projector onto the n_occ lowest eigenvectors of F (`diagonalize` + `ao_orb2dm`,
+dqc/qccalc/hf.py:105-113, 227-247; hcgto.py:272-281).  P is obtained without eigenvectors:
+
+    X0 = (e_max I - F) / (e_max - e_min)            Gershgorin bounds, spectrum mapped into [0, 1]
+    X  <- X^2            if tr X > n_occ            (lowers the trace)
+          2 X - X^2      otherwise                  (raises it)
+
+converges quadratically to P (30-40 iterations for molecular spectra); once |X^2 - X|_max < tol the iterate is frozen
+(continuing would let the trace test pick the error-doubling branch at round-off level), and two McWeeny steps
+3 X^2 - 2 X^3 -- contracting at both 0 and 1 -- polish it.  Everything is device-side (`torch.where` on device
+scalars, no host decision), so the whole map F -> D replays inside the Fock-build hipGraph.  The result equals the
+eigh-based projector to round-off (tests compare both); non-convergence (a vanishing HOMO-LUMO gap) is reported through
+the returned idempotency error and the caller falls back to eigh.
+"""
+import torch
+
+
+def projector_from_fock(fock: torch.Tensor, nocc: int, iters: int = 52, tol: float = 1e-13, fused: bool = True):
+    """fock (n, n) symmetric, orthonormal basis -> (P (n, n), idempotency error (0-dim device tensor)).
+    fused=True runs the iterations in the HIP kernel of csrc/purify.hip (one launch each); fused=False is the same
+    iteration written with torch ops (used by the CPU-side unit test and as the A/B reference)."""
+    n = fock.shape[-1]
+    eye = torch.eye(n, dtype=fock.dtype, device=fock.device)
+    diag = torch.diagonal(fock)
+    rad = fock.abs().sum(-1) - diag.abs()
+    emin, emax = (diag - rad).min(), (diag + rad).max()
+    x = (emax * eye - fock) / (emax - emin)
+    if fused and fock.is_cuda:
+        from . import lib
+        ld = (n + 15) // 16 * 16
+        xp = torch.zeros((ld, ld), dtype=fock.dtype, device=fock.device)
+        xp[:n, :n] = x
+        tmp = torch.empty_like(xp)
+        state = torch.empty(2 * (iters + 2), dtype=fock.dtype, device=fock.device)
+        lib.purify_tc2(xp, tmp, nocc, iters, tol, state)
+        x = xp[:n, :n]
+    else:
+        done = torch.zeros((), dtype=torch.bool, device=fock.device)
+        for _ in range(iters):
+            x2 = x @ x
+            done = done | ((x2 - x).abs().max() < tol)
+            cand = torch.where(torch.trace(x) > nocc, x2, 2.0 * x - x2)
+            x = torch.where(done, x, cand)
+    for _ in range(2):
+        x2 = x @ x
+        x = 3.0 * x2 - 2.0 * (x2 @ x)
+    x = (x + x.transpose(-2, -1)) * 0.5
+    err = ((x @ x) - x).abs().max() + (torch.trace(x) - nocc).abs()
+    return x, err

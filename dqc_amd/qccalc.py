@@ -13,6 +13,7 @@ unrestricted (UHF/UKS, SpinParam densities, stacked Fock matrices) are implement
 import os
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .utils.datastruct import SpinParam
@@ -126,10 +127,17 @@ class SCF_QCCalc:
         fs, es = [], []
         fock = eng.dm2scp(dm)
         # restricted engines replay the Fock build as one hipGraph (dqc_amd/graph.py); "graph": False runs it eagerly
-        graphed = None
+        # "diag": "purify" (default for closed shells) replaces eigh by GEMM-only purification inside the same graph
+        # (dqc_amd/purify.py); "eigh" keeps the reference's diagonalise-and-occupy step (hf.py:105-113)
+        graphed, purified = None, None
         if not pol and opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0"):
-            from .graph import GraphedFock
-            graphed = GraphedFock(eng)
+            from .graph import GraphedFock, GraphedSCFStep
+            w = eng.orb_weight
+            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and bool((w == w[0]).all()):
+                purified = GraphedSCFStep(eng)
+            else:
+                graphed = GraphedFock(eng)
+        perr = None
         self.converged = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
@@ -138,7 +146,16 @@ class SCF_QCCalc:
                 err = fock @ dms - dms @ fock
             else:
                 err = fock @ dm - dm @ fock  # [F, D], S = 1
-            emax = float(err.abs().max())
+            if perr is not None:  # projector of the step just taken: one host read together with the DIIS error
+                emax, pe = (float(v) for v in torch.stack([err.abs().max(), perr]).cpu())
+                if not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
+                    dm = eng.scp2dm(fprev)
+                    fock = eng.dm2scp(dm)
+                    perr = None
+                    err = fock @ dm - dm @ fock
+                    emax = float(err.abs().max())
+            else:
+                emax = float(err.abs().max())
             if emax < opts["f_tol"]:
                 self.converged = True
                 break
@@ -151,17 +168,26 @@ class SCF_QCCalc:
             if m > 1:
                 E = torch.stack(es)
                 B = torch.zeros((m + 1, m + 1), dtype=fock.dtype, device=fock.device)
-                B[:m, :m] = E @ E.T
+                # Gram matrix of the error vectors by broadcast-multiply-reduce: the (m, n^2) x (n^2, m) GEMM form of
+                # E @ E.T hits a pathological rocBLAS path for this tall-skinny fp64 shape (7 ms for 8 x 43264)
+                B[:m, :m] = (E.unsqueeze(1) * E.unsqueeze(0)).sum(-1)
                 B[m, :m] = -1
                 B[:m, m] = -1
                 rhs = torch.zeros(m + 1, dtype=fock.dtype, device=fock.device)
                 rhs[m] = -1
-                c = torch.linalg.lstsq(B.cpu(), rhs.cpu().unsqueeze(-1)).solution[:m, 0].to(fock.device)
+                # (m+1) x (m+1) Pulay system on the host with numpy: torch's CPU lstsq costs ~7 ms per call on a
+                # 256-thread box (thread-pool wake-up), several times the whole Fock build
+                c = np.linalg.lstsq(B.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0][:m]
+                c = torch.as_tensor(c, dtype=fock.dtype).to(fock.device)
                 fmix = (c.reshape((-1,) + (1,) * fock.dim()) * torch.stack(fs)).sum(0)
             else:
                 fmix = fock
-            if graphed is not None:
-                fock = graphed(eng.scp2orb(fmix)).clone()  # static buffers of the graph: copy out
+            fprev = fmix
+            if purified is not None:
+                f_out, d_out, perr = purified(fmix)
+                fock, dm, perr = f_out.clone(), d_out.clone(), perr.clone()  # static buffers of the graph: copy out
+            elif graphed is not None:
+                fock = graphed(eng.scp2orb(fmix)).clone()
                 dm = graphed.density_matrix().clone()
             else:
                 dm = eng.scp2dm(fmix)

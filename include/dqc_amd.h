@@ -148,6 +148,14 @@ int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart,
 int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int *atm, int natm, const int *bas,
                  int nbas, const double *env, int nenv, void *stream);
 
+/* ---- occupied-space projector without an eigensolver  (the `diagonalize` + `ao_orb2dm` step, hf.py:105-113, 227-247) --
+ * Trace-correcting purification X <- X^2 | 2X - X^2 (by the sign of tr X - nocc), one fused fp64-MFMA launch per
+ * iteration, frozen once max|X^2 - X| < tol; no host decision (hipGraph-capturable).  d_x (ld, ld): X0 = (emax I - F) /
+ * (emax - emin) zero padded to ld (multiple of 16) on entry, the projector on return; d_tmp (ld, ld) scratch;
+ * d_state: 2 * (iters + 2) doubles, on return trace[k] = tr X_k and (from offset iters + 2) idem[k] = max|X_k^2 - X_k|. */
+int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
+                   void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
