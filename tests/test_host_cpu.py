@@ -200,3 +200,20 @@ def test_cart2sph_matrix_host_function():
         out[ao:ao + ns, co:co + nc] = 0
         ao, co = ao + ns, co + nc
     assert np.abs(out).max() == 0.0
+
+
+def test_purification_restatement_on_cpu():
+    """dqc_amd.purify (torch form of the TC2 iteration the HIP kernel fuses): projector of a random gapped symmetric
+    matrix == eigh projector; gapless input is reported through the error"""
+    from dqc_amd.purify import projector_from_fock
+    g = torch.Generator().manual_seed(3)
+    n, nocc = 37, 9
+    q, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, generator=g))
+    ev = torch.cat([torch.linspace(-20.0, -0.4, nocc, dtype=torch.float64), torch.linspace(0.1, 3.0, n - nocc, dtype=torch.float64)])
+    f = (q * ev) @ q.T
+    p, err = projector_from_fock(f, nocc, fused=False)
+    pref = q[:, :nocc] @ q[:, :nocc].T
+    assert float(err) < 1e-12 and float((p - pref).abs().max()) < 1e-12
+    ev[nocc] = ev[nocc - 1]
+    _, err = projector_from_fock((q * ev) @ q.T, nocc, fused=False)
+    assert float(err) > 1e-6
