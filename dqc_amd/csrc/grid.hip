@@ -39,17 +39,19 @@ constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-f
 // All loads of a batch (NCT tiles x 2 components) are issued before the first FMA and there is no per-tile guard
 // (the callers make every column panel a full one), so 2 NCT loads per lane are in flight instead of 4 -- the
 // epilogue is a latency-bound HBM read otherwise.
-template <int NCT, bool GGA>
+template <int NCT, bool GGA, int Q0 = 0>
 DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1], const double *__restrict__ blk0,
                              const double *__restrict__ blkg, size_t cs, const int (&roff)[4], int col0) {
+    // Q0 = 1 skips the value component (the factor-form kernel gets rho from |A'|^2 and never re-reads Phi)
     // blk0 / blkg: uniform pointers to this block's first row of the value / gradient-carrying AO array;
     // roff[r]: block-local element offset (row * ld + lane column) of accumulator row r.
     // Software pipeline over the 4 x (1|4) (row, component) batches of NCT loads: batch b+1 is issued before batch
     // b is consumed, so NCT..2 NCT loads per lane are always in flight.
-    constexpr int NQ = GGA ? 4 : 1, NB = 4 * NQ;
+    constexpr int NQ = (GGA ? 4 : 1) - Q0, NB = 4 * NQ;
+    if (NB == 0) return;
     double t[2][NCT];
     auto issue = [&](int bt, double (&dst)[NCT]) {
-        const int r = bt / NQ, q = bt % NQ;
+        const int r = bt / NQ, q = bt % NQ + Q0;
         const double *base = (q == 0 ? blk0 : blkg + q * cs) + col0;  // uniform; tiles at immediate offsets
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) dst[ct] = base[roff[r] + ct * 16];
@@ -58,7 +60,7 @@ DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1],
 #pragma unroll
     for (int bt = 0; bt < NB; bt++) {
         if (bt + 1 < NB) issue(bt + 1, t[(bt + 1) & 1]);
-        const int r = bt / NQ, q = bt % NQ;
+        const int r = bt / NQ, q = bt % NQ + Q0;
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) p[r][q] += acc[ct][r] * t[bt & 1][ct];
         __builtin_amdgcn_sched_barrier(0);  // pin the pipeline: later batches must not be hoisted (spills)
@@ -372,6 +374,21 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
 #undef DQC_LR_MFMAS
     }
 
+    // rho_g = sum_r A'[g][r]^2 straight from the phase-1 accumulators (lane (lr = point, lk) holds r = 16 ct + 4 reg + lk):
+    // Phi is never read a second time
+    {
+        double rs = 0.0;
+#pragma unroll
+        for (int ct = 0; ct < NRT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) rs += a1[ct][q] * a1[ct][q];
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        const int row = g0 + wave * 16 + lr;
+        if (lk == 0 && row < ngrid) rho[row] = rs;
+    }
+    if (!GGA) return;
+
     double p[4][GGA ? 4 : 1];
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -438,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
             __syncthreads();
         }
         DEN_TRACE_POINT(1);
-        rowdot_epilogue<NCT, GGA>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
+        rowdot_epilogue<NCT, GGA, 1>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
         DEN_TRACE_POINT(2);
     }
 #pragma unroll
@@ -457,12 +474,9 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
         for (int r = 0; r < 4; r++) {
             const int row = g0 + wave * 16 + lk + 4 * r;
             if (row < ngrid) {
-                rho[row] = p[r][0];
-                if (GGA) {
-                    grho[row] = 2.0 * p[r][1];
-                    grho[(size_t)ngrid + row] = 2.0 * p[r][2];
-                    grho[2 * (size_t)ngrid + row] = 2.0 * p[r][3];
-                }
+                grho[row] = 2.0 * p[r][1];
+                grho[(size_t)ngrid + row] = 2.0 * p[r][2];
+                grho[2 * (size_t)ngrid + row] = 2.0 * p[r][3];
             }
         }
     }
