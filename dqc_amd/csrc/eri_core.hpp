@@ -67,6 +67,10 @@ struct EriOut {
     int nslot = 1, natm = 0, norig = 0;
     int dirn = 0;                   // +1: first bra shell is an "up" companion, -1: "down"
     double kscale = 0.0;            // weight of the exchange-type products (1: HF, 0: pure J)
+    // density-fitting gradient (gmode 1: (d_A a b|k) D_ab c_k -> +2 to a's atom, -2 to k's atom;
+    //                           gmode 2: (d_A k|l) c_k c_l    -> -1 to k's atom); ccart: fit coefficients, Cartesian
+    int gmode = 0;
+    const double *ccart = nullptr;
 };
 
 // index of the Cartesian component (lx, ly, lz) of shell l (inverse of cart_pow)
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 int u[3];
                 cart_pow(LA, cu, u[0], u[1], u[2]);
                 const size_t ib = cb0 + cb, ic = cc0 + cc, id = cd0 + cd;
-                const double dcd = D[ic * nc + id], dbd = D[ib * nc + id], dbc = D[ib * nc + ic];
+                double dcd = 0.0, dbd = 0.0, dbc = 0.0;
+                if (og.gmode == 0) { dcd = D[ic * nc + id]; dbd = D[ib * nc + id]; dbc = D[ib * nc + ic]; }
 #pragma unroll
                 for (int dir = 0; dir < 3; dir++) {
                     int o[3] = {u[0], u[1], u[2]};
@@ -259,8 +264,14 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                         o[dir]++;
                     }
                     const size_t ia = ca0 + cart_index(la, o[0], o[2]);
-                    const double f = jfac * D[ia * nc + ib] * dcd -
-                                     og.kscale * (D[ia * nc + ic] * dbd + (same_cd ? 0.0 : D[ia * nc + id] * dbc));
+                    double f;
+                    if (og.gmode == 0)
+                        f = jfac * D[ia * nc + ib] * dcd -
+                            og.kscale * (D[ia * nc + ic] * dbd + (same_cd ? 0.0 : D[ia * nc + id] * dbc));
+                    else if (og.gmode == 1)
+                        f = 2.0 * D[ia * nc + ib] * og.ccart[ic];
+                    else
+                        f = -og.ccart[ia] * og.ccart[ic];
                     g[dir] += coef * acc[m] * f;
                 }
             }
@@ -272,16 +283,24 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 #pragma unroll
             for (int o = WRED / 2; o > 0; o >>= 1) g[dir] += __shfl_xor(g[dir], o);
         double *gp = og.gpart + ((size_t)(blockIdx.x % og.nslot) * og.natm + og.sh_atom[a]) * 3;
+        double *gk = og.gpart + ((size_t)(blockIdx.x % og.nslot) * og.natm + og.sh_atom[ksh]) * 3;  // gmode 1 only
         if (TPQ <= 64) {
             if (s == 0 && active)
-                for (int dir = 0; dir < 3; dir++) atomicAdd(&gp[dir], g[dir]);
+                for (int dir = 0; dir < 3; dir++) {
+                    atomicAdd(&gp[dir], g[dir]);
+                    if (og.gmode == 1) atomicAdd(&gk[dir], -g[dir]);
+                }
         } else {  // the whole block is one quartet: combine the four waves through LDS
             __syncthreads();
             if ((tid & 63) == 0)
                 for (int dir = 0; dir < 3; dir++) lds[(tid >> 6) * 3 + dir] = g[dir];
             __syncthreads();
             if (tid == 0 && active)
-                for (int dir = 0; dir < 3; dir++) atomicAdd(&gp[dir], lds[dir] + lds[3 + dir] + lds[6 + dir] + lds[9 + dir]);
+                for (int dir = 0; dir < 3; dir++) {
+                    const double v = lds[dir] + lds[3 + dir] + lds[6 + dir] + lds[9 + dir];
+                    atomicAdd(&gp[dir], v);
+                    if (og.gmode == 1) atomicAdd(&gk[dir], -v);
+                }
         }
         return;
     }
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 struct HostPairs {
     std::vector<int> sh, pp_off;
     std::vector<double> pp;
-    int cls_start[32], cls_count[32];  // class c(la,lb) = la(la+1)/2+lb  (grad.hip: la*8+lb... see there)
+    int cls_start[48], cls_count[48];  // class c(la,lb) = la(la+1)/2+lb  (grad.hip: la*8+lb... see there)
 };
 
 // shell pairs (i >= j) of the shells [s0, s1); unit >= 0: instead the "pairs" (i, unit shell) used by the 2- and
@@ -404,7 +423,7 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
         if (x.cls != y.cls) return x.cls < y.cls;
         return x.npp > y.npp;
     });
-    for (int c = 0; c < 32; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
+    for (int c = 0; c < 48; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
     hp.pp_off.push_back(0);
     for (size_t n = 0; n < all.size(); n++) {
         const P &pr = all[n];

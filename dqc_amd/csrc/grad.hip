@@ -38,13 +38,13 @@ static void cart_offsets(const Basis &b, int nsh, std::vector<int> &cao, int &nc
 }
 
 // ordered pairs (first in [f0, f1), second in [0, nsecond)), class index = la * 8 + lb, NO swap
-static void build_pairs_ordered(const Basis &b, HostPairs &hp, int f0, int f1, int nsecond) {
+static void build_pairs_ordered(const Basis &b, HostPairs &hp, int f0, int f1, int s0, int s1) {
     struct P { int a, b, cls, npp; std::vector<double> pp; };
     std::vector<P> all;
     for (int i = f0; i < f1; i++) {
         const HostShell &A = b.shells[i];
         if (A.l < 0) continue;  // placeholder (no down companion of an s shell)
-        for (int j = 0; j < nsecond; j++) {
+        for (int j = s0; j < s1; j++) {
             const HostShell &B = b.shells[j];
             P pr;
             pr.a = i; pr.b = j; pr.cls = A.l * 8 + B.l;
@@ -67,7 +67,7 @@ static void build_pairs_ordered(const Basis &b, HostPairs &hp, int f0, int f1, i
         if (x.cls != y.cls) return x.cls < y.cls;
         return x.npp > y.npp;
     });
-    for (int c = 0; c < 32; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
+    for (int c = 0; c < 48; c++) { hp.cls_start[c] = 0; hp.cls_count[c] = 0; }
     hp.sh.clear(); hp.pp.clear(); hp.pp_off.clear();
     hp.pp_off.push_back(0);
     for (size_t n = 0; n < all.size(); n++) {
@@ -111,6 +111,34 @@ static int launch_grad_bra(const GradCtx &c, hipStream_t st) {
     if ((rc = launch_grad_class<LA, LB, LC, LD>(c, st))) return rc;
     DQC_GK(0, 0) DQC_GK(1, 0) DQC_GK(1, 1) DQC_GK(2, 0) DQC_GK(2, 1) DQC_GK(2, 2)
 #undef DQC_GK
+    return 0;
+}
+
+// density-fitting gradients: ket pairs are (auxiliary shell, unit), classes (LC, 0), LC up to f
+template <int LA, int LB>
+static int launch_grad_bra_df(const GradCtx &c, hipStream_t st) {
+    int rc;
+#define DQC_GK(LC) \
+    if ((rc = launch_grad_class<LA, LB, LC, 0>(c, st))) return rc;
+    DQC_GK(0) DQC_GK(1) DQC_GK(2) DQC_GK(3)
+#undef DQC_GK
+    return 0;
+}
+
+static int launch_grad_df3c(const GradCtx &c, hipStream_t st) {
+    int rc;
+#define DQC_GB(LA) \
+    if ((rc = launch_grad_bra_df<LA, 0>(c, st)) || (rc = launch_grad_bra_df<LA, 1>(c, st)) || (rc = launch_grad_bra_df<LA, 2>(c, st))) return rc;
+    DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3)
+#undef DQC_GB
+    return 0;
+}
+
+static int launch_grad_df2c(const GradCtx &c, hipStream_t st) {
+    int rc;
+    if ((rc = launch_grad_bra_df<0, 0>(c, st)) || (rc = launch_grad_bra_df<1, 0>(c, st)) || (rc = launch_grad_bra_df<2, 0>(c, st)) ||
+        (rc = launch_grad_bra_df<3, 0>(c, st)) || (rc = launch_grad_bra_df<4, 0>(c, st)))
+        return rc;
     return 0;
 }
 
@@ -316,8 +344,8 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int
             b.shells.push_back(h);
         }
     HostPairs hup, hdown, hket;
-    build_pairs_ordered(b, hup, N, 2 * N, N);
-    build_pairs_ordered(b, hdown, 2 * N, 3 * N, N);
+    build_pairs_ordered(b, hup, N, 2 * N, 0, N);
+    build_pairs_ordered(b, hdown, 2 * N, 3 * N, 0, N);
     build_pairs(b, hket, 0, N);
     // upload_shells needs l >= 0 everywhere: placeholders become s shells (never referenced by a pair)
     for (HostShell &h : b.shells)
@@ -397,6 +425,110 @@ int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart,
     hipLaunchKernelGGL(int1e_grad_kernel, dim3((npair + 63) / 64), dim3(64), 0, st, d_grad, ds, d_cao, d_atom, d_dcart, d_wcart,
                        ncart, natm, d_xyz, d_z);
     DQC_CHECK_LAUNCH();
+    DQC_HIP(hipStreamSynchronize(st));
+    return DQC_OK;
+}
+
+int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, const int *atm, int natm, const int *bas,
+                int nbas, const double *env, int nenv, int sh0, int sh1, int k0, int k1, void *stream) {
+    // gradient of the density-fitted Coulomb energy E_J = 1/2 t^T M^-1 t (t_k = sum D_ij (ij|k), M = (k|l), c = M^-1 t):
+    //   d_grad (natm, 3) += sum D_ij c_k d(ij|k) - 1/2 sum c_k c_l d(k|l)
+    // over the CONCATENATED tables (orbital shells [sh0, sh1), auxiliary shells [k0, k1)); d_dcart (ncart, ncart) and
+    // d_ccart (ncart): density matrix and fit coefficients in the Cartesian basis of ALL shells of the table
+    // (zero outside the orbital block / auxiliary segment).  Orbital shells up to d, auxiliary shells up to f.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    Basis b;
+    int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    if (sh0 < 0 || sh1 > nbas || sh0 > sh1 || k0 < 0 || k1 > nbas || k0 > k1) { set_error("dqc_df_grad: shell ranges outside the table"); return DQC_EINVAL; }
+    if (sh0 == sh1 || k0 == k1) return DQC_OK;
+    for (int i = 0; i < nbas; i++) {
+        const int l = b.shells[i].l;
+        if (i >= sh0 && i < sh1 && l > GRAD_LMAX) { set_error("dqc_df_grad: orbital shells above d are not supported in the gradient path"); return DQC_EINVAL; }
+        if (i >= k0 && i < k1 && l > ERI_LMAX) { set_error("dqc_df_grad: auxiliary shells above f are not supported"); return DQC_EINVAL; }
+    }
+    const int N = nbas;
+    std::vector<int> cao, sh_atom(3 * N + 1, 0);
+    int ncart;
+    cart_offsets(b, N, cao, ncart);
+    cao.resize(3 * N + 1, 0);
+    for (int i = 0; i < N; i++) sh_atom[i] = b.shells[i].atom;
+    for (int pass = 0; pass < 2; pass++)
+        for (int i = 0; i < N; i++) {
+            HostShell h = b.shells[i];
+            h.l = pass == 0 ? h.l + 1 : h.l - 1;
+            const int po = (int)b.exps.size();
+            for (int p = 0; p < h.nprim; p++) {
+                const double e = b.exps[b.shells[i].prim_off + p], c = b.coefs[b.shells[i].prim_off + p];
+                b.exps.push_back(e);
+                b.coefs.push_back(pass == 0 ? 2.0 * e * c : c);
+            }
+            h.prim_off = po;
+            b.shells.push_back(h);
+        }
+    HostShell u;
+    u.atom = 0; u.l = 0; u.nprim = 1; u.ao_off = b.nao; u.prim_off = (int)b.exps.size();
+    u.r[0] = u.r[1] = u.r[2] = 0.0;
+    b.exps.push_back(0.0);
+    b.coefs.push_back(1.0);  // GRAD mode contracts CARTESIAN blocks: the unit function is the Cartesian s function 1
+                             // (df.hip uses sqrt(4 pi) because there the l = 0 solid-harmonic factor is applied)
+    b.shells.push_back(u);
+    const int unit = 3 * N;
+    HostPairs h3up, h3down, h2up, h2down, hket;
+    build_pairs_ordered(b, h3up, N + sh0, N + sh1, sh0, sh1);
+    build_pairs_ordered(b, h3down, 2 * N + sh0, 2 * N + sh1, sh0, sh1);
+    build_pairs_ordered(b, h2up, N + k0, N + k1, unit, unit + 1);
+    build_pairs_ordered(b, h2down, 2 * N + k0, 2 * N + k1, unit, unit + 1);
+    build_pairs(b, hket, k0, k1, unit);
+    for (HostShell &h : b.shells)
+        if (h.l < 0) h.l = 0;
+    DevPool pool;
+    GradCtx c;
+    if ((rc = upload_shells(c.ds, b, pool, st))) { set_error("dqc_df_grad: device upload failed"); return rc; }
+    auto up = [&](HostPairs &hp, DevPairs &dp) {
+        int *d_sh = nullptr, *d_off = nullptr;
+        double *d_pp = nullptr;
+        int r;
+        if ((r = pool.upload(&d_sh, hp.sh, st)) || (r = pool.upload(&d_off, hp.pp_off, st)) || (r = pool.upload(&d_pp, hp.pp, st)))
+            return r;
+        dp = DevPairs{d_sh, d_off, d_pp};
+        return 0;
+    };
+    DevPairs d3up, d3down, d2up, d2down, dket;
+    int *d_cao = nullptr, *d_atom = nullptr;
+    if ((rc = up(h3up, d3up)) || (rc = up(h3down, d3down)) || (rc = up(h2up, d2up)) || (rc = up(h2down, d2down)) ||
+        (rc = up(hket, dket)) || (rc = pool.upload(&d_cao, cao, st)) || (rc = pool.upload(&d_atom, sh_atom, st))) {
+        set_error("dqc_df_grad: device upload failed");
+        return rc;
+    }
+    const int nslot = 64;
+    double *d_part = nullptr;
+    if (hipMalloc((void **)&d_part, sizeof(double) * nslot * natm * 3) != hipSuccess) { set_error("dqc_df_grad: out of memory"); return DQC_ENOMEM; }
+    pool.ptrs.push_back(d_part);
+    DQC_HIP(hipMemsetAsync(d_part, 0, sizeof(double) * nslot * natm * 3, st));
+    c.dket = dket;
+    c.hket = &hket;
+    c.og = EriOut{0, 0, 0, 0};
+    c.og.dcart = d_dcart; c.og.ccart = d_ccart; c.og.ncart = ncart; c.og.cao = d_cao; c.og.sh_atom = d_atom; c.og.gpart = d_part;
+    c.og.nslot = nslot; c.og.natm = natm; c.og.norig = N;
+    c.og.gmode = 1;
+    c.dbra = d3up; c.hbra = &h3up; c.og.dirn = +1;
+    if ((rc = launch_grad_df3c(c, st))) return rc;
+    c.dbra = d3down; c.hbra = &h3down; c.og.dirn = -1;
+    if ((rc = launch_grad_df3c(c, st))) return rc;
+    c.og.gmode = 2;
+    c.dbra = d2up; c.hbra = &h2up; c.og.dirn = +1;
+    if ((rc = launch_grad_df2c(c, st))) return rc;
+    c.dbra = d2down; c.hbra = &h2down; c.og.dirn = -1;
+    if ((rc = launch_grad_df2c(c, st))) return rc;
+    std::vector<double> part((size_t)nslot * natm * 3), g((size_t)natm * 3);
+    DQC_HIP(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+    DQC_HIP(hipMemcpyAsync(g.data(), d_grad, sizeof(double) * g.size(), hipMemcpyDeviceToHost, st));
+    DQC_HIP(hipStreamSynchronize(st));
+    for (int sidx = 0; sidx < nslot; sidx++)
+        for (size_t i = 0; i < g.size(); i++) g[i] += part[(size_t)sidx * natm * 3 + i];
+    DQC_HIP(hipMemcpyAsync(d_grad, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice, st));
     DQC_HIP(hipStreamSynchronize(st));
     return DQC_OK;
 }

@@ -38,6 +38,7 @@ class DFMI355:
         tab = lib.Tables(atm, bas, env)
         nsh_orb = sum(len(ab.bases) for ab in self._atombases)
         orb_range, aux_range = (0, nsh_orb), (nsh_orb, tab.nbas)
+        self._tab, self._orb_range, self._aux_range = tab, orb_range, aux_range  # kept for the nuclear gradient
         self._j2c = lib.int2c2e(tab, aux_range, self.device)             # (nxao, nxao)
         self._j3c = lib.int3c2e(tab, orb_range, aux_range, self.device)  # (nao, nao, nxao)
         # inverse of the SPD metric through its Cholesky factor (the reference: torch.inverse(j2c), dfmol.py:49); a

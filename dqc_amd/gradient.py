@@ -14,7 +14,8 @@ The XC part differentiates the discretised functional E_xc = sum_g w_g(R) e(rho(
 autograd does: (i) Becke-weight derivative (torch autograd through dqc_amd.grid's own weight code, e_g held fixed),
 (ii) grid points riding on their parent atom: + sum_{g in A} w_g v_g grad rho(r_g), (iii) basis-function centres:
 - 2 sum_g w_g v_g sum_{mu in A} grad phi_mu (D phi)_mu (LDA; the GGA forms with AO second derivatives are in
-_xc_gga_gradient).  Meta-GGA, unrestricted and density-fitted gradients are not built yet.
+_xc_gga_gradient).  Meta-GGA and unrestricted gradients are not built yet; with density fitting the two-electron term is
+_df_coulomb_gradient (dqc_df_grad).
 """
 import torch
 
@@ -28,8 +29,6 @@ def nuclear_gradient(qc) -> torch.Tensor:
     if eng.polarized:
         raise NotImplementedError("nuclear gradients of unrestricted calculations are not built yet")
     h = eng.hamilton
-    if h.df is not None:
-        raise NotImplementedError("nuclear gradients with density fitting are not built yet")
     if eng.is_ks and h.xcfamily not in (1, 2):
         raise NotImplementedError("nuclear gradients are built for HF, LDA and GGA functionals (not meta-GGA)")
     mol = eng.get_system()
@@ -50,10 +49,35 @@ def nuclear_gradient(qc) -> torch.Tensor:
     natm = len(mol.atomzs)
     grad = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
     lib.int1e_grad(grad, dcart, wcart, h._tab, h._zs)
-    lib.eri_grad(grad, dcart, 0.0 if eng.is_ks else 1.0, h._tab)
+    if h.df is None:
+        lib.eri_grad(grad, dcart, 0.0 if eng.is_ks else 1.0, h._tab)
+    else:
+        _df_coulomb_gradient(h, d_ao, grad)
     if eng.is_ks:
         grad = grad + (_xc_lda_gradient(eng, d_ao) if h.xcfamily == 1 else _xc_gga_gradient(eng, d_ao))
     return grad + _nuclei_gradient(mol).to(dev)
+
+
+def _df_coulomb_gradient(h, d_ao, grad):
+    """density-fitted J (DFMol.get_elrep, dfmol.py:60-79):  E_J = 1/2 t^T M^-1 t  ->  sum D c d(ij|k) - 1/2 c^T dM c"""
+    df = h.df
+    dev = h.device
+    nao, _, naux = df.j3c.shape
+    t = (df.j3c.reshape(nao * nao, naux) * d_ao.reshape(-1, 1)).sum(0)        # t_k = sum_ij D_ij (ij|k)
+    c = df._inv_j2c @ t
+    T = lib.cart2sph_matrix(df._tab, dev)                                       # all shells: orbital, then auxiliary
+    nall = T.shape[0]
+    dbig = torch.zeros((nall, nall), dtype=torch.float64, device=dev)
+    dbig[:nao, :nao] = d_ao
+    cbig = torch.zeros(nall, dtype=torch.float64, device=dev)
+    cbig[nao:] = c
+    dcart = (T.T @ dbig @ T).contiguous()
+    ccart = (T.T @ cbig).contiguous()
+    # the concatenated table lists every atom twice (orbital parent, auxiliary parent): fold the two halves
+    gbig = torch.zeros((df._tab.natm, 3), dtype=torch.float64, device=dev)
+    lib.df_grad(gbig, dcart, ccart, df._tab, df._orb_range, df._aux_range)
+    natm = grad.shape[0]
+    grad += gbig[:natm] + gbig[natm:]
 
 
 def _nuclei_gradient(mol):

@@ -53,6 +53,7 @@ def load():
     lib.dqc_cart2sph_matrix.argtypes = [dp, ip, c_int]
     lib.dqc_int1e_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double] + tab + [c_vp]
+    lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
@@ -194,6 +195,14 @@ def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
     _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
                                  _stream()), "dqc_purify_tc2")
     return x_pad
+
+
+def df_grad(grad, dcart, ccart, tab, orb_range, aux_range):
+    """grad (natm, 3) += gradient of the density-fitted Coulomb energy; dcart (ncart, ncart), ccart (ncart) over the
+    Cartesian basis of the whole concatenated table"""
+    (s0, s1), (k0, k1) = orb_range, aux_range
+    _check(load().dqc_df_grad(_ptr(grad), _ptr(dcart), _ptr(ccart), *tab.args(), s0, s1, k0, k1, _stream()), "dqc_df_grad")
+    return grad
 
 
 def eri_dense(tiles, nao):

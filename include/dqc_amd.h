@@ -147,6 +147,14 @@ int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart,
                    const int *bas, int nbas, const double *env, int nenv, const double *zs, void *stream);
 int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int *atm, int natm, const int *bas,
                  int nbas, const double *env, int nenv, void *stream);
+/* gradient of the density-fitted Coulomb energy E_J = 1/2 t^T M^-1 t (dfmol.py:60-79 differentiated):
+ *   d_grad += sum D_ij c_k d(ij|k) - 1/2 sum c_k c_l d(k|l),  c = M^-1 t,
+ * over the concatenated tables of dqc_int3c2e; d_dcart (ncart, ncart) / d_ccart (ncart): density matrix and fit
+ * coefficients in the Cartesian basis of ALL shells of the table (T^T . T with T = dqc_cart2sph_matrix of the whole table;
+ * zero outside the orbital block / the auxiliary segment).  d_grad has one row per atom OF THE TABLE (the concatenated
+ * table lists the molecule's atoms twice: the caller folds the two halves).  Orbital shells up to d, auxiliary up to f. */
+int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, const int *atm, int natm, const int *bas,
+                int nbas, const double *env, int nenv, int sh0, int sh1, int k0, int k1, void *stream);
 
 /* ---- occupied-space projector without an eigensolver  (the `diagonalize` + `ao_orb2dm` step, hf.py:105-113, 227-247) --
  * Trace-correcting purification X <- X^2 | 2X - X^2 (by the sign of tr X - nocc), one fused fp64-MFMA launch per

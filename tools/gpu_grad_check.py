@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 
 def energy(mol, basis, xc, grid):
     m = dqc_amd.Mol(mol, basis=basis, grid=grid, device=dev)
+    if DF:
+        m.densityfit(auxbasis="etb")
     qc = (dqc_amd.KS(m, xc=xc) if xc else dqc_amd.HF(m)).run(fwd_options={"f_tol": 1e-11, "maxiter": 200})
     return qc
 
@@ -22,6 +24,9 @@ cases = [("h2-321g-rhf", ([1, 1], [[0, 0, -0.7], [0, 0, 0.7]]), "3-21G", None, "
          ("h2o-ccpvdz-pbe", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2"),
          ("h2o-ccpvdz-lda", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "lda_x+lda_c_pw", "sg2")]
 h = 1e-3
+DF = "--df" in sys.argv
+if DF:
+    cases = [c for c in cases if c[3]]
 import dqc_amd.grid as _g
 for name, mol, basis, xc, grid in cases + [(c[0] + "-nocut",) + c[1:] for c in cases if c[3]]:
     _g._BECKE_CUT = 2.0 if name.endswith("-nocut") else 0.74
