@@ -66,6 +66,7 @@ struct EriOut {
     double *gpart = nullptr;        // (nslot, natm, 3) partial gradients (spread to keep atomics apart)
     int nslot = 1, natm = 0, norig = 0;
     int dirn = 0;                   // +1: first bra shell is an "up" companion, -1: "down"
+    double jscale = 1.0;            // weight of the Coulomb-type product
     double kscale = 0.0;            // weight of the exchange-type products (1: HF, 0: pure J)
     // density-fitting gradient (gmode 1: (d_A a b|k) D_ab c_k -> +2 to a's atom, -2 to k's atom;
     //                           gmode 2: (d_A k|l) c_k c_l    -> -1 to k's atom); ccart: fit coefficients, Cartesian
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         const int la = LA - og.dirn;
         const int ca0 = og.cao[a], cb0 = og.cao[jsh], cc0 = og.cao[ksh], cd0 = og.cao[lsh];
         const bool same_cd = ksh == lsh;
-        const double jfac = same_cd ? 2.0 : 4.0;
+        const double jfac = (same_cd ? 2.0 : 4.0) * og.jscale;
         const double *D = og.dcart;
         const size_t nc = og.ncart;
         double g[3] = {0.0, 0.0, 0.0};

@@ -6,7 +6,7 @@
 // Hellmann-Feynman + Pulay expression, which needs no response equations:
 //     dE/dR_A = sum D dh/dR_A - sum W dS/dR_A + 1/2 sum D D d(ab|cd)/dR_A [J - K/2 weights] + dE_xc/dR_A + dE_nn/dR_A
 // This file provides the two integral-derivative terms, contracted on the fly (no derivative tensor is stored):
-//   dqc_eri_grad   : g_A = sum_{a in A} sum_bcd (d_A a b|c d) [2 D_ab D_cd - k D_ac D_bd]
+//   dqc_eri_grad   : g_A = sum_{a in A} sum_bcd (d_A a b|c d) [2 j D_ab D_cd - k D_ac D_bd]
 //   dqc_int1e_grad : g_A = 2 sum_{a in A} sum_b [D_ab (d_A a|T + V|b) - W_ab (d_A a|b)],  g_C -= 2 sum_ab D_ab (d_A a|v_C|b)
 // d/dA of a contracted Cartesian Gaussian of angular momentum l is an (l+1)-shell with coefficients 2 alpha c minus
 // an (l-1)-shell; the 2e term therefore reuses the Rys shell-quartet kernel unchanged, with those companion shells
@@ -313,9 +313,9 @@ int dqc_cart2sph_matrix(double *h_out, const int *bas, int nbas) {
     return DQC_OK;
 }
 
-int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int *atm, int natm, const int *bas, int nbas,
+int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double kscale, const int *atm, int natm, const int *bas, int nbas,
                  const double *env, int nenv, void *stream) {
-    // d_grad (natm, 3) += sum_{a in A} sum_bcd (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]; d_dcart (ncart, ncart)
+    // d_grad (natm, 3) += sum_{a in A} sum_bcd (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]; d_dcart (ncart, ncart)
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     Basis b;
@@ -378,7 +378,7 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int
     c.hket = &hket;
     c.og = EriOut{0, 0, 0, 0};
     c.og.dcart = d_dcart; c.og.ncart = ncart; c.og.cao = d_cao; c.og.sh_atom = d_atom; c.og.gpart = d_part;
-    c.og.nslot = nslot; c.og.natm = natm; c.og.norig = N; c.og.kscale = kscale;
+    c.og.nslot = nslot; c.og.natm = natm; c.og.norig = N; c.og.jscale = jscale; c.og.kscale = kscale;
     c.dbra = dup; c.hbra = &hup; c.og.dirn = +1;
     if ((rc = launch_grad_all(c, st))) return rc;
     c.dbra = ddown; c.hbra = &hdown; c.og.dirn = -1;

@@ -52,7 +52,7 @@ def load():
     lib.dqc_ncart.argtypes = [ip, c_int]
     lib.dqc_cart2sph_matrix.argtypes = [dp, ip, c_int]
     lib.dqc_int1e_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [dp, c_vp]
-    lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double] + tab + [c_vp]
+    lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double, ctypes.c_double] + tab + [c_vp]
     lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
@@ -184,9 +184,9 @@ def int1e_grad(grad, dcart, wcart, tab, zs=None):
     return grad
 
 
-def eri_grad(grad, dcart, kscale, tab):
-    """grad (natm, 3) += two-electron derivative term  sum (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]"""
-    _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(kscale), *tab.args(), _stream()), "dqc_eri_grad")
+def eri_grad(grad, dcart, kscale, tab, jscale=1.0):
+    """grad (natm, 3) += two-electron derivative term  sum (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]"""
+    _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(jscale), float(kscale), *tab.args(), _stream()), "dqc_eri_grad")
     return grad
 
 

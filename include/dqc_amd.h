@@ -139,13 +139,14 @@ int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, co
  * tensor is stored).  Densities are in the CARTESIAN AO basis: D_cart = T^T D_ao T with T = dqc_cart2sph_matrix
  * (HOST array (nao, ncart), ncart = dqc_ncart).  Both ADD into d_grad (natm, 3) and synchronise the stream.
  *   dqc_int1e_grad: 2 sum_{a in A} sum_b [D_ab (d_A a|T+V|b) - W_ab (d_A a|b)]  + Hellmann-Feynman term of every nucleus
- *   dqc_eri_grad  : sum_{a in A} sum_bcd (d_A a b|c d) [2 D_ab D_cd - kscale D_ac D_bd]   (kscale 1: HF, 0: pure J)
+ *   dqc_eri_grad  : sum_{a in A} sum_bcd (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]
+ *                   (RHF: (1, 1); RKS: (1, 0); UHF: (1, 0) with the total density plus (0, 2) with each spin density)
  * Shells up to d (dqc_eri_grad) / f (dqc_int1e_grad). */
 int dqc_ncart(const int *bas, int nbas);
 int dqc_cart2sph_matrix(double *h_out, const int *bas, int nbas);
 int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart, const int *atm, int natm,
                    const int *bas, int nbas, const double *env, int nenv, const double *zs, void *stream);
-int dqc_eri_grad(double *d_grad, const double *d_dcart, double kscale, const int *atm, int natm, const int *bas,
+int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double kscale, const int *atm, int natm, const int *bas,
                  int nbas, const double *env, int nenv, void *stream);
 /* gradient of the density-fitted Coulomb energy E_J = 1/2 t^T M^-1 t (dfmol.py:60-79 differentiated):
  *   d_grad += sum D_ij c_k d(ij|k) - 1/2 sum c_k c_l d(k|l),  c = M^-1 t,

@@ -441,7 +441,7 @@ def run_scf_pol(moldesc, basis, spin, xc=None, grid="sg3", **kw):
     return eng.run(**kw), eng
 
 
-def nuclear_gradient_fd(moldesc, basis, xc=None, grid="sg3", h=1e-3, **kw):
+def nuclear_gradient_fd(moldesc, basis, xc=None, grid="sg3", h=1e-3, spin=None, **kw):
     """dE/dR by central finite differences of the (pinned) oracle SCF energy: by construction what the reference's
     autograd returns (its own gradient tests are gradcheck against finite differences, test_hf.py:82-111,
     test_ks.py:117-137).  Small molecules only: 6 natm SCF runs."""
@@ -455,6 +455,9 @@ def nuclear_gradient_fd(moldesc, basis, xc=None, grid="sg3", h=1e-3, **kw):
             for sgn in (+1, -1):
                 p = pos.copy()
                 p[a, d] += sgn * h
-                e.append(run_scf((list(zs), p.tolist()), basis, xc=xc, grid=grid, **kw)[0])
+                if spin is None:
+                    e.append(run_scf((list(zs), p.tolist()), basis, xc=xc, grid=grid, **kw)[0])
+                else:  # unrestricted engines (hf.py:93-103, ks.py polarised branches)
+                    e.append(run_scf_pol((list(zs), p.tolist()), basis, spin, xc=xc, grid=grid, **kw)[0])
             g[a, d] = (e[0] - e[1]) / (2 * h)
     return g

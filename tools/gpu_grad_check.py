@@ -9,7 +9,10 @@ dev = torch.device("cuda:0")
 
 
 def energy(mol, basis, xc, grid):
-    m = dqc_amd.Mol(mol, basis=basis, grid=grid, device=dev)
+    spin = None
+    if isinstance(basis, tuple):
+        basis, spin = basis
+    m = dqc_amd.Mol(mol, basis=basis, grid=grid, device=dev, spin=spin)
     if DF:
         m.densityfit(auxbasis="etb")
     qc = (dqc_amd.KS(m, xc=xc) if xc else dqc_amd.HF(m)).run(fwd_options={"f_tol": 1e-11, "maxiter": 200})
@@ -23,6 +26,12 @@ cases = [("h2-321g-rhf", ([1, 1], [[0, 0, -0.7], [0, 0, 0.7]]), "3-21G", None, "
          ("lih-321g-pbe", ([3, 1], [[0, 0.1, -1.5], [0, 0, 1.5]]), "3-21G", "gga_x_pbe+gga_c_pbe", 4),
          ("h2o-ccpvdz-pbe", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2"),
          ("h2o-ccpvdz-lda", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "lda_x+lda_c_pw", "sg2")]
+if "--pol" in sys.argv:  # unrestricted: (basis, spin)
+    CH3 = ([6, 1, 1, 1], [[0, 0, 0.05], [2.039, 0, 0], [-1.0195, 1.7658, 0], [-1.0195, -1.7658, 0.1]])
+    cases = [("ch3-321g-uhf", CH3, ("3-21G", 1), None, 4),
+             ("ch3-321g-ulda", CH3, ("3-21G", 1), "lda_x+lda_c_pw", 4),
+             ("ch3-ccpvdz-upbe", CH3, ("cc-pvdz", 1), "gga_x_pbe+gga_c_pbe", "sg2"),
+             ("o2-321g-upbe", ([8, 8], [[0, 0, -1.14], [0.05, 0, 1.14]]), ("3-21G", 2), "gga_x_pbe+gga_c_pbe", 4)]
 h = 1e-3
 DF = "--df" in sys.argv
 if DF:
