@@ -60,9 +60,41 @@ class LibXC(BaseXC):
         assert rho.dim() == 1, "batched densities are looped by the caller"
         return rho.contiguous(), (None if (grad is None or self.family == 1) else grad.contiguous())
 
+    def _pol_mgga(self, densinfo, want_e, want_v):
+        """spin-polarised meta-GGA (libxc_wrapper.py polarised family-4 branch).  Exchange functionals obey the spin-scaling
+        relation E_x[rho_u, rho_d] = 1/2 E_x[2 rho_u] + 1/2 E_x[2 rho_d], so mgga_x_* terms run through the unpolarised
+        kernel on (2 rho_s, 2 grad rho_s, 2 tau_s); d e / d rho_s, d e / d grad rho_s, d e / d tau_s are then exactly the
+        kernel's outputs at the scaled arguments.  LDA / GGA terms go through the polarised kernel.  Returns
+        (edens, [ValGrad_u, ValGrad_d])"""
+        mx = [(c, n) for c, n in self.terms if n.startswith("mgga_x_")]
+        rest = [(c, n) for c, n in self.terms if _FAMILY[n] != 4]
+        if len(mx) + len(rest) != len(self.terms):
+            raise NotImplementedError("spin-polarised meta-GGA correlation functionals are not implemented")
+        e, pots = 0.0, []
+        for d in (densinfo.u, densinfo.d):
+            es, v, vg, vt = lib.xc_eval_mgga(mx, (2.0 * d.value).contiguous(), (2.0 * d.grad).contiguous(),
+                                             (2.0 * d.kin).contiguous(), want_e=want_e, want_v=want_v)
+            if want_e:
+                e = e + 0.5 * es
+            pots.append(ValGrad(value=v, grad=vg, lapl=None, kin=vt) if want_v else None)
+        if rest:
+            gga = max(_FAMILY[n] for _, n in rest) == 2
+            gu = densinfo.u.grad.contiguous() if gga else None
+            gd = densinfo.d.grad.contiguous() if gga else None
+            er, (vu, vd), (ggu, ggd) = lib.xc_eval_pol(rest, densinfo.u.value.contiguous(), densinfo.d.value.contiguous(),
+                                                       gu, gd, want_e=want_e, want_v=want_v)
+            if want_e:
+                e = e + er
+            if want_v:
+                for p_, v_, g_ in zip(pots, (vu, vd), (ggu, ggd)):
+                    p_.value = p_.value + v_
+                    if g_ is not None:
+                        p_.grad = p_.grad + g_
+        return e, pots
+
     def get_edensityxc(self, densinfo):
         if isinstance(densinfo, SpinParam) and self.family == 4:
-            raise NotImplementedError("spin-polarised meta-GGA is not implemented")
+            return self._pol_mgga(densinfo, True, False)[0]
         if isinstance(densinfo, SpinParam):  # polarised (libxc.py:66-85 polarised branch)
             (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
             if not self.terms:
@@ -79,7 +111,8 @@ class LibXC(BaseXC):
 
     def get_vxc(self, densinfo):
         if isinstance(densinfo, SpinParam) and self.family == 4:
-            raise NotImplementedError("spin-polarised meta-GGA is not implemented")
+            pu, pd = self._pol_mgga(densinfo, False, True)[1]
+            return SpinParam(u=pu, d=pd)
         if isinstance(densinfo, SpinParam):  # polarised (libxc.py:40-63 polarised branch)
             (ru, gu), (rd, gd) = self._flat(densinfo.u), self._flat(densinfo.d)
             if not self.terms:
