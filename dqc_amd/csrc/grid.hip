@@ -838,6 +838,149 @@ __global__ __launch_bounds__(VWS_NT, 3) void vxc_ws_kernel(double *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Vxc for larger bases: the wave-specialised kernel with RECTANGULAR output ownership.  vxc_ws_kernel splits the
+// T x T output tiles linearly over `nsplit` blocks that each stage ALL columns of a slab; beyond two blocks per
+// slab that re-reads the slab nsplit times (nsplit = 18 at nao = 624).  Here block (slab, i, j) owns the tile
+// rectangle  rows [i T / NR, (i+1) T / NR)  x  cols [j T / NC, (j+1) T / NC)  (<= 8 x 11 tiles) and its producers
+// stage only the Phi columns of those rows (A operand) and the four AO components of those columns (-> Psi, B
+// operand): per-block loads are what vxc_ws_kernel loads at nao = 208, and a slab is re-read NC + 4 NR times in
+// total instead of 5 nsplit.  Chunks are always 16 points (39 KB per LDS buffer).
+// ---------------------------------------------------------------------------------------------
+template <int MAXT, int NLA, int NLB, bool GGA>
+__global__ __launch_bounds__(VWS_NT, 3) void vxc_ws2_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
+                                                           int ngrid, int ld, const double *__restrict__ w,
+                                                           const double *__restrict__ vrho,
+                                                           const double *__restrict__ vgrad, int slab, int NR, int NC,
+                                                           int LSA, int LSB, const double *__restrict__ aob) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int KCH = 16;
+    const int BUF = KCH * (LSA + LSB);  // phi part (stride LSA) followed by psi part (stride LSB)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t cs = (size_t)ngrid * ld;
+    const int T = ld >> 4, nsplit = NR * NC;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * nsplit), rem = id - grp * 8 * nsplit;
+    const int split = rem / 8, sl = grp * 8 + (rem & 7);
+    const int gs = sl * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int nchunk = (ge - gs + KCH - 1) / KCH;
+    const int bi = split / NC, bj = split % NC;
+    const int r0 = bi * T / NR, nr = (bi + 1) * T / NR - r0;   // tile rows of this block
+    const int c0 = bj * T / NC, nc = (bj + 1) * T / NC - c0;   // tile columns
+
+    if (wave >= VXC_WAVES) {
+        // ------------------------------------------------------------------ producers
+        constexpr int TPR = VWS_PROD / KCH;  // 16 threads per chunk row
+        const int pt = tid - 512;
+        const int prow = pt / TPR, pcol = pt % TPR;
+        const int wa = nr * 16, wb = nc * 16;  // staged widths (doubles)
+        double2 ra[NLA], rb[NLB][GGA ? 4 : 1];
+        double cf[GGA ? 4 : 1], wg = 0.0;
+        bool rowok = false;
+        auto prefetch = [&](int c) {
+            const int g = gs + c * KCH + prow;
+            rowok = g < ge;
+            const int gg = rowok ? g : gs;
+            wg = w[gg];
+            cf[0] = vrho[gg];
+            if (GGA) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) cf[d + 1] = vgrad[(size_t)d * ngrid + gg];
+            }
+            const double *srca = ao + (size_t)gg * ld + r0 * 16;
+            const double *srcb = (GGA ? ao : aob) + (size_t)gg * ld + c0 * 16;
+#pragma unroll
+            for (int i = 0; i < NLA; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                ra[i] = *reinterpret_cast<const double2 *>(srca + (c2 < wa ? c2 : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                const int cc = c2 < wb ? c2 : 0;
+#pragma unroll
+                for (int d = 0; d < (GGA ? 4 : 1); d++) rb[i][d] = *reinterpret_cast<const double2 *>(srcb + d * cs + cc);
+            }
+        };
+        auto stage = [&](int buf) {
+            const double ww = rowok ? wg : 0.0;
+            cf[0] *= ww;
+            if (GGA) {
+#pragma unroll
+                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * ww;
+            }
+            double *pa = lds + buf * BUF + prow * LSA, *pb = lds + buf * BUF + KCH * LSA + prow * LSB;
+#pragma unroll
+            for (int i = 0; i < NLA; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                if (c2 < wa) *reinterpret_cast<double2 *>(pa + c2) = rowok ? ra[i] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int i = 0; i < NLB; i++) {
+                const int c2 = (pcol + i * TPR) * 2;
+                if (c2 < wb) {
+                    double2 ps = make_double2(cf[0] * rb[i][0].x, cf[0] * rb[i][0].y);
+                    if (GGA) {
+#pragma unroll
+                        for (int d = 1; d < 4; d++) { ps.x += cf[d] * rb[i][d].x; ps.y += cf[d] * rb[i][d].y; }
+                    }
+                    *reinterpret_cast<double2 *>(pb + c2) = ps;
+                }
+            }
+        };
+        prefetch(0);
+        stage(0);
+        if (nchunk > 1) prefetch(1);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c++) {
+            if (c + 1 < nchunk) stage((c + 1) & 1);
+            if (c + 2 < nchunk) prefetch(c + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int lr = lane & 15, lk = lane >> 4;
+    const int ttot = nr * nc;
+    const int per_wave = (ttot + VXC_WAVES - 1) / VXC_WAVES;
+    const int t0 = wave * per_wave;
+    const int nt = max(0, min(per_wave, ttot - t0));
+    v4d acc[MAXT];
+    unsigned offab[MAXT];  // LDS offsets of the A (low 16 bits) and B (high 16 bits) fragments
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        const int tl = min(t0 + t, ttot - 1);
+        offab[t] = (unsigned)(lk * LSA + (tl / nc) * 16 + lr) | ((unsigned)(KCH * LSA + lk * LSB + (tl % nc) * 16 + lr) << 16);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        const double *base = lds + (c & 1) * BUF;
+#pragma unroll
+        for (int kk = 0; kk < KCH / 4; kk++) {
+            const int koa = kk * 4 * LSA, kob = kk * 4 * LSB;
+#pragma unroll
+            for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
+                const double a = base[koa + (offab[t] & 0xffffu)];
+                const double b = base[kob + (offab[t] >> 16)];
+                acc[t] = mfma_f64(a, b, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (t < nt) {
+            const int tl = t0 + t;
+            const int ia = (r0 + tl / nc) * 16 + lk, ib = (c0 + tl % nc) * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Vxc, LDS-DMA variant: the four AO components of the next 8-point chunk are copied HBM -> LDS by
 // global_load_lds_dwordx4 (no staging VGPRs), so one block keeps ALL n x n output tiles in registers
 // (up to 22 per wave) and the slab is read from HBM exactly once.  Per chunk:
@@ -1043,6 +1186,30 @@ static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hi
     return DQC_EINVAL;
 }
 
+template <int MAXT, int NLA, int NLB, bool GGA>
+static void launch_vxc_ws2_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
+                                const double *w, const double *vrho, const double *vgrad, int slab, int NR, int NC, int LSA,
+                                int LSB, const double *aob) {
+    auto kern = vxc_ws2_kernel<MAXT, NLA, NLB, GGA>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob);
+}
+
+template <bool GGA>
+static int launch_vxc_ws2(int maxt, int nla, int nlb, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
+                          int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int NR,
+                          int NC, int LSA, int LSB, const double *aob) {
+#define DQC_VW2_CASE(N, A, B)                                                                                        \
+    if (maxt == N && nla == A && nlb == B) {                                                                          \
+        launch_vxc_ws2_inst<N, A, B, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob); \
+        return 0;                                                                                                     \
+    }
+    DQC_VW2_CASE(8, 4, 4) DQC_VW2_CASE(8, 4, 6) DQC_VW2_CASE(11, 4, 4) DQC_VW2_CASE(11, 4, 6)
+#undef DQC_VW2_CASE
+    set_error("vxc_ws2: internal dispatch error");
+    return DQC_EINVAL;
+}
+
 template <bool GGA>
 static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                       int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
@@ -1159,6 +1326,30 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             nslab = (ngrid + slab - 1) / slab;
             int rc = gga ? launch_vxc_glds<true>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
                          : launch_vxc_glds<false>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
+            if (rc) return rc;
+            DQC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            DQC_CHECK_LAUNCH();
+            return DQC_OK;
+        }
+        if (ttot > 2 * 11 * VXC_WAVES && !(impl_env && impl_env[0] == 'r')) {
+            // larger bases: rectangular ownership (vxc_ws2_kernel), rectangles of at most 8 x 11 tiles
+            const int NR = (T + 7) / 8, NC = (T + 10) / 11;
+            const int nrmax = (T + NR - 1) / NR, ncmax = (T + NC - 1) / NC;
+            const int need2 = (nrmax * ncmax + VXC_WAVES - 1) / VXC_WAVES;
+            const int maxt2 = need2 <= 8 ? 8 : 11;
+            auto pad16 = [](int w_) { return (w_ & 31) == 16 ? w_ : w_ + 16; };  // == 16 (mod 32): conflict-free fragments
+            const int LSA = pad16(nrmax * 16), LSB = pad16(ncmax * 16);
+            const int nla = 4, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;
+            const int nsplit2 = NR * NC;
+            int nslab = std::max(8, (512 / nsplit2) / 8 * 8);
+            int slab = (ngrid + nslab - 1) / nslab;
+            slab = (slab + 15) / 16 * 16;
+            nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
+            const size_t shmem2 = sizeof(double) * 2 * 16 * (size_t)(LSA + LSB);
+            dim3 grid2(nslab * nsplit2);
+            int rc = gga ? launch_vxc_ws2<true>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob)
+                         : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
             hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
