@@ -41,6 +41,9 @@ struct EriCfg {
     static constexpr int REG0 = GSZ > NOUT + BUF1 ? GSZ : NOUT + BUF1;
     static constexpr int REGION = REG0 | 1;  // odd stride: conflict-free when every lane owns a region
     static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)REGION * QPB;
+    // GRAD mode contracts straight from the accumulators: only the 2D-integral staging area is needed
+    static constexpr int REGION_G = GSZ | 1;
+    static constexpr size_t LDS_BYTES_G = sizeof(double) * (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
 };
 
 // output modes of the kernel
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 
     const int tid = threadIdx.x;
     const int q = tid / TPQ, s = tid % TPQ;  // quartet slot in the block, lane inside the quartet group
-    double *reg = lds + (size_t)q * Cfg::REGION;
+    constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : Cfg::REGION;
+    double *reg = lds + (size_t)q * REGION;
 
     long long task = (long long)blockIdx.x * QPB + q;
     const bool active = task < ntask;

@@ -12,7 +12,7 @@
 // an (l-1)-shell; the 2e term therefore reuses the Rys shell-quartet kernel unchanged, with those companion shells
 // first in the bra pair, in its GRAD output mode (eri_core.hpp).  Densities enter in the Cartesian AO basis
 // (D_cart = T^T D T, T = dqc_cart2sph_matrix), so no solid-harmonic transform is needed on the device.
-// Supported: shells up to d (companions up to f).
+// Supported: shells up to f (companions up to g).
 #include "eri_core.hpp"
 
 namespace dqc {
@@ -26,7 +26,7 @@ namespace hostc2s {
 #undef C2S_QUAL
 }  // namespace hostc2s
 
-constexpr int GRAD_LMAX = 2;  // orbital shells up to d in the gradient path
+constexpr int GRAD_LMAX = 3;  // orbital shells up to f in the gradient path (companions up to g)
 
 static void cart_offsets(const Basis &b, int nsh, std::vector<int> &cao, int &ncart) {
     cao.resize(nsh);
@@ -97,8 +97,8 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     const long long ntask = (long long)nb * nk;
     const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, (double *)nullptr, c.ds, c.dbra, c.dket,
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_G);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_G, st, (double *)nullptr, c.ds, c.dbra, c.dket,
                        c.hbra->cls_start[cb], nb, c.hket->cls_start[ck], nk, 0, ntask, c.og);
     DQC_CHECK_LAUNCH();
     return 0;
@@ -109,7 +109,7 @@ static int launch_grad_bra(const GradCtx &c, hipStream_t st) {
     int rc;
 #define DQC_GK(LC, LD) \
     if ((rc = launch_grad_class<LA, LB, LC, LD>(c, st))) return rc;
-    DQC_GK(0, 0) DQC_GK(1, 0) DQC_GK(1, 1) DQC_GK(2, 0) DQC_GK(2, 1) DQC_GK(2, 2)
+    DQC_GK(0, 0) DQC_GK(1, 0) DQC_GK(1, 1) DQC_GK(2, 0) DQC_GK(2, 1) DQC_GK(2, 2) DQC_GK(3, 0) DQC_GK(3, 1) DQC_GK(3, 2) DQC_GK(3, 3)
 #undef DQC_GK
     return 0;
 }
@@ -128,8 +128,8 @@ static int launch_grad_bra_df(const GradCtx &c, hipStream_t st) {
 static int launch_grad_df3c(const GradCtx &c, hipStream_t st) {
     int rc;
 #define DQC_GB(LA) \
-    if ((rc = launch_grad_bra_df<LA, 0>(c, st)) || (rc = launch_grad_bra_df<LA, 1>(c, st)) || (rc = launch_grad_bra_df<LA, 2>(c, st))) return rc;
-    DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3)
+    if ((rc = launch_grad_bra_df<LA, 0>(c, st)) || (rc = launch_grad_bra_df<LA, 1>(c, st)) || (rc = launch_grad_bra_df<LA, 2>(c, st)) || (rc = launch_grad_bra_df<LA, 3>(c, st))) return rc;
+    DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3) DQC_GB(4)
 #undef DQC_GB
     return 0;
 }
@@ -145,8 +145,8 @@ static int launch_grad_df2c(const GradCtx &c, hipStream_t st) {
 static int launch_grad_all(const GradCtx &c, hipStream_t st) {
     int rc;
 #define DQC_GB(LA) \
-    if ((rc = launch_grad_bra<LA, 0>(c, st)) || (rc = launch_grad_bra<LA, 1>(c, st)) || (rc = launch_grad_bra<LA, 2>(c, st))) return rc;
-    DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3)
+    if ((rc = launch_grad_bra<LA, 0>(c, st)) || (rc = launch_grad_bra<LA, 1>(c, st)) || (rc = launch_grad_bra<LA, 2>(c, st)) || (rc = launch_grad_bra<LA, 3>(c, st))) return rc;
+    DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3) DQC_GB(4)
 #undef DQC_GB
     return 0;
 }
@@ -323,7 +323,7 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     if (rc) return rc;
     if (nbas == 0) return DQC_OK;
     for (const HostShell &s : b.shells)
-        if (s.l > GRAD_LMAX) { set_error("dqc_eri_grad: shells above d are not supported in the gradient path"); return DQC_EINVAL; }
+        if (s.l > GRAD_LMAX) { set_error("dqc_eri_grad: shells above f are not supported in the gradient path"); return DQC_EINVAL; }
     const int N = nbas;
     std::vector<int> cao, sh_atom(N);
     int ncart;
@@ -445,7 +445,7 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
     if (sh0 == sh1 || k0 == k1) return DQC_OK;
     for (int i = 0; i < nbas; i++) {
         const int l = b.shells[i].l;
-        if (i >= sh0 && i < sh1 && l > GRAD_LMAX) { set_error("dqc_df_grad: orbital shells above d are not supported in the gradient path"); return DQC_EINVAL; }
+        if (i >= sh0 && i < sh1 && l > GRAD_LMAX) { set_error("dqc_df_grad: orbital shells above f are not supported in the gradient path"); return DQC_EINVAL; }
         if (i >= k0 && i < k1 && l > ERI_LMAX) { set_error("dqc_df_grad: auxiliary shells above f are not supported"); return DQC_EINVAL; }
     }
     const int N = nbas;

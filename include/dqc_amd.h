@@ -141,7 +141,7 @@ int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, co
  *   dqc_int1e_grad: 2 sum_{a in A} sum_b [D_ab (d_A a|T+V|b) - W_ab (d_A a|b)]  + Hellmann-Feynman term of every nucleus
  *   dqc_eri_grad  : sum_{a in A} sum_bcd (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]
  *                   (RHF: (1, 1); RKS: (1, 0); UHF: (1, 0) with the total density plus (0, 2) with each spin density)
- * Shells up to d (dqc_eri_grad) / f (dqc_int1e_grad). */
+ * Shells up to f. */
 int dqc_ncart(const int *bas, int nbas);
 int dqc_cart2sph_matrix(double *h_out, const int *bas, int nbas);
 int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart, const int *atm, int natm,
@@ -153,7 +153,7 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
  * over the concatenated tables of dqc_int3c2e; d_dcart (ncart, ncart) / d_ccart (ncart): density matrix and fit
  * coefficients in the Cartesian basis of ALL shells of the table (T^T . T with T = dqc_cart2sph_matrix of the whole table;
  * zero outside the orbital block / the auxiliary segment).  d_grad has one row per atom OF THE TABLE (the concatenated
- * table lists the molecule's atoms twice: the caller folds the two halves).  Orbital shells up to d, auxiliary up to f. */
+ * table lists the molecule's atoms twice: the caller folds the two halves).  Shells up to f. */
 int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, const int *atm, int natm, const int *bas,
                 int nbas, const double *env, int nenv, int sh0, int sh1, int k0, int k1, void *stream);
 
