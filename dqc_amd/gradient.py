@@ -16,7 +16,7 @@ differentiates the discretised functional E_xc = sum_g w_g(R) e(rho_s(r_g(R))) e
 with b = Phi D_s, c_i = d_i Phi D_s, u = the gradient part of the potential (`vgrad` of dqc_xc_eval*), S_j = sum_i u_i d_i d_j Phi:
 (ii)  grid points riding on atom A:  sum_{g in A} w [v_rho d_j rho + 2 sum_mu (b S_j + c_j (u . grad phi))]
 (iii) centres of the AOs on A:       -2 sum_g w sum_{mu in A} [d_j phi (v_rho b + u . c) + b S_j]
-((ii) + (iii) summed over atoms cancel identically; LDA: u = 0).  Meta-GGA gradients are not built yet; with density
+((ii) + (iii) summed over atoms cancel identically; LDA: u = 0; meta-GGA: the tau terms of _xc_gradient).  With density
 fitting the two-electron term is _df_coulomb_gradient (dqc_df_grad).
 """
 import torch
@@ -32,8 +32,6 @@ def nuclear_gradient(qc) -> torch.Tensor:
     """qc: a converged dqc_amd.HF / dqc_amd.KS.  Returns dE/dR, shape (natm, 3), Hartree / Bohr."""
     eng = qc._engine
     h = eng.hamilton
-    if eng.is_ks and h.xcfamily not in (1, 2):
-        raise NotImplementedError("nuclear gradients are built for HF, LDA and GGA functionals (not meta-GGA)")
     mol = eng.get_system()
     dev = h.device
     X = h._orthozer
@@ -103,46 +101,56 @@ def _nuclei_gradient(mol):
 
 
 def _xc_gradient(eng, d_aos):
-    """d_aos: [D] (restricted) or [D_u, D_d]; LDA (deriv-1 AOs) or GGA (deriv-3 AOs)"""
+    """d_aos: [D] (restricted) or [D_u, D_d]; LDA (deriv-1 AOs), GGA / meta-GGA (deriv-3 AOs).  The potentials come from
+    the functional object itself (BaseXC.get_vxc on ValGrad / SpinParam densities), so every functional the Hamiltonian
+    can run has a gradient.  Meta-GGA adds, with tau = 1/2 sum_d d_d Phi D d_d Phi and c_d = d_d Phi D:
+        (ii)  + w v_tau sum_mu sum_d (d_d d_j phi_mu) c_{mu,d}        (iii)  - the same restricted to mu on A
+    (v_lapl = 0 for every functional of the kernel set)."""
+    from .utils.datastruct import ValGrad
     h = eng.hamilton
     mol = eng.get_system()
     dev = h.device
     nao, ld = h._nao_ao, h._ld
-    gga = h.xcfamily == 2
+    fam = h.xcfamily
+    gga = fam >= 2
     ao = lib.eval_gto(h._tab, h.rgrid, 3 if gga else 1)                        # (10 | 4, ngrid, ld)
     dpads = [lib.pad_matrix(d, ld) for d in d_aos]
-    dens = [lib.grid_density(ao[:4], nao, dp, True) for dp in dpads]           # (rho_s, grad rho_s)
-    if len(d_aos) == 1:
-        rho, grho = dens[0]
-        edens, vrho, u = lib.xc_eval(h.xc.terms, rho, grho if gga else None, want_e=True, want_v=True)
-        pots = [(vrho, u)]
-    else:
-        (ru, gu), (rd, gd) = dens
-        edens, (vu, vd), (uu, ud) = lib.xc_eval_pol(h.xc.terms, ru, rd, gu if gga else None, gd if gga else None,
-                                                    want_e=True, want_v=True)
-        pots = [(vu, uu), (vd, ud)]
+    bs, cs_, infos = [], [], []
+    for dp in dpads:
+        rho_s, grho_s = lib.grid_density(ao[:4], nao, dp, True)
+        b = ao[0] @ dp                                                         # (ngrid, ld)
+        c = [ao[1 + i] @ dp for i in range(3)] if gga else None
+        tau = 0.5 * sum((c[i] * ao[1 + i]).sum(1) for i in range(3)) if fam == 4 else None
+        bs.append(b)
+        cs_.append(c)
+        infos.append(ValGrad(value=rho_s, grad=grho_s if gga else None, kin=tau))
+    dens = infos[0] if len(infos) == 1 else SpinParam(u=infos[0], d=infos[1])
+    edens = h.xc.get_edensityxc(dens)
+    pot = h.xc.get_vxc(dens)
+    pots = [pot] if len(infos) == 1 else [pot.u, pot.d]
     w = h.dvolume
     natm = len(mol.atomzs)
     owner = _grid_owner(mol, h.rgrid.shape[0], dev)
     ao_atom = _ao_owner(h, dev)
     g = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
-    for dp, (rho_s, grho_s), (vrho, u) in zip(dpads, dens, pots):
-        b = ao[0] @ dp                                                         # (ngrid, ld)
+    for info, b, c, pt in zip(infos, bs, cs_, pots):
+        vrho, u, vtau = pt.value, pt.grad, pt.kin
         q = torch.empty((h.rgrid.shape[0], 3), dtype=torch.float64, device=dev)
         per_ao = torch.empty((nao, 3), dtype=torch.float64, device=dev)
         if gga:
-            c = [ao[1 + i] @ dp for i in range(3)]
             t1 = vrho.unsqueeze(-1) * b + sum(u[i].unsqueeze(-1) * c[i] for i in range(3))
             ugphi = sum(u[i].unsqueeze(-1) * ao[1 + i] for i in range(3))      # u . grad phi
         else:
             t1 = vrho.unsqueeze(-1) * b
         for j in range(3):
             if gga:
-                bs = b * sum(u[i].unsqueeze(-1) * ao[_HESS[i][j]] for i in range(3))
-                q[:, j] = w * (vrho * grho_s[j] + 2.0 * (bs.sum(1) + (c[j] * ugphi).sum(1)))
-                per_ao[:, j] = ((ao[1 + j] * t1 + bs) * w.unsqueeze(-1)).sum(0)[:nao]
+                bsj = b * sum(u[i].unsqueeze(-1) * ao[_HESS[i][j]] for i in range(3))
+                if fam == 4:  # tau terms: v_tau sum_d (d_d d_j phi) c_d; same form in (ii) and (iii), without the factor 2
+                    bsj = bsj + 0.5 * vtau.unsqueeze(-1) * sum(ao[_HESS[d][j]] * c[d] for d in range(3))
+                q[:, j] = w * (vrho * info.grad[j] + 2.0 * (bsj.sum(1) + (c[j] * ugphi).sum(1)))
+                per_ao[:, j] = ((ao[1 + j] * t1 + bsj) * w.unsqueeze(-1)).sum(0)[:nao]
             else:
-                q[:, j] = w * vrho * grho_s[j]
+                q[:, j] = w * vrho * _grad_rho(ao, b, j)
                 per_ao[:, j] = (ao[1 + j] * t1 * w.unsqueeze(-1)).sum(0)[:nao]
         g.index_add_(0, owner, q)              # (ii)
         g.index_add_(0, ao_atom, -2.0 * per_ao)  # (iii)
@@ -151,6 +159,11 @@ def _xc_gradient(eng, d_aos):
     grid = get_predefined_grid(mol._grid_inp, mol.atomzs.tolist(), pos, dtype=torch.float64, device=dev)
     loss = (grid.get_dvolume() * edens.detach()).sum()
     return g + torch.autograd.grad(loss, pos)[0]
+
+
+def _grad_rho(ao, b, j):
+    """d_j rho = 2 sum_mu (D phi)_mu d_j phi_mu"""
+    return 2.0 * (b * ao[1 + j]).sum(1)
 
 
 def _grid_owner(mol, ngrid, dev):

@@ -25,6 +25,8 @@ cases = [("h2-321g-rhf", ([1, 1], [[0, 0, -0.7], [0, 0, 0.7]]), "3-21G", None, "
          ("h2-321g-lda", ([1, 1], [[0, 0, -0.7], [0, 0, 0.7]]), "3-21G", "lda_x", 4),
          ("lih-321g-pbe", ([3, 1], [[0, 0.1, -1.5], [0, 0, 1.5]]), "3-21G", "gga_x_pbe+gga_c_pbe", 4),
          ("h2o-ccpvdz-pbe", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2"),
+         ("lih-321g-scan", ([3, 1], [[0, 0.1, -1.5], [0, 0, 1.5]]), "3-21G", "mgga_x_scan", 4),
+         ("h2o-ccpvdz-scan", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "mgga_x_scan", "sg2"),
          ("h2o-ccpvdz-lda", ([8, 1, 1], [[0, 0, 0.2217], [0, 1.4309, -0.8867], [0.1, -1.4309, -0.8867]]), "cc-pvdz", "lda_x+lda_c_pw", "sg2")]
 if "--pol" in sys.argv:  # unrestricted: (basis, spin)
     CH3 = ([6, 1, 1, 1], [[0, 0, 0.05], [2.039, 0, 0], [-1.0195, 1.7658, 0], [-1.0195, -1.7658, 0.1]])
