@@ -57,26 +57,29 @@ class GraphedFock:
 
 
 class GraphedSCFStep:
-    """hipGraph of one whole restricted SCF step  F_in -> D = n P(F_in) -> F_out = dm2scp(D)  with the occupied-space
-    projector from GEMM-only purification (dqc_amd/purify.py) instead of an eigendecomposition: no rocSOLVER call,
-    no host decision, one graph launch per iteration.  Needs uniform occupations (closed shell).
+    """hipGraph of one whole SCF step  F_in -> D = n P(F_in) -> F_out = dm2scp(D)  with the occupied-space projector from
+    GEMM-only purification (dqc_amd/purify.py) instead of an eigendecomposition: no rocSOLVER call, no host decision,
+    one graph launch per iteration.  Needs uniform occupations per spin (closed shell, or high-spin unrestricted:
+    F_in = stacked (F_u, F_d), D = SpinParam of the two projectors).
 
         step = GraphedSCFStep(engine);  fock, dm, err = step(f_in)     # static buffers, valid until the next call
-    `err` (0-dim device tensor) is the idempotency + trace error of the projector; the caller checks it at the point
+    `err` (0-dim device tensor) is the idempotency + trace error of the projector(s); the caller checks it at the point
     where it synchronises anyway and falls back to the eigh path when purification did not converge."""
 
     def __init__(self, engine, warmup: int = 1):
-        if engine.polarized:
-            raise NotImplementedError("GraphedSCFStep covers the restricted engines")
-        w = engine.orb_weight
-        if not bool((w == w[0]).all()):
-            raise NotImplementedError("purification needs uniform occupations")
         self.engine = engine
-        self.occ = float(w[0])
+        self.pol = engine.polarized
+        ws = [engine.orb_weight.u, engine.orb_weight.d] if self.pol else [engine.orb_weight]
+        for w in ws:
+            if w.numel() and not bool((w == w[0]).all()):
+                raise NotImplementedError("purification needs uniform occupations")
+        self.occ = [float(w[0]) if w.numel() else 0.0 for w in ws]
+        self.nocc = [engine.norb.u, engine.norb.d] if self.pol else [engine.norb]
         n = engine.shape[-1]
-        self.f_in = torch.zeros((n, n), dtype=engine.dtype, device=engine.device)
+        shape = (2, n, n) if self.pol else (n, n)
+        self.f_in = torch.zeros(shape, dtype=engine.dtype, device=engine.device)
         idx = torch.arange(n, device=engine.device)
-        self.f_in[idx, idx] = idx.to(engine.dtype)  # any matrix with a gap at n_occ
+        self.f_in[..., idx, idx] = idx.to(engine.dtype)  # any matrix with a gap at n_occ
         s = torch.cuda.Stream(device=engine.device)
         s.wait_stream(torch.cuda.current_stream(engine.device))
         with torch.cuda.stream(s):
@@ -94,8 +97,19 @@ class GraphedSCFStep:
     def _body(self):
         from .purify import projector_from_fock
         f = (self.f_in + self.f_in.transpose(-2, -1)) * 0.5
-        p, err = projector_from_fock(f, self.engine.norb)
-        dm = p * self.occ
+        if not self.pol:
+            p, err = projector_from_fock(f, self.nocc[0])
+            dm = p * self.occ[0]
+            return self.engine.dm2scp(dm), dm, err
+        dms, err = [], 0.0
+        for s_ in range(2):
+            if self.nocc[s_] == 0:  # no electron of this spin (H atom, ...)
+                dms.append(torch.zeros_like(f[s_]))
+                continue
+            p, e = projector_from_fock(f[s_], self.nocc[s_])
+            dms.append(p * self.occ[s_])
+            err = err + e
+        dm = SpinParam(u=dms[0], d=dms[1])
         return self.engine.dm2scp(dm), dm, err
 
     def __call__(self, f_in):

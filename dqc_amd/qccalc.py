@@ -130,12 +130,13 @@ class SCF_QCCalc:
         # "diag": "purify" (default for closed shells) replaces eigh by GEMM-only purification inside the same graph
         # (dqc_amd/purify.py); "eigh" keeps the reference's diagonalise-and-occupy step (hf.py:105-113)
         graphed, purified = None, None
-        if not pol and opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0"):
+        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0"):
             from .graph import GraphedFock, GraphedSCFStep
-            w = eng.orb_weight
-            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and bool((w == w[0]).all()):
+            ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
+            uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
+            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform:
                 purified = GraphedSCFStep(eng)
-            else:
+            elif not pol:
                 graphed = GraphedFock(eng)
         perr = None
         best_err, best_it = float("inf"), 0
@@ -153,7 +154,8 @@ class SCF_QCCalc:
                     dm = eng.scp2dm(fprev)
                     fock = eng.dm2scp(dm)
                     perr = None
-                    err = fock @ dm - dm @ fock
+                    dmm = torch.stack([dm.u, dm.d]) if pol else dm
+                    err = fock @ dmm - dmm @ fock
                     emax = float(err.abs().max())
             else:
                 emax = float(err.abs().max())
@@ -192,7 +194,9 @@ class SCF_QCCalc:
             fprev = fmix
             if purified is not None:
                 f_out, d_out, perr = purified(fmix)
-                fock, dm, perr = f_out.clone(), d_out.clone(), perr.clone()  # static buffers of the graph: copy out
+                # static buffers of the graph: copy out
+                fock, perr = f_out.clone(), perr.clone()
+                dm = SpinParam(u=d_out.u.clone(), d=d_out.d.clone()) if pol else d_out.clone()
             elif graphed is not None:
                 fock = graphed(eng.scp2orb(fmix)).clone()
                 dm = graphed.density_matrix().clone()
