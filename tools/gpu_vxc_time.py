@@ -1,12 +1,22 @@
-"""time the Vxc kernel alone on the C5 shape (used with DQC_AMD_LIB ablation builds)"""
+"""time the Vxc kernel alone on the C5 shape (used with DQC_AMD_LIB ablation builds); argv[1] = data kind:
+randn (default) | zeros | small (randn * 1e-3 with 90 % exact zeros) | ones"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dqc_amd import lib
 dev = torch.device("cuda:0")
+kind = sys.argv[1] if len(sys.argv) > 1 else "randn"
 nao, ngrid = 208, 353400
 ld = lib.padded_nao(nao)
-ao = torch.randn((4, ngrid, ld), dtype=torch.float64, device=dev)
+torch.manual_seed(0)
+if kind == "zeros":
+    ao = torch.zeros((4, ngrid, ld), dtype=torch.float64, device=dev)
+elif kind == "ones":
+    ao = torch.ones((4, ngrid, ld), dtype=torch.float64, device=dev)
+else:
+    ao = torch.randn((4, ngrid, ld), dtype=torch.float64, device=dev)
+    if kind == "small":
+        ao = ao * 1e-3 * (torch.rand_like(ao) > 0.9)
 w = torch.rand(ngrid, dtype=torch.float64, device=dev)
 v = torch.randn(ngrid, dtype=torch.float64, device=dev)
 vg = torch.randn((3, ngrid), dtype=torch.float64, device=dev)
@@ -18,4 +28,4 @@ for gga in (True, False):
     for _ in range(20):
         f()
     e1.record(); torch.cuda.synchronize()
-    print("vxc gga=%d: %.3f ms" % (gga, e0.elapsed_time(e1) / 20))
+    print("vxc %s gga=%d: %.3f ms" % (kind, gga, e0.elapsed_time(e1) / 20))
