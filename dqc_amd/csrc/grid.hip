@@ -721,6 +721,10 @@ constexpr int VWS_GS = 4 * VWS_LSMAX;             // doubles between k-groups
 constexpr int VWS_XS = (16 / 4) * VWS_GS;         // doubles between Phi and Psi (16-point chunks)
 constexpr int VWS_BUF = 2 * VWS_XS;               // doubles per buffer: 64 KB; two buffers = 128 KB of the 160 KB
 typedef const __attribute__((address_space(3))) double lds_cdouble_t;
+// vxc_ws2_kernel (rectangles of at most 8 x 11 tiles): Phi rows <= 8*16 (+16 pad), Psi rows <= 11*16 (+16 pad)
+constexpr int WS2_GSA = 4 * 144, WS2_GSB = 4 * 208;       // k-group strides (doubles)
+constexpr int WS2_XS = 4 * WS2_GSA;                       // Phi part -> Psi part
+constexpr int WS2_BUF = WS2_XS + 4 * WS2_GSB;             // doubles per buffer (44 KB)
 
 // One chunk of a consumer wave: (KCH / 4) k-steps x MAXT tiles of fragment reads + MFMAs, SOFTWARE-PIPELINED by hand.  Left
 // to itself the compiler emits  ds_read a; ds_read b; s_waitcnt lgkmcnt(0); v_mfma  per tile (it minimises fragment
@@ -730,21 +734,21 @@ typedef const __attribute__((address_space(3))) double lds_cdouble_t;
 #ifndef WS_D
 #define WS_D 2
 #endif
-template <int MAXT, int KCH, int D = WS_D>
+template <int MAXT, int KCH, int D = WS_D, int GSA = VWS_GS, int GSB = VWS_GS>
 __device__ __forceinline__ void ws_chunk(const unsigned (&pa)[MAXT], const unsigned (&pb)[MAXT], v4d (&acc)[MAXT]) {
     constexpr int NS = (KCH / 4) * MAXT;
     double fa[D + 1], fb[D + 1];
 #pragma unroll
     for (int s = 0; s < D && s < NS; s++) {
-        fa[s % (D + 1)] = *(lds_cdouble_t *)(pa[s % MAXT] + (s / MAXT) * VWS_GS * 8);
-        fb[s % (D + 1)] = *(lds_cdouble_t *)(pb[s % MAXT] + (s / MAXT) * VWS_GS * 8);
+        fa[s % (D + 1)] = *(lds_cdouble_t *)(pa[s % MAXT] + (s / MAXT) * GSA * 8);
+        fb[s % (D + 1)] = *(lds_cdouble_t *)(pb[s % MAXT] + (s / MAXT) * GSB * 8);
     }
 #pragma unroll
     for (int s = 0; s < NS; s++) {  // tiles past the wave's count are clamped duplicates, discarded later
         if (s + D < NS) {
             const int s2 = s + D;
-            fa[s2 % (D + 1)] = *(lds_cdouble_t *)(pa[s2 % MAXT] + (s2 / MAXT) * VWS_GS * 8);
-            fb[s2 % (D + 1)] = *(lds_cdouble_t *)(pb[s2 % MAXT] + (s2 / MAXT) * VWS_GS * 8);
+            fa[s2 % (D + 1)] = *(lds_cdouble_t *)(pa[s2 % MAXT] + (s2 / MAXT) * GSA * 8);
+            fb[s2 % (D + 1)] = *(lds_cdouble_t *)(pb[s2 % MAXT] + (s2 / MAXT) * GSB * 8);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[s % MAXT] = mfma_f64(fa[s % (D + 1)], fb[s % (D + 1)], acc[s % MAXT]);
@@ -960,7 +964,9 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
                                                            int LSA, int LSB, const double *__restrict__ aob) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int KCH = 16;
-    const int BUF = KCH * (LSA + LSB);  // phi part (stride LSA) followed by psi part (stride LSB)
+    // chunk layout as in vxc_ws_kernel: fixed strides between the 4-point k-groups (Phi part: WS2_GSA, Psi part: WS2_GSB), so that
+    // the consumers' fragment reads are  address register + immediate;  rows inside a k-group at the run-time strides LSA / LSB
+    constexpr int BUF = WS2_BUF;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const size_t cs = (size_t)ngrid * ld;
     const int T = ld >> 4, nsplit = NR * NC;
@@ -973,75 +979,95 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     const int bi = split / NC, bj = split % NC;
     const int r0 = bi * T / NR, nr = (bi + 1) * T / NR - r0;   // tile rows of this block
     const int c0 = bj * T / NC, nc = (bj + 1) * T / NC - c0;   // tile columns
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
 
     if (wave >= VXC_WAVES) {
-        // ------------------------------------------------------------------ producers
+        // ------------------------------------------------------------------ producers (see vxc_ws_kernel: buffer loads with
+        // SGPR base + loop-invariant VGPR offset + immediate, range-checked against the slab end; the combine in its own window)
+        __builtin_amdgcn_s_setprio(3);
         constexpr int TPR = VWS2_PROD / KCH;  // 16 threads per chunk row
         const int pt = tid - 512;
         const int prow = pt / TPR, pcol = pt % TPR;
         const int wa = nr * 16, wb = nc * 16;  // staged widths (doubles)
-        double2 ra[NLA], rb[NLB][GGA ? 4 : 1];
+        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+        unsigned wla = lds0 + 8u * (unsigned)((prow >> 2) * WS2_GSA + (prow & 3) * LSA + pcol * 2);
+        unsigned wlb = lds0 + 8u * (unsigned)(WS2_XS + (prow >> 2) * WS2_GSB + (prow & 3) * LSB + pcol * 2);
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        typedef double vd2 __attribute__((ext_vector_type(2)));
+        constexpr int BUF_FLAGS = 0x00020000;
+        v4u ra[NLA], rb[NLB][GGA ? 4 : 1];
         double cf[GGA ? 4 : 1], wg = 0.0;
-        bool rowok = false;
+        auto as_d = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
         auto prefetch = [&](int c) {
-            const int g = gs + c * KCH + prow;
-            rowok = g < ge;
-            const int gg = rowok ? g : gs;
-            wg = w[gg];
-            cf[0] = vrho[gg];
+            const int g0 = gs + c * KCH;
+            const int rows = ge - g0;
+            auto rsrc = [&](const double *base, size_t bytes) {
+                return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, BUF_FLAGS);
+            };
+            const v2u xw = __builtin_amdgcn_raw_buffer_load_b64(rsrc(w + g0, (size_t)rows * 8), prow * 8, 0, 0);
+            wg = as_d(xw[0], xw[1]);
+            const v2u xr = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vrho + g0, (size_t)rows * 8), prow * 8, 0, 0);
+            cf[0] = as_d(xr[0], xr[1]);
             if (GGA) {
 #pragma unroll
-                for (int d = 0; d < 3; d++) cf[d + 1] = vgrad[(size_t)d * ngrid + gg];
+                for (int d = 0; d < 3; d++) {
+                    const v2u xg = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vgrad + (size_t)d * ngrid + g0, (size_t)rows * 8), prow * 8, 0, 0);
+                    cf[d + 1] = as_d(xg[0], xg[1]);
+                }
             }
-            const double *srca = ao + (size_t)gg * ld + r0 * 16;
-            const double *srcb = (GGA ? ao : aob) + (size_t)gg * ld + c0 * 16;
+            // bytes from the rectangle's first column of row g0 to the end of the slab (the loads of a row stop at its staged width)
+            const size_t nba = (size_t)rows * ld * 8 - (size_t)r0 * 128, nbb = (size_t)rows * ld * 8 - (size_t)c0 * 128;
+            {
+                const auto r = rsrc(ao + (size_t)g0 * ld + r0 * 16, nba);
 #pragma unroll
-            for (int i = 0; i < NLA; i++) {
-                const int c2 = (pcol + i * TPR) * 2;
-                ra[i] = *reinterpret_cast<const double2 *>(srca + (c2 < wa ? c2 : 0));
+                for (int i = 0; i < NLA; i++)
+                    if ((pcol + i * TPR) * 2 < wa) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < NLB; i++) {
-                const int c2 = (pcol + i * TPR) * 2;
-                const int cc = c2 < wb ? c2 : 0;
+            for (int d = 0; d < (GGA ? 4 : 1); d++) {
+                const auto r = rsrc((GGA ? ao : aob) + d * cs + (size_t)g0 * ld + c0 * 16, nbb);
 #pragma unroll
-                for (int d = 0; d < (GGA ? 4 : 1); d++) rb[i][d] = *reinterpret_cast<const double2 *>(srcb + d * cs + cc);
+                for (int i = 0; i < NLB; i++)
+                    if ((pcol + i * TPR) * 2 < wb) rb[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
             }
         };
-        auto stage = [&](int buf) {
-            const double ww = rowok ? wg : 0.0;
-            cf[0] *= ww;
+        auto stage = [&]() {
+            cf[0] *= wg;
             if (GGA) {
 #pragma unroll
-                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * ww;
+                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * wg;
             }
-            double *pa = lds + buf * BUF + prow * LSA, *pb = lds + buf * BUF + KCH * LSA + prow * LSB;
 #pragma unroll
-            for (int i = 0; i < NLA; i++) {
-                const int c2 = (pcol + i * TPR) * 2;
-                if (c2 < wa) *reinterpret_cast<double2 *>(pa + c2) = rowok ? ra[i] : make_double2(0.0, 0.0);
-            }
+            for (int i = 0; i < NLA; i++)
+                if ((pcol + i * TPR) * 2 < wa) *(__attribute__((address_space(3))) v4u *)(wla + i * TPR * 16) = ra[i];
 #pragma unroll
             for (int i = 0; i < NLB; i++) {
-                const int c2 = (pcol + i * TPR) * 2;
-                if (c2 < wb) {
-                    double2 ps = make_double2(cf[0] * rb[i][0].x, cf[0] * rb[i][0].y);
+                if ((pcol + i * TPR) * 2 < wb) {
+                    vd2 ps = {cf[0] * as_d(rb[i][0][0], rb[i][0][1]), cf[0] * as_d(rb[i][0][2], rb[i][0][3])};
                     if (GGA) {
 #pragma unroll
-                        for (int d = 1; d < 4; d++) { ps.x += cf[d] * rb[i][d].x; ps.y += cf[d] * rb[i][d].y; }
+                        for (int d = 1; d < 4; d++) {
+                            ps.x += cf[d] * as_d(rb[i][d][0], rb[i][d][1]);
+                            ps.y += cf[d] * as_d(rb[i][d][2], rb[i][d][3]);
+                        }
                     }
-                    *reinterpret_cast<double2 *>(pb + c2) = ps;
+                    *(__attribute__((address_space(3))) vd2 *)(wlb + i * TPR * 16) = ps;
                 }
             }
         };
         prefetch(0);
-        stage(0);
+        stage();
         if (nchunk > 1) prefetch(1);
         __syncthreads();
         for (int c = 0; c < nchunk; c++) {
-            if (c + 1 < nchunk) stage((c + 1) & 1);
+            const unsigned delta = (c & 1) ? (unsigned)(-BUF * 8) : (unsigned)(BUF * 8);  // buffer (c + 1) & 1
+            wla += delta;
+            wlb += delta;
+            __syncthreads();  // the consumers have finished chunk c - 1 and wait: the vector ALUs are free for the combine
+            if (c + 1 < nchunk) stage();
+            __syncthreads();  // the consumers start the MFMAs of chunk c
             if (c + 2 < nchunk) prefetch(c + 2);
-            __syncthreads();
         }
         return;
     }
@@ -1053,27 +1079,22 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     const int t0 = wave * per_wave;
     const int nt = max(0, min(per_wave, ttot - t0));
     v4d acc[MAXT];
-    unsigned offab[MAXT];  // LDS offsets of the A (low 16 bits) and B (high 16 bits) fragments
+    unsigned pa[MAXT], pb[MAXT];  // LDS byte addresses of the A / B fragments (k-group 0, current buffer)
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         acc[t] = v4d{0, 0, 0, 0};
         const int tl = min(t0 + t, ttot - 1);
-        offab[t] = (unsigned)(lk * LSA + (tl / nc) * 16 + lr) | ((unsigned)(KCH * LSA + lk * LSB + (tl % nc) * 16 + lr) << 16);
+        pa[t] = lds0 + 8u * (unsigned)(lk * LSA + (tl / nc) * 16 + lr);
+        pb[t] = lds0 + 8u * (unsigned)(WS2_XS + lk * LSB + (tl % nc) * 16 + lr);
     }
     __syncthreads();
     for (int c = 0; c < nchunk; c++) {
-        const double *base = lds + (c & 1) * BUF;
+        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
+        __syncthreads();  // ... and closes
+        ws_chunk<MAXT, KCH, 4, WS2_GSA, WS2_GSB>(pa, pb, acc);
+        const unsigned delta = (c & 1) ? (unsigned)(-BUF * 8) : (unsigned)(BUF * 8);
 #pragma unroll
-        for (int kk = 0; kk < KCH / 4; kk++) {
-            const int koa = kk * 4 * LSA, kob = kk * 4 * LSB;
-#pragma unroll
-            for (int t = 0; t < MAXT; t++) {  // straight-line: tiles past nt are clamped duplicates, discarded later
-                const double a = base[koa + (offab[t] & 0xffffu)];
-                const double b = base[kob + (offab[t] >> 16)];
-                acc[t] = mfma_f64(a, b, acc[t]);
-            }
-        }
-        __syncthreads();
+        for (int t = 0; t < MAXT; t++) { pa[t] += delta; pb[t] += delta; }
     }
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
@@ -1448,7 +1469,8 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             int slab = (ngrid + nslab - 1) / nslab;
             slab = (slab + 15) / 16 * 16;
             nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
-            const size_t shmem2 = sizeof(double) * 2 * 16 * (size_t)(LSA + LSB);
+            const size_t shmem2 = sizeof(double) * 2 * WS2_BUF;  // fixed-stride chunk layout, two buffers
+            if (LSA > 144 || LSB > 208) { set_error("vxc_ws2: internal layout error"); return DQC_EINVAL; }
             dim3 grid2(nslab * nsplit2);
             int rc = gga ? launch_vxc_ws2<true>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob)
                          : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob);
