@@ -4,7 +4,7 @@
 // `ao_orb2dm`, dqc/qccalc/hf.py:105-113, 227-247; dqc/hamilton/hcgto.py:272-281, done with xitorch.lsymeig).  On MI355X
 // rocSOLVER's eigh of a 208 x 208 matrix (4.5 ms) costs more than twice the whole Fock build, so P is obtained from
 // GEMMs only (dqc_amd/purify.py states the iteration).  One launch per iteration:
-//     X2 = X X  (fp64 MFMA, one wave per 16 x 16 tile, operands straight from L2 -- X is symmetric, so both fragments
+//     X2 = X X  (fp64 MFMA, one 4-wave block per 16 x 16 tile with the K range split over the waves, operands straight from L2 -- X is symmetric, so both fragments
 //               are read as rows)
 //     X' = done ? X : (tr X > n_occ ? X2 : 2 X - X2)
 //     tr X' and max |X2 - X| accumulate into per-iteration slots of a small state array (atomics), which the NEXT
@@ -18,21 +18,36 @@ namespace dqc {
 typedef double pv4d __attribute__((ext_vector_type(4)));
 
 // state layout: trace[k] = tr X_k, idem[k] = max |X_k^2 - X_k|  (k = 0 .. iters), stored as doubles
-__global__ __launch_bounds__(64) void purify_tc2_kernel(double *__restrict__ xout, const double *__restrict__ xin, int ld,
-                                                        double nocc, double tol, int k, double *__restrict__ trace,
-                                                        double *__restrict__ idem) {
+// One block of four waves per 16 x 16 tile: the K range is split over the waves (one batch of loads each for ld <= 208:
+// a single L2 round trip per iteration instead of four), partial tiles are summed through LDS.  A frozen iterate only
+// copies its tile (the launch is then a few microseconds).
+__global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xout, const double *__restrict__ xin, int ld,
+                                                         double nocc, double tol, int k, double *__restrict__ trace,
+                                                         double *__restrict__ idem) {
+    __shared__ double red[3][4][64];
     const int T = ld >> 4;
     const int ti = blockIdx.x / T, tj = blockIdx.x % T;
-    const int lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     bool done = false;
     for (int j = 0; j < k; j++) done = done || (idem[j] < tol);
+    if (done) {  // wave-uniform, block-uniform
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const size_t e = (size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr;
+                xout[e] = xin[e];
+            }
+        }
+        return;
+    }
     const double tr = trace[k];
     pv4d acc = {0.0, 0.0, 0.0, 0.0};
     // A[i][kk] = X[kk][i] (symmetric): both operands are 4 rows x 128 bytes
     const double *pa = xin + (size_t)lk * ld + ti * 16 + lr;
     const double *pb = xin + (size_t)lk * ld + tj * 16 + lr;
-    const int nk = ld >> 2;
-    for (int k0 = 0; k0 < nk; k0 += 13) {  // 26 loads in flight per batch
+    const int nk = ld >> 2, per = (nk + 3) >> 2;
+    const int kbeg = wave * per, kend = min(kbeg + per, nk);
+    for (int k0 = kbeg; k0 < kend; k0 += 13) {  // 26 loads in flight per batch
         double a[13], b[13];
 #pragma unroll
         for (int q = 0; q < 13; q++) {
@@ -42,16 +57,23 @@ __global__ __launch_bounds__(64) void purify_tc2_kernel(double *__restrict__ xou
         }
 #pragma unroll
         for (int q = 0; q < 13; q++)
-            if (k0 + q < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+            if (k0 + q < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
     // C[row = lk + 4 r][col = lr]
     double tsum = 0.0, emax = 0.0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
         const double x = xin[(size_t)row * ld + col], x2 = acc[r];
-        const double cand = tr > nocc ? x2 : 2.0 * x - x2;
-        const double out = done ? x : cand;
+        const double out = tr > nocc ? x2 : 2.0 * x - x2;
         xout[(size_t)row * ld + col] = out;
         emax = fmax(emax, fabs(x2 - x));
         if (row == col) tsum += out;
@@ -95,7 +117,7 @@ extern "C" int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, i
     const int T = ld >> 4;
     double *cur = d_x, *nxt = d_tmp;
     for (int k = 0; k < iters; k++) {
-        hipLaunchKernelGGL(purify_tc2_kernel, dim3(T * T), dim3(64), 0, st, nxt, cur, ld, nocc, tol, k, trace, idem);
+        hipLaunchKernelGGL(purify_tc2_kernel, dim3(T * T), dim3(256), 0, st, nxt, cur, ld, nocc, tol, k, trace, idem);
         DQC_CHECK_LAUNCH();
         std::swap(cur, nxt);
     }
