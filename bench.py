@@ -120,7 +120,7 @@ def main():
                 dao = lib.pad_matrix(dao_n, h._ld)
                 ev[2].record()
                 if fac is not None:
-                    rho, grho = lib.grid_density_lr(h._ao, h._nao_ao, fac, True)
+                    rho, grho = lib.grid_density_lr(h._ao, h._nao_ao, fac[0], True)  # C5: one panel (r = 46 -> 48)
                 else:
                     rho, grho = lib.grid_density(h._ao, h._nao_ao, dao, True)
                 ev[3].record()

@@ -238,7 +238,7 @@ class HamiltonMI355:
         + in-place version of the result) so that the grid pass can use the rank-n_occ density kernel."""
         orb_w = orb * orb_weight.unsqueeze(-2)
         dm = torch.matmul(orb, orb_w.transpose(-2, -1))
-        if orb.dim() == 2 and self._lowrank_density and lib.padded_norb(orb.shape[-1]) > 0:
+        if orb.dim() == 2 and self._lowrank_density:
             # occupations are >= 0 in every SCF caller; a negative weight simply disables the factor path.
             # Two entries are kept: the spin-up and spin-down matrices of an unrestricted iteration.
             self._dm_factor = ([[dm, dm._version, orb, orb_weight]] + (self._dm_factor or []))[:2]
@@ -255,7 +255,7 @@ class HamiltonMI355:
         return ok
 
     def _factor_of(self, dm):
-        """padded AO-basis factor pair of `dm` if it came out of ao_orb2dm unmodified, else None"""
+        """list of padded AO-basis factor pairs (column panels of L) of `dm` if it came out of ao_orb2dm unmodified, else None"""
         for c in self._dm_factor or []:
             if c[0] is dm and c[1] == dm._version:
                 if len(c) == 4:  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
@@ -264,7 +264,13 @@ class HamiltonMI355:
                         self._dm_factor.remove(c)
                         return None
                     l_ao = self._orthozer @ (orb * torch.sqrt(w).unsqueeze(-2))
-                    c[2:] = [lib.pad_factor(l_ao, self._ld)]
+                    r = l_ao.shape[-1]
+                    if lib.padded_norb(r) > 0:
+                        c[2:] = [[lib.pad_factor(l_ao, self._ld)]]
+                    else:  # wider than the kernel's widest instantiation: D = sum_p L_p L_p^T over column panels of L
+                        npan = (r + 127) // 128
+                        wid = (r + npan - 1) // npan
+                        c[2:] = [[lib.pad_factor(l_ao[:, i:i + wid].contiguous(), self._ld) for i in range(0, r, wid)]]
                 return c[2]
         return None
 
@@ -317,7 +323,11 @@ class HamiltonMI355:
             raise RuntimeError("Please call `setup_grid(grid, gradlevel>=1)` to calculate the density gradient")
         fac = self._factor_of(dm) if self.xcfamily != 4 else None
         if fac is not None:  # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
-            rho, grho = lib.grid_density_lr(self._ao, self._nao_ao, fac, gga)
+            rho, grho = lib.grid_density_lr(self._ao, self._nao_ao, fac[0], gga)
+            for f in fac[1:]:
+                r2, g2 = lib.grid_density_lr(self._ao, self._nao_ao, f, gga)
+                rho = rho + r2
+                grho = None if grho is None else grho + g2
             return ValGrad(value=rho, grad=grho)
         dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
         dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
