@@ -66,6 +66,11 @@ class DFMI355:
             mat = torch.stack([one(d) for d in dm.reshape(-1, *dm.shape[-2:])]).reshape(*bshape, X.shape[-1], X.shape[-1])
         return LinearOperator.m(mat, is_hermitian=True)
 
+    def coulomb_ao(self, dao: torch.Tensor) -> torch.Tensor:
+        """AO-basis J of an AO-basis density matrix (the kernel call of get_elrep without the basis conversions)"""
+        mat = lib.df_coulomb(self._j3c, self._inv_j2c, dao.contiguous(), self._work)
+        return (mat + mat.transpose(-2, -1)) * 0.5
+
     @property
     def j2c(self) -> torch.Tensor:
         return self._j2c

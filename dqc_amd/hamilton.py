@@ -342,6 +342,12 @@ class HamiltonMI355:
         return ValGrad(value=rho, grad=grho, lapl=(lb + gg) * 2, kin=gg * 0.5)
 
     def _get_vxc_from_potinfo(self, potinfo: ValGrad):
+        vm = self._vxc_ao_from_potinfo(potinfo)
+        mat = self._convert2(vm[:self._nao_ao, :self._nao_ao])
+        return (mat + mat.transpose(-2, -1)) * 0.5
+
+    def _vxc_ao_from_potinfo(self, potinfo: ValGrad):
+        """(ld, ld) AO-basis Vxc matrix (hcgto.py:445-489 before the conversion to the orthogonal basis)"""
         vg = potinfo.grad if self.xcfamily in (2, 4) else None
         vm = lib.grid_vxc(self._ao, self._nao_ao, self.dvolume, potinfo.value.contiguous(),
                           None if vg is None else vg.contiguous())
@@ -352,7 +358,19 @@ class HamiltonMI355:
             lk = ((2.0 * lapl if lapl is not None else 0.0) + 0.5 * kin).contiguous()
             for d in (1, 2, 3):
                 vm = vm + lib.grid_vxc_pair(self._ao[d], self._ao[d], self._nao_ao, self.dvolume, lk)
-        mat = self._convert2(vm[:self._nao_ao, :self._nao_ao])
+        return vm
+
+    def get_elrep_plus_vxc(self, dm):
+        """J[D] + Vxc[D] of ONE restricted density matrix as a plain tensor in the orthogonalised basis -- the sum
+        `_KSEngine.__dm2fock` forms (ks.py:176-187) -- with a single AO -> orthogonal conversion X^T (J_ao + V_ao) X instead
+        of one per operator.  Same numbers as get_elrep(dm) + get_vxc(dm) up to round-off."""
+        assert self.xc is not None and dm.dim() == 2
+        if self._df is not None:
+            jao = self._df.coulomb_ao(self._unconvert_dm(dm))
+        else:
+            jao, _ = lib.jk(self._tiles, self._unconvert_dm(dm), self._jkwork, False)
+        vm = self._vxc_ao_from_potinfo(self.xc.get_vxc(self._dm2densinfo(dm)))
+        mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
 
     def getparamnames(self, methodname: str, prefix: str = "") -> List[str]:

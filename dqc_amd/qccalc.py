@@ -51,6 +51,9 @@ class _Engine:
             core = self.knvext + self.hamilton.get_elrep(dm.u + dm.d)
             v = self.hamilton.get_vxc(dm) if self.is_ks else self.hamilton.get_exchange(dm)
             return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])
+        if self.is_ks and dm.dim() == 2 and hasattr(self.hamilton, "get_elrep_plus_vxc"):
+            # J + Vxc with one AO -> orthogonal conversion (the operators' own sum, ks.py:176-187, converts each)
+            return self.knvext.fullmatrix() + self.hamilton.get_elrep_plus_vxc(dm)
         elrep = self.hamilton.get_elrep(dm)
         if self.is_ks:
             fock = self.knvext + elrep + self.hamilton.get_vxc(dm)
