@@ -365,10 +365,16 @@ class HamiltonMI355:
         `_KSEngine.__dm2fock` forms (ks.py:176-187) -- with a single AO -> orthogonal conversion X^T (J_ao + V_ao) X instead
         of one per operator.  Same numbers as get_elrep(dm) + get_vxc(dm) up to round-off."""
         assert self.xc is not None and dm.dim() == 2
-        if self._df is not None:
-            jao = self._df.coulomb_ao(self._unconvert_dm(dm))
+        fac = self._factor_of(dm)
+        if fac is not None and len(fac) == 1:  # D_ao = L_ao L_ao^T: one thin GEMM instead of X D X^T
+            n = self._nao_ao
+            dao = (fac[0][0] @ fac[0][1])[:n, :n].contiguous()
         else:
-            jao, _ = lib.jk(self._tiles, self._unconvert_dm(dm), self._jkwork, False)
+            dao = self._unconvert_dm(dm)
+        if self._df is not None:
+            jao = self._df.coulomb_ao(dao)
+        else:
+            jao, _ = lib.jk(self._tiles, dao, self._jkwork, False)
         vm = self._vxc_ao_from_potinfo(self.xc.get_vxc(self._dm2densinfo(dm)))
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
