@@ -196,6 +196,20 @@ def main():
     names = ["jk_tiles", "orth_transforms", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
     ktime = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
 
+    # the Hartree-Fock flavour of the J/K pass (get_elrep + get_exchange, hf.py:198-199): one fused J + K launch over the same
+    # tiles, timed on molecule 0 (reported next to the kernel times; not part of `value`)
+    jk_hf_ms = None
+    if h0.df is None:
+        dao0 = h0._unconvert_dm(dms[0]).contiguous()
+        lib.jk(h0._tiles, dao0, h0._jkwork, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            lib.jk(h0._tiles, dao0, h0._jkwork, True)
+        e1.record()
+        torch.cuda.synchronize()
+        jk_hf_ms = e0.elapsed_time(e1) / args.steps
+
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components
         alg_bytes = {
@@ -266,6 +280,7 @@ def main():
             "full_scf_iterations_per_s_eigh": nmol * args.steps / elapsed_full_eigh,
             "setup_s_per_rank": setup_s,
             "kernel_ms_per_molecule": ktime,
+            "jk_with_exchange_ms": jk_hf_ms,
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
         }

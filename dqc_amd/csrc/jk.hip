@@ -51,12 +51,12 @@ __global__ void jk_finish_kernel(double *__restrict__ J, double *__restrict__ K,
 }
 
 template <bool WITH_K>
-__global__ __launch_bounds__(256) void jk_tiles_kernel(const double *__restrict__ tiles, double *__restrict__ work,
+__global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ tiles, double *__restrict__ work,
                                                        int npad, long long ntiles) {
-    constexpr int LDT = 65;
+    constexpr int LDT = 68;  // row stride of the tile parked in LDS: 16-byte aligned rows, bank = 4 row + col (mod 32)
     __shared__ double s_col[4][64];
-    __shared__ double s_g[WITH_K ? 64 * LDT : 1];
-    __shared__ double s_d[WITH_K ? 4 : 1][64];  // D[J,K], D[I,K], D[J,L], D[I,L]
+    __shared__ __attribute__((aligned(16))) double s_g[WITH_K ? 64 * LDT : 2];
+    __shared__ double s_d[WITH_K ? 4 : 1][72];  // D[J,K], D[I,K], D[J,L], D[I,L]; element (a, v) at a * 9 + v
     const size_t n2 = (size_t)npad * npad;
     const double *Dp = work;
     double *Jacc = work + n2, *Kacc = work + 2 * n2;
@@ -93,16 +93,17 @@ __global__ __launch_bounds__(256) void jk_tiles_kernel(const double *__restrict_
                 cs[c] += g[r][c] * dij[r];
             }
         if (WITH_K) {
-            __syncthreads();  // previous tile's LDS readers are done
+            // (the barrier at the end of the previous iteration has retired that tile's LDS readers)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) s_g[(r0 + r) * LDT + c0 + c] = g[r][c];
+            for (int r = 0; r < 4; r++) {
+                *reinterpret_cast<double2 *>(&s_g[(r0 + r) * LDT + c0]) = make_double2(g[r][0], g[r][1]);
+                *reinterpret_cast<double2 *>(&s_g[(r0 + r) * LDT + c0 + 2]) = make_double2(g[r][2], g[r][3]);
+            }
             // D blocks: thread t loads element (t&63) of block (t>>6)
             {
                 const int blk = t >> 6, e = t & 63, x = e >> 3, y = e & 7;
                 const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
-                s_d[blk][e] = Dp[(size_t)(R * 8 + x) * npad + Cb * 8 + y];
+                s_d[blk][x * 9 + y] = Dp[(size_t)(R * 8 + x) * npad + Cb * 8 + y];
             }
         }
         // ---- J: row sums over the 16 lanes of a row group, column sums over the 16 row groups ----
@@ -133,23 +134,27 @@ __global__ __launch_bounds__(256) void jk_tiles_kernel(const double *__restrict_
             atomicAdd(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v);
         }
         if (WITH_K) {
-            // four contractions; thread = output o (64) x partial group pg (4), 16 terms each
-            const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7;
+            // four contractions; thread = output o (64) x partial group pg (4), 16 of the 64 terms each.  Which 16 is chosen
+            // per contraction so that the 32 lanes of a half-wave (x fixed, y = 0..7, pg = 0..3) hit 32 different LDS banks at
+            // every step (row stride 68: bank = 4 row + col mod 32; yh = y >> 2):
+            //   K1  row = 8x + a, col = 8v + y : v = pg + 4u, all a               -> bank = 8 pg + y + const
+            //   K2  row = 8a + x, col = 8v + y : v = pg + 4u, all a               -> bank = 8 pg + y + const
+            //   K3  row = 8x + a, col = 8y + v : v = pg + 4 (u ^ yh), all a       -> 8 (y & 3) + pg + 4 (u ^ yh) + const
+            //   K4  row = 8a + x, col = 8y + v : v = pg + 4 (u ^ yh), all a       -> same
+            // (with the straightforward split every read had 3- to 4-way conflicts and the K part cost as much as the stream)
+            const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;
             double k1 = 0, k2 = 0, k3 = 0, k4 = 0;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 2; u++) {
+                const int q = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
 #pragma unroll
-                for (int v = 0; v < 8; v++) {
-                    const int a = 2 * pg + u;  // first summed index
-                    // K1[i=x][l=y] += g[x][a][v][y] D[J,K](a,v)
-                    k1 += s_g[(x * 8 + a) * LDT + v * 8 + y] * s_d[0][a * 8 + v];
-                    // K2[j=x][l=y] += g[a][x][v][y] D[I,K](a,v)
-                    k2 += s_g[(a * 8 + x) * LDT + v * 8 + y] * s_d[1][a * 8 + v];
-                    // K3[i=x][k=y] += g[x][a][y][v] D[J,L](a,v)
-                    k3 += s_g[(x * 8 + a) * LDT + y * 8 + v] * s_d[2][a * 8 + v];
-                    // K4[j=x][k=y] += g[a][x][y][v] D[I,L](a,v)
-                    k4 += s_g[(a * 8 + x) * LDT + y * 8 + v] * s_d[3][a * 8 + v];
+                for (int a = 0; a < 8; a++) {
+                    k1 += s_g[(x * 8 + a) * LDT + q * 8 + y] * s_d[0][a * 9 + q];    // g[x][a][v=q][y]  D[J,K](a,v)
+                    k2 += s_g[(a * 8 + x) * LDT + q * 8 + y] * s_d[1][a * 9 + q];    // g[a][x][v=q][y]  D[I,K](a,v)
+                    k3 += s_g[(x * 8 + a) * LDT + y * 8 + q4] * s_d[2][a * 9 + q4];  // g[x][a][y][v=q4] D[J,L](a,v)
+                    k4 += s_g[(a * 8 + x) * LDT + y * 8 + q4] * s_d[3][a * 9 + q4];  // g[a][x][y][v=q4] D[I,L](a,v)
                 }
+            }
             k1 += __shfl_xor(k1, 1); k1 += __shfl_xor(k1, 2);
             k2 += __shfl_xor(k2, 1); k2 += __shfl_xor(k2, 2);
             k3 += __shfl_xor(k3, 1); k3 += __shfl_xor(k3, 2);
