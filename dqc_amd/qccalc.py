@@ -142,6 +142,7 @@ class SCF_QCCalc:
             elif not pol:
                 graphed = GraphedFock(eng)
         perr = None
+        gram = np.zeros((0, 0))
         best_err, best_it = float("inf"), 0
         self.converged = False
         for it in range(int(opts["maxiter"])):
@@ -151,17 +152,23 @@ class SCF_QCCalc:
                 err = fock @ dms - dms @ fock
             else:
                 err = fock @ dm - dm @ fock  # [F, D], S = 1
-            if perr is not None:  # projector of the step just taken: one host read together with the DIIS error
-                emax, pe = (float(v) for v in torch.stack([err.abs().max(), perr]).cpu())
-                if not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
-                    dm = eng.scp2dm(fprev)
-                    fock = eng.dm2scp(dm)
-                    perr = None
-                    dmm = torch.stack([dm.u, dm.d]) if pol else dm
-                    err = fock @ dmm - dmm @ fock
-                    emax = float(err.abs().max())
-            else:
+            # ONE host read per iteration: max |[F, D]|, the projector error of the step just taken, and the new row of the
+            # DIIS Gram matrix (this error vector against the stored ones) travel together
+            ev = err.reshape(-1)
+            hist = es[-(int(opts["history"]) - 1):] if int(opts["history"]) > 1 else []
+            row = (torch.stack(hist + [ev]) * ev).sum(-1)
+            head = torch.stack([err.abs().max(), perr if perr is not None else torch.zeros((), dtype=fock.dtype, device=fock.device)])
+            host = torch.cat([head, row]).cpu().numpy()
+            emax, pe, grow = float(host[0]), float(host[1]), host[2:]
+            if perr is not None and not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
+                dm = eng.scp2dm(fprev)
+                fock = eng.dm2scp(dm)
+                perr = None
+                dmm = torch.stack([dm.u, dm.d]) if pol else dm
+                err = fock @ dmm - dmm @ fock
+                ev = err.reshape(-1)
                 emax = float(err.abs().max())
+                grow = (torch.stack(hist + [ev]) * ev).sum(-1).cpu().numpy()
             self.scf_error = emax  # max |[F, D]| of the last iterate
             # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,
             # growing with the matrix size): accept an iterate that is within 100 f_tol and has not improved for 8 steps
@@ -172,24 +179,30 @@ class SCF_QCCalc:
                 self.converged = True
                 break
             fs.append(fock)
-            es.append(err.reshape(-1))
+            es.append(ev)
             if len(fs) > opts["history"]:
                 fs.pop(0)
                 es.pop(0)
             m = len(fs)
+            # the Gram matrix lives on the host and grows by the row just read (broadcast-multiply-reduce on the device:
+            # the GEMM form E @ E.T hits a pathological rocBLAS path for the tall-skinny fp64 shape, 7 ms for 8 x 43264)
+            keep = m - 1  # == len(hist): the stored vectors that survive
+            gnew = np.zeros((m, m))
+            if keep:
+                gnew[:keep, :keep] = gram[-keep:, -keep:]
+            gnew[keep, :] = grow
+            gnew[:, keep] = grow
+            gram = gnew
             if m > 1:
-                E = torch.stack(es)
-                B = torch.zeros((m + 1, m + 1), dtype=fock.dtype, device=fock.device)
-                # Gram matrix of the error vectors by broadcast-multiply-reduce: the (m, n^2) x (n^2, m) GEMM form of
-                # E @ E.T hits a pathological rocBLAS path for this tall-skinny fp64 shape (7 ms for 8 x 43264)
-                B[:m, :m] = (E.unsqueeze(1) * E.unsqueeze(0)).sum(-1)
+                B = np.zeros((m + 1, m + 1))
+                B[:m, :m] = gram
                 B[m, :m] = -1
                 B[:m, m] = -1
-                rhs = torch.zeros(m + 1, dtype=fock.dtype, device=fock.device)
+                rhs = np.zeros(m + 1)
                 rhs[m] = -1
                 # (m+1) x (m+1) Pulay system on the host with numpy: torch's CPU lstsq costs ~7 ms per call on a
                 # 256-thread box (thread-pool wake-up), several times the whole Fock build
-                c = np.linalg.lstsq(B.cpu().numpy(), rhs.cpu().numpy(), rcond=None)[0][:m]
+                c = np.linalg.lstsq(B, rhs, rcond=None)[0][:m]
                 c = torch.as_tensor(c, dtype=fock.dtype).to(fock.device)
                 fmix = (c.reshape((-1,) + (1,) * fock.dim()) * torch.stack(fs)).sum(0)
             else:
