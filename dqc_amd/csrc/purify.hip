@@ -99,6 +99,60 @@ __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double
     if (threadIdx.x == 0) trace0[0] = part[0] + part[1] + part[2] + part[3];
 }
 
+// Orthonormal basis of the range of a projector from GEMMs + one small launch: Y = P Omega (n x r, Omega a fixed random matrix,
+// r = rank P) spans range(P); with G = Y^T Y = C C^T (Cholesky), Q = Y C^-T has orthonormal columns and Q Q^T = P.  The SCF
+// step uses it to hand the purified density matrix to the Hamiltonian in FACTOR form (ao_orb2dm(Q, n): hcgto.py:272-281), so
+// that the grid pass takes the rank-r density kernel.  Single-wave blocks (barriers cost nothing): every block factors G in
+// its own LDS (left-looking, lane i owns row i) and forward-substitutes `rb` rows of Y, one per lane, also in LDS.
+// A G that is not positive definite (purification failed) gives NaNs, which the caller's idempotency check turns into the
+// eigh fallback.
+__global__ __launch_bounds__(64) void orth_factor_kernel(double *__restrict__ q, const double *__restrict__ y,
+                                                         const double *__restrict__ g, int n, int r, int rb) {
+    extern __shared__ double sm[];
+    const int ldc = r | 1, t = threadIdx.x;  // odd row stride: the rows of different lanes start in different banks
+    double *c = sm, *rw = sm + (size_t)r * ldc;
+    const int row0 = blockIdx.x * rb;
+    for (int e = t; e < r * r; e += 64) c[(e / r) * ldc + e % r] = g[e];
+    for (int e = t; e < rb * r; e += 64) {
+        const int rr = e / r, k = e % r;
+        rw[rr * ldc + k] = row0 + rr < n ? y[(size_t)(row0 + rr) * r + k] : 0.0;
+    }
+    __syncthreads();
+    // dot(a[0:k], b[0:k]) with 16 LDS reads in flight
+    auto dotk = [](const double *a, const double *b, int k) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int j = 0;
+        for (; j + 7 < k; j += 8) {
+            const double x0 = a[j], x1 = a[j + 1], x2 = a[j + 2], x3 = a[j + 3], x4 = a[j + 4], x5 = a[j + 5], x6 = a[j + 6], x7 = a[j + 7];
+            const double y0 = b[j], y1 = b[j + 1], y2 = b[j + 2], y3 = b[j + 3], y4 = b[j + 4], y5 = b[j + 5], y6 = b[j + 6], y7 = b[j + 7];
+            a0 += x0 * y0; a1 += x1 * y1; a2 += x2 * y2; a3 += x3 * y3;
+            a0 += x4 * y4; a1 += x5 * y5; a2 += x6 * y6; a3 += x7 * y7;
+        }
+        for (; j < k; j++) a0 += a[j] * b[j];
+        return (a0 + a1) + (a2 + a3);
+    };
+    // step k: column k of C (left-looking: finished columns only; lane i owns row i), then -- row k of C being final -- entry
+    // k of every row of Q (Q[row] C^T = Y[row], one row per lane); the two dot products of a step overlap
+    for (int k = 0; k < r; k++) {
+        const double *ck = c + k * ldc;
+        for (int i = k + t; i < r; i += 64) c[i * ldc + k] -= dotk(c + i * ldc, ck, k);
+        __syncthreads();
+        const double dinv = 1.0 / sqrt(ck[k]);
+        __syncthreads();
+        for (int i = k + t; i < r; i += 64) c[i * ldc + k] = i == k ? 1.0 / dinv : c[i * ldc + k] * dinv;
+        for (int rr = t; rr < rb; rr += 64) {  // row k of C left of the diagonal is final since step k - 1
+            double *w = rw + rr * ldc;
+            w[k] = (w[k] - dotk(w, ck, k)) * dinv;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = t; e < rb * r; e += 64) {
+        const int rr = e / r, k = e % r;
+        if (row0 + rr < n) q[(size_t)(row0 + rr) * r + k] = rw[rr * ldc + k];
+    }
+}
+
 }  // namespace dqc
 
 extern "C" int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
@@ -122,5 +176,20 @@ extern "C" int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, i
         std::swap(cur, nxt);
     }
     if (cur != d_x) DQC_HIP(hipMemcpyAsync(d_x, cur, sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, st));
+    return DQC_OK;
+}
+
+extern "C" int dqc_orth_factor(double *d_q, const double *d_y, const double *d_g, int n, int r, void *stream) {
+    // d_y (n, r) row-major with full column rank, d_g (r, r) = Y^T Y  ->  d_q (n, r) = Y C^-T, G = C C^T.  Enqueues only.
+    using namespace dqc;
+    if (n <= 0 || r <= 0) return DQC_OK;
+    int rb = 64;  // rows of Y per block: as many as fit next to the r x r factor
+    const int ldc = r | 1;
+    while (rb > 8 && sizeof(double) * (size_t)(r + rb) * ldc > 150 * 1024) rb >>= 1;
+    const size_t lds = sizeof(double) * (size_t)(r + rb) * ldc;
+    if (lds > 150 * 1024) { set_error("dqc_orth_factor: r above 132 is not supported"); return DQC_EINVAL; }
+    (void)hipFuncSetAttribute((const void *)orth_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(orth_factor_kernel, dim3((n + rb - 1) / rb), dim3(64), lds, (hipStream_t)stream, d_q, d_y, d_g, n, r, rb);
+    DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -75,7 +75,10 @@ class GraphedSCFStep:
                 raise NotImplementedError("purification needs uniform occupations")
         self.occ = [float(w[0]) if w.numel() else 0.0 for w in ws]
         self.nocc = [engine.norb.u, engine.norb.d] if self.pol else [engine.norb]
+        self.weights = ws
         n = engine.shape[-1]
+        gen = torch.Generator().manual_seed(20240229)
+        self.omega = [torch.randn((n, r), dtype=engine.dtype, generator=gen).to(engine.device) for r in self.nocc]
         shape = (2, n, n) if self.pol else (n, n)
         self.f_in = torch.zeros(shape, dtype=engine.dtype, device=engine.device)
         idx = torch.arange(n, device=engine.device)
@@ -94,12 +97,25 @@ class GraphedSCFStep:
         h._jk_cache = None
         h._dm_factor = None
 
+    def _dm_of_projector(self, p, s_):
+        """occ * P as ao_orb2dm(Q, occ) with Q an orthonormal basis of range(P) (Cholesky QR of P . Omega, one small launch:
+        dqc_orth_factor), so that the Hamiltonian knows the rank-n_occ factor of the matrix and the grid pass takes the
+        factor-form density kernel; wide occupied spaces keep the anonymous matrix"""
+        from . import lib
+        r = self.nocc[s_]
+        w = self.weights[s_]
+        if not (0 < r <= 128 and lib.padded_norb(r) > 0 and self.engine.hamilton._lowrank_density):
+            return p * self.occ[s_]
+        y = p @ self.omega[s_]
+        q = lib.orth_factor(y, y.transpose(-2, -1) @ y)
+        return self.engine.hamilton.ao_orb2dm(q, w)
+
     def _body(self):
         from .purify import projector_from_fock
         f = (self.f_in + self.f_in.transpose(-2, -1)) * 0.5
         if not self.pol:
             p, err = projector_from_fock(f, self.nocc[0])
-            dm = p * self.occ[0]
+            dm = self._dm_of_projector(p, 0)
             return self.engine.dm2scp(dm), dm, err
         dms, err = [], 0.0
         for s_ in range(2):
@@ -107,7 +123,7 @@ class GraphedSCFStep:
                 dms.append(torch.zeros_like(f[s_]))
                 continue
             p, e = projector_from_fock(f[s_], self.nocc[s_])
-            dms.append(p * self.occ[s_])
+            dms.append(self._dm_of_projector(p, s_))
             err = err + e
         dm = SpinParam(u=dms[0], d=dms[1])
         return self.engine.dm2scp(dm), dm, err

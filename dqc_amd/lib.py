@@ -55,6 +55,7 @@ def load():
     lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double, ctypes.c_double] + tab + [c_vp]
     lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
+    lib.dqc_orth_factor.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
@@ -195,6 +196,14 @@ def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
     _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
                                  _stream()), "dqc_purify_tc2")
     return x_pad
+
+
+def orth_factor(y, g):
+    """y (n, r) = P Omega, g (r, r) = y^T y -> (n, r) orthonormal basis of range(P) (Cholesky QR in one launch)"""
+    n, r = y.shape
+    q = torch.empty_like(y)
+    _check(load().dqc_orth_factor(_ptr(q), _ptr(y.contiguous()), _ptr(g.contiguous()), n, r, _stream()), "dqc_orth_factor")
+    return q
 
 
 def df_grad(grad, dcart, ccart, tab, orb_range, aux_range):

@@ -165,6 +165,11 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
 int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                    void *stream);
 
+/* Orthonormal basis of the range of a projector (the orbitals `ao_orb2dm` wants, hcgto.py:272-281, without an eigensolver):
+ * d_y (n, r) = P . Omega with full column rank, d_g (r, r) = Y^T Y  ->  d_q (n, r) = Y C^-T with G = C C^T, so Q^T Q = 1 and
+ * Q Q^T = P.  One launch (Cholesky in LDS + row-wise forward substitution); r <= 132.  Enqueues only. */
+int dqc_orth_factor(double *d_q, const double *d_y, const double *d_g, int n, int r, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
