@@ -321,14 +321,23 @@ class HamiltonMI355:
         gga = self.xcfamily in (2, 4)
         if gga and not self.is_grad_ao_set:
             raise RuntimeError("Please call `setup_grid(grid, gradlevel>=1)` to calculate the density gradient")
-        fac = self._factor_of(dm) if self.xcfamily != 4 else None
-        if fac is not None:  # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
+        fac = self._factor_of(dm)
+        # meta-GGA: the laplacian of the density is only formed for functionals that may use it (none of the kernel set does:
+        # LibXC objects; a user-supplied BaseXC gets it, as in the reference, through the full-matrix path below)
+        from .xc import LibXC
+        if fac is not None and (self.xcfamily != 4 or (isinstance(self.xc, LibXC) and self.is_lapl_ao_set)):
+            # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
             rho, grho = lib.grid_density_lr(self._ao, self._nao_ao, fac[0], gga)
             for f in fac[1:]:
                 r2, g2 = lib.grid_density_lr(self._ao, self._nao_ao, f, gga)
                 rho = rho + r2
                 grho = None if grho is None else grho + g2
-            return ValGrad(value=rho, grad=grho)
+            if self.xcfamily != 4:
+                return ValGrad(value=rho, grad=grho)
+            # tau = 1/2 sum_d sum_r (d_d Phi . L)_r^2 (hcgto.py:420-438 grad_grad term): the factor kernel on each gradient
+            # component, phase 1 only
+            gg = sum(lib.grid_density_lr(self._ao[d], self._nao_ao, f, False)[0] for d in (1, 2, 3) for f in fac)
+            return ValGrad(value=rho, grad=grho, lapl=None, kin=gg * 0.5)
         dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
         dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
         rho, grho = lib.grid_density(self._ao, self._nao_ao, dao, gga)
