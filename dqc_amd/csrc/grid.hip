@@ -771,7 +771,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
                                                           int ngrid, int ld, const double *__restrict__ w,
                                                           const double *__restrict__ vrho,
                                                           const double *__restrict__ vgrad, int slab, int nsplit,
-                                                          int tiles_per_split, const double *__restrict__ aob) {
+                                                          int tiles_per_split, const double *__restrict__ aob, int sym) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(KCH == 16, "the fixed-stride chunk layout is laid out for 16-point chunks");
     const int LS = ld;
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
                 for (int i = 0; i < NLP; i++)
                     if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
             }
-            if (!GGA) {
+            if (!GGA && !sym) {  // (sym: the second operand is the first)
                 const auto r = rsrc(aob + (size_t)g0 * ld, nb);
 #pragma unroll
                 for (int i = 0; i < NLP; i++)
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
 #pragma unroll
             for (int i = 0; i < NLP; i++) {
                 if ((pcol + i * TPR) * 2 < ld) {
-                    const v4u pb = raw[i][GGA ? 0 : 1];
+                    const v4u pb = (GGA || sym) ? raw[i][0] : raw[i][1];
                     vd2 ps = {cf[0] * as_d(pb[0], pb[1]), cf[0] * as_d(pb[2], pb[3])};
                     if (GGA) {
 #pragma unroll
@@ -896,7 +896,16 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
 
     // ---------------------------------------------------------------------- consumers
     const int lr = lane & 15, lk = lane >> 4;
-    const int T = ld >> 4, ttot = T * T;
+    // sym: A^T diag(w v) A with ONE operand (LDA Vxc, the tau terms of a meta-GGA) is symmetric -- only the tiles (i <= j) are
+    // computed, off-diagonal ones doubled so that the final (M + M^T) / 2 restores both halves
+    const int T = ld >> 4, ttot = sym ? T * (T + 1) / 2 : T * T;
+    auto tile_ij = [&](int u, int &ti, int &tj) {
+        if (!sym) { ti = u / T; tj = u - ti * T; return; }
+        int i = 0, rem = u;
+        while (rem >= T - i) { rem -= T - i; i++; }  // row i of the upper triangle holds T - i tiles
+        ti = i;
+        tj = i + rem;
+    };
     const int tc0 = split * tiles_per_split;
     const int tc1 = min(tc0 + tiles_per_split, ttot);
     const int per_wave = (tc1 - tc0 + VXC_WAVES - 1) / VXC_WAVES;
@@ -908,9 +917,10 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         acc[t] = v4d{0, 0, 0, 0};
-        const int tid2 = min(t0 + t, ttot - 1);
-        pa[t] = lds0 + 8u * (unsigned)(lk * LS + (tid2 / T) * 16 + lr);
-        pb[t] = lds0 + 8u * (unsigned)(VWS_XS + lk * LS + (tid2 % T) * 16 + lr);
+        int ti, tj;
+        tile_ij(min(t0 + t, ttot - 1), ti, tj);
+        pa[t] = lds0 + 8u * (unsigned)(lk * LS + ti * 16 + lr);
+        pb[t] = lds0 + 8u * (unsigned)(VWS_XS + lk * LS + tj * 16 + lr);
     }
     __syncthreads();
     if (wave == 0) VXC_TRACE_POINT(0, 0);
@@ -935,11 +945,13 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
 #pragma unroll
     for (int t = 0; t < MAXT; t++) {
         if (t < nt) {
-            const int tl = t0 + t;
-            const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
+            int ti, tj;
+            tile_ij(t0 + t, ti, tj);
+            const int ia = ti * 16 + lk, ib = tj * 16 + lr;
+            const double sc = (sym && ti != tj) ? 2.0 : 1.0;
 #pragma unroll
 #ifndef ABL_VWS_NO_EPI
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
 #else
             for (int r = 0; r < 4; r++) if (acc[t][r] == 1.2345) vmat[0] = 1.0;
 #endif
@@ -1285,25 +1297,25 @@ static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vma
 template <int MAXT, int NLP, int KCH, bool GGA>
 static void launch_vxc_ws_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                                const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps,
-                               const double *aob) {
+                               const double *aob, int sym) {
     auto kern = vxc_ws_kernel<MAXT, NLP, KCH, GGA>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);
+    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym);
 }
 
 template <bool GGA>
 static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat,
                          const double *ao, int ngrid, int ld, const double *w, const double *vrho, const double *vgrad,
-                         int slab, int nsplit, int tps, const double *aob) {
+                         int slab, int nsplit, int tps, const double *aob, int sym) {
 #define DQC_VWS_CASE(N, L)                                                                                          \
     if (maxt == N && nlp == L && kch == 16) {                                                                       \
-        launch_vxc_ws_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob); \
+        launch_vxc_ws_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym); \
         return 0;                                                                                                   \
     }
-    DQC_VWS_CASE(2, 1) DQC_VWS_CASE(4, 1) DQC_VWS_CASE(8, 1) DQC_VWS_CASE(11, 1)
-    DQC_VWS_CASE(2, 2) DQC_VWS_CASE(4, 2) DQC_VWS_CASE(8, 2) DQC_VWS_CASE(11, 2)
-    DQC_VWS_CASE(2, 4) DQC_VWS_CASE(4, 4) DQC_VWS_CASE(8, 4) DQC_VWS_CASE(11, 4)
-    DQC_VWS_CASE(8, 7) DQC_VWS_CASE(11, 7)
+    DQC_VWS_CASE(2, 1) DQC_VWS_CASE(4, 1) DQC_VWS_CASE(6, 1) DQC_VWS_CASE(8, 1) DQC_VWS_CASE(11, 1)
+    DQC_VWS_CASE(2, 2) DQC_VWS_CASE(4, 2) DQC_VWS_CASE(6, 2) DQC_VWS_CASE(8, 2) DQC_VWS_CASE(11, 2)
+    DQC_VWS_CASE(2, 4) DQC_VWS_CASE(4, 4) DQC_VWS_CASE(6, 4) DQC_VWS_CASE(8, 4) DQC_VWS_CASE(11, 4)
+    DQC_VWS_CASE(6, 7) DQC_VWS_CASE(8, 7) DQC_VWS_CASE(11, 7)
 #undef DQC_VWS_CASE
     set_error("vxc_ws: internal dispatch error");
     return DQC_EINVAL;
@@ -1455,7 +1467,12 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
-        if (ttot > 2 * 11 * VXC_WAVES && !(impl_env && impl_env[0] == 'r')) {
+        // one-operand forms without a gradient term (LDA Vxc, the tau terms of a meta-GGA) are symmetric matrices: the
+        // wave-specialised kernel then computes the upper-triangular tiles only
+        const bool ws_shape = ld <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r');
+        const bool sym = ws_shape && !gga && d_aob == d_ao;
+        const int ttot_w = sym ? T * (T + 1) / 2 : ttot;
+        if (ttot_w > 2 * 11 * VXC_WAVES && !(impl_env && impl_env[0] == 'r')) {
             // larger bases: rectangular ownership (vxc_ws2_kernel), rectangles of at most 8 x 11 tiles
             const int NR = (T + 7) / 8, NC = (T + 10) / 11;
             const int nrmax = (T + NR - 1) / NR, ncmax = (T + NC - 1) / NC;
@@ -1481,14 +1498,15 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             return DQC_OK;
         }
         // tiles per block are capped at 11 per wave so that accumulators + prefetch registers fit 256 VGPRs
-        static const int sizes[] = {2, 4, 8, 11};
+        static const int sizes_ws[] = {2, 4, 6, 8, 11}, sizes_reg[] = {2, 4, 8, 11, 11};
+        const int *sizes_p = ws_shape ? sizes_ws : sizes_reg;
         const int cap = 11 * VXC_WAVES;
-        const int nsplit = (ttot + cap - 1) / cap;
-        const int tps = (ttot + nsplit - 1) / nsplit;
+        const int nsplit = (ttot_w + cap - 1) / cap;
+        const int tps = (ttot_w + nsplit - 1) / nsplit;
         const int need = (tps + VXC_WAVES - 1) / VXC_WAVES;
         int maxt = 11;
-        for (int sz : sizes)
-            if (sz >= need) { maxt = sz; break; }
+        for (int q = 0; q < 5; q++)
+            if (sizes_p[q] >= need) { maxt = sizes_p[q]; break; }
         // chunk depth: 16 points while the double-buffered (phi, psi) chunk fits LDS, else 8
         const int kch = (sizeof(double) * 2 * 2 * 16 * (size_t)ld <= 150 * 1024) ? 16 : 8;
         const int tpr = 512 / kch;  // threads per chunk row
@@ -1509,8 +1527,8 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         const int nlp = nlpneed <= 1 ? 1 : (nlpneed <= 2 ? 2 : (nlpneed <= 4 ? 4 : (nlpneed <= 7 ? 7 : 8)));
         if (nlpneed <= 7 && kch == 16 && ld <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r')) {
             const size_t shmem_ws = sizeof(double) * 2 * VWS_BUF;  // fixed-stride chunk layout, two buffers
-            int rc = gga ? launch_vxc_ws<true>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob)
-                         : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob);
+            int rc = gga ? launch_vxc_ws<true>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, 0)
+                         : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, sym ? 1 : 0);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
             hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
