@@ -166,12 +166,18 @@ def _grad_rho(ao, b, j):
     return 2.0 * (b * ao[1 + j]).sum(1)
 
 
+_ATOM_GRID_SIZE = {}
+
+
 def _grid_owner(mol, ngrid, dev):
     """parent atom of every grid point: the atomic grids are concatenated atom by atom (dqc_amd.grid.get_grid)"""
     sizes = []
     for z in mol.atomzs.tolist():
-        one = get_predefined_grid(mol._grid_inp, [z], torch.zeros((1, 3), dtype=torch.float64), dtype=torch.float64, device="cpu")
-        sizes.append(one.get_rgrid().shape[0])
+        key = (str(mol._grid_inp), int(z))
+        if key not in _ATOM_GRID_SIZE:  # the size of an atomic grid depends on the element and the grid recipe only
+            one = get_predefined_grid(mol._grid_inp, [z], torch.zeros((1, 3), dtype=torch.float64), dtype=torch.float64, device="cpu")
+            _ATOM_GRID_SIZE[key] = one.get_rgrid().shape[0]
+        sizes.append(_ATOM_GRID_SIZE[key])
     assert sum(sizes) == ngrid
     return torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
 
