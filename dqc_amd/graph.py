@@ -108,15 +108,19 @@ class GraphedSCFStep:
             return p * self.occ[s_]
         y = p @ self.omega[s_]
         q = lib.orth_factor(y, y.transpose(-2, -1) @ y)
-        return self.engine.hamilton.ao_orb2dm(q, w)
+        dm = self.engine.hamilton.ao_orb2dm(q, w)
+        # a failed factorisation (NaN / wrong range) must surface in the step's error so that the caller falls back to eigh
+        self._factor_err = self._factor_err + (dm - p * self.occ[s_]).abs().max()
+        return dm
 
     def _body(self):
         from .purify import projector_from_fock
         f = (self.f_in + self.f_in.transpose(-2, -1)) * 0.5
+        self._factor_err = 0.0
         if not self.pol:
             p, err = projector_from_fock(f, self.nocc[0])
             dm = self._dm_of_projector(p, 0)
-            return self.engine.dm2scp(dm), dm, err
+            return self.engine.dm2scp(dm), dm, err + self._factor_err
         dms, err = [], 0.0
         for s_ in range(2):
             if self.nocc[s_] == 0:  # no electron of this spin (H atom, ...)
@@ -126,7 +130,7 @@ class GraphedSCFStep:
             dms.append(self._dm_of_projector(p, s_))
             err = err + e
         dm = SpinParam(u=dms[0], d=dms[1])
-        return self.engine.dm2scp(dm), dm, err
+        return self.engine.dm2scp(dm), dm, err + self._factor_err
 
     def __call__(self, f_in):
         if f_in is not self.f_in:
