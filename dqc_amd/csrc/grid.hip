@@ -689,10 +689,12 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 // 16x16x4 per 64.6 cycles, 78 TF chip-wide) only while TWO of its waves are issuing MFMAs; a single issuing wave
 // gets one per 140 cycles (36 TF).  In vxc_kernel every wave alternates MFMA work with loads, the Psi combination
 // and LDS writes, so for part of every chunk fewer than two waves per SIMD feed the matrix pipe.  Here a block is
-// 12 waves: waves 0-7 (two per SIMD) are CONSUMERS that do nothing but fragment reads + MFMAs; waves 8-11 (one per
-// SIMD) are PRODUCERS that load the next chunk's four AO components, form Psi and write the (Phi, Psi) chunk to the
-// other LDS buffer.  One s_barrier per chunk hands the buffers over.  Tile ownership, split-K over slabs, the
-// XCD-aware block decode and the atomic epilogue are those of vxc_kernel.
+// 16 waves: waves 0-7 (two per SIMD) are CONSUMERS that do nothing but fragment reads + MFMAs; waves 8-15 (two per
+// SIMD) are PRODUCERS that fetch the next chunk's four AO components (buffer loads: no VALU address arithmetic), form
+// Psi and write the (Phi, Psi) chunk to the other LDS buffer.  An fp64 MFMA occupies the SIMD's vector ALU, so the
+// producers' VALU work cannot overlap the MFMAs: it runs in a window between two s_barriers per chunk during which the
+// consumers wait; the loads fly during the MFMA phase (see the comments in the kernel and DESIGN.md, section 3).  Tile
+// ownership, split-K over slabs, the XCD-aware block decode and the atomic epilogue are those of vxc_kernel.
 // ---------------------------------------------------------------------------------------------
 #ifndef VWS_PROD_THREADS
 #define VWS_PROD_THREADS 512
