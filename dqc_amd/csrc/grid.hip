@@ -1121,162 +1121,7 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Vxc, LDS-DMA variant: the four AO components of the next 8-point chunk are copied HBM -> LDS by
-// global_load_lds_dwordx4 (no staging VGPRs), so one block keeps ALL n x n output tiles in registers
-// (up to 22 per wave) and the slab is read from HBM exactly once.  Per chunk:
-//   wait DMA(c) | barrier | issue DMA(c+1) | Psi = sum_d cf_d * raw_d (LDS -> LDS) | barrier | MFMAs
-// Raw s_barrier + counted waits keep DMA(c+1) in flight across the barriers and under the MFMA phase.
-// ---------------------------------------------------------------------------------------------
-constexpr int VG_KC = 8;
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
-template <int MAXT, bool GGA>
-__global__ __launch_bounds__(512, 2) void vxc_glds_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
-                                                          int ngrid, int ld, const double *__restrict__ w,
-                                                          const double *__restrict__ vrho,
-                                                          const double *__restrict__ vgrad, int slab) {
-    constexpr int NC = GGA ? 4 : 1;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int LS = ld;
-    const int RAW = NC * VG_KC * LS;            // doubles per raw buffer
-    double *raw0 = lds, *psi = lds + 2 * RAW;   // raw[2][NC][KC][LS], psi[KC][LS]
-    double *scf = psi + VG_KC * LS;             // cf[NC][KC]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int T = ld >> 4, ttot = T * T;
-    const size_t cs = (size_t)ngrid * ld;
-    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
-    if (gs >= ngrid) return;
-    const int per_wave = (ttot + VXC_WAVES - 1) / VXC_WAVES;
-    const int t0 = wave * per_wave;
-    const int nt = max(0, min(per_wave, ttot - t0));
-
-    v4d acc[MAXT];
-    unsigned offab[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        acc[t] = v4d{0, 0, 0, 0};
-        const int tl = min(t0 + t, ttot - 1);
-        offab[t] = (unsigned)(lk * LS + (tl / T) * 16 + lr) | ((unsigned)(lk * LS + (tl % T) * 16 + lr) << 16);
-    }
-
-    // DMA plan: a component's chunk (KC rows x ld doubles, contiguous in HBM and in LDS) is ld/16 wave
-    // instructions of 1 KiB; instruction j of the chunk (j < NC*ld/16) is issued by wave j % 8
-    const int ipc = ld >> 4;              // instructions per component
-    const int ninstr = NC * ipc;
-    auto issue_dma = [&](int gc, int buf) {
-        for (int j = wave; j < ninstr; j += VXC_WAVES) {
-            const int c = j / ipc, ji = j - c * ipc;
-            const int el = ji * 128 + lane * 2;         // element inside the (KC x ld) chunk
-            int g = gc + el / ld;
-            const int col = el % ld;
-            g = min(g, ngrid - 1);                      // rows past the end re-read the last row; their cf is 0
-            const double *src = ao + c * cs + (size_t)g * ld + col;
-            double *dst = raw0 + buf * RAW + c * VG_KC * LS + ji * 128;  // wave-uniform; lane*16 B added by hardware
-#ifndef ABL_VXC_NO_LOAD
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
-#endif
-        }
-    };
-    auto load_cf = [&](int gc) -> double {
-        double v = 0.0;
-        if (tid < NC * VG_KC) {
-            const int c = tid / VG_KC, g = gc + (tid % VG_KC);
-            if (g < ge) {
-                const double wg = w[g];
-                v = c == 0 ? wg * vrho[g] : 2.0 * wg * vgrad[(size_t)(c - 1) * ngrid + g];
-            }
-        }
-        return v;
-    };
-
-    const int half = ld >> 1;
-    issue_dma(gs, 0);
-    double cf = load_cf(gs);
-    int buf = 0;
-    for (int gc = gs; gc < ge; gc += VG_KC) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA(c) pieces landed, cf arrived
-        if (tid < NC * VG_KC) scf[tid] = cf;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // raw[buf] complete for every wave; psi/raw[buf^1] free
-        const bool more = gc + VG_KC < ge;
-        if (more) {
-            issue_dma(gc + VG_KC, buf ^ 1);                // in flight during combine + MFMA
-            cf = load_cf(gc + VG_KC);
-        }
-        const double *rb = raw0 + buf * RAW;
-        for (int e = tid; e < VG_KC * half; e += 512) {
-            const int row = e / half, c2 = (e - row * half) * 2;
-            const double2 r0 = *reinterpret_cast<const double2 *>(rb + row * LS + c2);
-            const double c0 = scf[row];
-            double2 ps = make_double2(c0 * r0.x, c0 * r0.y);
-            if (GGA) {
-#pragma unroll
-                for (int d = 1; d < 4; d++) {
-                    const double2 rd = *reinterpret_cast<const double2 *>(rb + d * VG_KC * LS + row * LS + c2);
-                    const double cd = scf[d * VG_KC + row];
-                    ps.x += cd * rd.x;
-                    ps.y += cd * rd.y;
-                }
-            }
-            *reinterpret_cast<double2 *>(psi + row * LS + c2) = ps;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // psi complete
-#pragma unroll 1
-        for (int kk = 0; kk < VG_KC / 4; kk++) {
-            const int ko = kk * 4 * LS;
-#pragma unroll
-            for (int t = 0; t < MAXT; t++) {  // straight-line; clamped duplicate tiles are discarded at the end
-                const double a = rb[ko + (offab[t] & 0xffffu)];
-                const double b = psi[ko + (offab[t] >> 16)];
-#ifndef ABL_VXC_NO_MFMA
-                acc[t] = mfma_f64(a, b, acc[t]);
-#else
-                acc[t][0] += a * b;
-#endif
-            }
-        }
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        if (t < nt) {
-            const int tl = t0 + t;
-            const int ia = (tl / T) * 16 + lk, ib = (tl % T) * 16 + lr;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#ifdef ABL_VXC_NO_ATOMIC
-                if (acc[t][r] == 12345.678)
-#endif
-                    atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
-        }
-    }
-}
-
-template <bool GGA>
-static int launch_vxc_glds(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid,
-                           int ld, const double *w, const double *vrho, const double *vgrad, int slab) {
-#define DQC_VG_CASE(N)                                                                                            \
-    case N:                                                                                                       \
-        (void)hipFuncSetAttribute((const void *)vxc_glds_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)shmem);                                                                    \
-        hipLaunchKernelGGL((vxc_glds_kernel<N, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, \
-                           slab);                                                                                 \
-        break;
-    switch (maxt) {
-        DQC_VG_CASE(2) DQC_VG_CASE(4) DQC_VG_CASE(8) DQC_VG_CASE(12) DQC_VG_CASE(16) DQC_VG_CASE(22)
-    default:
-        set_error("vxc(glds): internal dispatch error");
-        return DQC_EINVAL;
-    }
-#undef DQC_VG_CASE
-    return 0;
-}
-
+// V = (M + M^T) / 2 on the zero-padded (ld, ld) matrix
 __global__ void symmetrize_kernel(double *m, int ld) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
     if (i < ld && j < i) {
@@ -1445,30 +1290,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
     const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
-        static const char *impl_env = getenv("DQC_VXC_IMPL");  // "glds" selects the LDS-DMA variant (A/B runs); measured
-                                                               // slower than register staging on MI355X (profiles/)
-        const int ncomp_used = gga ? 4 : 1;
-        const size_t glds_lds = sizeof(double) * ((size_t)2 * ncomp_used * VG_KC * ld + (size_t)VG_KC * ld + 64);
-        const bool use_glds = ttot <= 22 * VXC_WAVES && glds_lds <= 160 * 1024 && (impl_env && impl_env[0] == 'g') &&
-                              d_aob == d_ao;
-        if (use_glds) {
-            static const int gsizes[] = {2, 4, 8, 12, 16, 22};
-            const int need = (ttot + VXC_WAVES - 1) / VXC_WAVES;
-            int maxt = 22;
-            for (int sz : gsizes)
-                if (sz >= need) { maxt = sz; break; }
-            int nslab = 256;  // one 8-wave block per CU
-            int slab = (ngrid + nslab - 1) / nslab;
-            slab = (slab + VG_KC - 1) / VG_KC * VG_KC;
-            nslab = (ngrid + slab - 1) / slab;
-            int rc = gga ? launch_vxc_glds<true>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
-                         : launch_vxc_glds<false>(maxt, dim3(nslab), glds_lds, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
-            if (rc) return rc;
-            DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
-            DQC_CHECK_LAUNCH();
-            return DQC_OK;
-        }
+        static const char *impl_env = getenv("DQC_VXC_IMPL");  // "reg": the unspecialised vxc_kernel (A/B runs)
         // one-operand forms without a gradient term (LDA Vxc, the tau terms of a meta-GGA) are symmetric matrices: the
         // wave-specialised kernel then computes the upper-triangular tiles only
         const bool ws_shape = ld <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r');
