@@ -217,3 +217,66 @@ def test_purification_restatement_on_cpu():
     ev[nocc] = ev[nocc - 1]
     _, err = projector_from_fock((q * ev) @ q.T, nocc, fused=False)
     assert float(err) > 1e-6
+
+
+def test_scf_driver_diis_on_a_model_problem_cpu():
+    """SCF_QCCalc.run (the DIIS fixed-point driver behind HF / KS, scf_qccalc.py:84-116 data flow) on a CPU model engine:
+    F(D) = H0 + g diag(D) with two doubly occupied orbitals.  The incrementally maintained Gram matrix of the error
+    vectors must give the same answer as a damped fixed-point iteration run to convergence, in far fewer steps, for the
+    restricted and the unrestricted code path (history shorter than the run, so that rows are dropped)"""
+    from dqc_amd.qccalc import SCF_QCCalc
+    from dqc_amd.utils.datastruct import SpinParam
+
+    n, g = 8, 0.6
+    gen = torch.Generator().manual_seed(11)
+    a = torch.randn((n, n), dtype=torch.float64, generator=gen)
+    h0 = (a + a.T) * 0.5 + torch.diag(torch.arange(n, dtype=torch.float64))
+
+    class Engine:
+        def __init__(self, pol):
+            self.polarized = pol
+            self.shape, self.dtype, self.device = (n, n), torch.float64, torch.device("cpu")
+            w = torch.full((2,), 1.0 if pol else 2.0, dtype=torch.float64)
+            self.orb_weight = SpinParam(u=w, d=w[:1]) if pol else w
+            self.norb = SpinParam(u=2, d=1) if pol else 2
+
+        def _f(self, dtot, dspin):
+            return h0 + g * torch.diag(torch.diagonal(dtot)) - 0.2 * g * torch.diag(torch.diagonal(dspin))
+
+        def dm2scp(self, dm):
+            if self.polarized:
+                tot = dm.u + dm.d
+                return torch.stack([self._f(tot, dm.u), self._f(tot, dm.d)])
+            return self._f(dm, 0.5 * dm)
+
+        def _occ(self, f, w):
+            _, c = torch.linalg.eigh((f + f.T) * 0.5)
+            c = c[:, :w.shape[0]]
+            return (c * w) @ c.T
+
+        def scp2dm(self, scp):
+            if self.polarized:
+                return SpinParam(u=self._occ(scp[0], self.orb_weight.u), d=self._occ(scp[1], self.orb_weight.d))
+            return self._occ(scp, self.orb_weight)
+
+        def dm2energy(self, dm):
+            return torch.zeros(())
+
+        def get_system(self):
+            return None
+
+    for pol in (False, True):
+        eng = Engine(pol)
+        qc = SCF_QCCalc(eng).run(fwd_options={"graph": False, "history": 4, "f_tol": 1e-11, "maxiter": 60})
+        assert qc.converged and qc.niter < 40
+        # reference: damped fixed point to convergence
+        z = torch.zeros((n, n), dtype=torch.float64)
+        dm = eng.scp2dm(eng.dm2scp(SpinParam(u=z, d=z) if pol else z))
+        for _ in range(4000):
+            new = eng.scp2dm(eng.dm2scp(dm))
+            dm = SpinParam(u=0.7 * dm.u + 0.3 * new.u, d=0.7 * dm.d + 0.3 * new.d) if pol else 0.7 * dm + 0.3 * new
+        got = qc.aodm()
+        if pol:
+            assert float((got.u - dm.u).abs().max()) < 1e-8 and float((got.d - dm.d).abs().max()) < 1e-8
+        else:
+            assert float((got - dm).abs().max()) < 1e-8
