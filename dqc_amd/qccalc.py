@@ -110,7 +110,7 @@ class SCF_QCCalc:
         return self._engine.get_system()
 
     def run(self, dm0="1e", eigen_options=None, fwd_options=None, bck_options=None):
-        opts = {"maxiter": 50, "f_tol": 1e-9, "history": 8}
+        opts = {"maxiter": 50, "f_tol": 1e-9, "history": 12}
         opts.update(fwd_options or {})
         eng = self._engine
         if isinstance(dm0, str):
