@@ -576,6 +576,39 @@ void orc_int2e_s4(double *out, const int *atm, int natm, const int *bas, int nba
     free(pps); free(hb); free(npp); free(ao_loc);
 }
 
+/* Listed shell quartets (test infrastructure for bases whose packed matrix does not fit the host: naphthalene /
+ * cc-pVTZ is 58 GB packed).  quartets: (nq, 4) shell indices (i, j, k, l); the spherical block
+ * [sa][sb][sc][sd] of quartet q is written row-major at out + offs[q] -- the same numbers orc_int2e_s4 scatters. */
+void orc_int2e_quartets(double *out, const long long *offs, const int *quartets, int nq, const int *atm, int natm,
+                        const int *bas, int nbas, const double *env)
+{
+    (void)natm; (void)nbas;
+    init_herm();
+#pragma omp parallel
+    {
+        size_t wsz = (size_t)MAXCART * MAXCART * MAXCART * MAXCART;
+        double *work = (double *)malloc(sizeof(double) * (2 * wsz + (size_t)MAXHERM * MAXCART * MAXCART));
+#pragma omp for schedule(dynamic)
+        for (int q = 0; q < nq; q++) {
+            Shell S[4];
+            for (int x = 0; x < 4; x++) S[x] = get_shell(quartets[4 * q + x], atm, bas, env);
+            PrimPair *pp[2];
+            double *hb[2];
+            int np[2];
+            for (int x = 0; x < 2; x++) {
+                Shell A = S[2 * x], B = S[2 * x + 1];
+                np[x] = A.nprim * B.nprim;
+                pp[x] = (PrimPair *)malloc(sizeof(PrimPair) * np[x]);
+                hb[x] = (double *)malloc(sizeof(double) * (size_t)np[x] * NCART(A.l) * NCART(B.l) * NHERM(A.l + B.l));
+                build_prim_pairs(A, B, pp[x], hb[x]);
+            }
+            eri_quartet(S[0], S[1], S[2], S[3], pp[0], np[0], pp[1], np[1], out + offs[q], work);
+            for (int x = 0; x < 2; x++) { free(pp[x]); free(hb[x]); }
+        }
+        free(work);
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* 3-centre and 2-centre 2-electron integrals (density fitting).
  * Reference call sites: dqc/df/dfmol.py:35-40 -> intor.coul2c / coul3c -> int2c2e("r12") / int3c2e("ar12")

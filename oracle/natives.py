@@ -69,6 +69,20 @@ def int2e(t):
     return fills4(int2e_s4(t), t.nao)
 
 
+def int2e_quartets(t, quartets):
+    """spherical blocks (sa, sb, sc, sd) of the listed shell quartets (nq, 4) -- for bases whose packed matrix
+    does not fit the host (the numbers are those int2e_s4 would scatter)"""
+    q = np.ascontiguousarray(quartets, dtype=np.int32).reshape(-1, 4)
+    dims = 2 * t.bas[q, 1] + 1                      # (nq, 4)
+    sizes = np.prod(dims, axis=1).astype(np.int64)
+    offs = np.zeros(len(q) + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offs[1:])
+    out = np.zeros(int(offs[-1]))
+    lib().orc_int2e_quartets(_p(out), offs.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), _p(q, ctypes.c_int),
+                             ctypes.c_int(len(q)), *_tab(t))
+    return [out[offs[i]:offs[i + 1]].reshape(tuple(int(d) for d in dims[i])) for i in range(len(q))]
+
+
 def int3c2e(tc, orb_range, aux_range):
     """(ij|k) over the concatenated tables `tc`: orbital shells [s0, s1), auxiliary shells [k0, k1) -> (nao, nao, naux)"""
     (s0, s1), (k0, k1) = orb_range, aux_range
