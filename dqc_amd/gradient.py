@@ -34,6 +34,9 @@ def nuclear_gradient(qc) -> torch.Tensor:
     h = eng.hamilton
     mol = eng.get_system()
     dev = h.device
+    if h._vext is not None:
+        raise NotImplementedError("nuclear gradients with an external potential are not implemented: the vext term "
+                                  "(grid points and basis centres moving in vext) is missing from dqc_amd.gradient")
     X = h._orthozer
     pol = eng.polarized
     dms = [qc._dm.u, qc._dm.d] if pol else [qc._dm]

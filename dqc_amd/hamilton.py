@@ -107,13 +107,22 @@ class HamiltonMI355:
         self.kinnucl_mat = self._convert2(kin + nuc)
         self.nucl_mat = self._convert2(nuc)
         if self._df is None:
+            # exact J/K keeps the 8-fold-unique 8^4 tiles resident: ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, > 288 GB
+            # near nao 740).  Fail with a message instead of an allocator OOM deep inside the fill.
+            need = int(lib.load().dqc_eri_tile_count(tab.nao)) * 4096 * 8
+            free, _total = torch.cuda.mem_get_info(dev)
+            if need > free:
+                raise lib.DqcAmdError(
+                    "the exact-J/K ERI tile store of this basis needs %.1f GB (nao = %d) but only %.1f GB of device memory "
+                    "are free: use the density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...)) "
+                    "for Kohn-Sham runs of this size" % (need / 1e9, tab.nao, free / 1e9))
             self._tiles = lib.eri_tiles(tab, dev)
             self._jkwork = lib.jk_workspace(self._nao_ao, dev)
         else:  # hcgto.py:133-135
             self._df.build()
         self.is_built = True
-        if self._vext is not None:
-            self.kinnucl_mat = self.kinnucl_mat + self.get_vext(self._vext).fullmatrix()
+        if self._vext is not None:  # hcgto.py:144-146
+            self.kinnucl_mat = self.kinnucl_mat + self.get_vext(self._vext.to(self.device)).fullmatrix()
         return self
 
     def setup_grid(self, grid, xc=None) -> None:

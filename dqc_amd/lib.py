@@ -29,10 +29,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(_LIBPATH) and os.environ.get("DQC_AMD_AUTOBUILD", "0") == "1" and "DQC_AMD_LIB" not in os.environ:
+        from . import build as _build  # fresh clone: compile the HIP sources in-tree (hipcc, ~1 min)
+        _build.build()
     if not os.path.exists(_LIBPATH):
         raise DqcAmdError(
             "libdqc_amd.so not found at %s -- build it with `python -m dqc_amd.build` "
-            "(hipcc --offload-arch=gfx950); the MI355X path has no CPU fallback" % _LIBPATH)
+            "(hipcc --offload-arch=gfx950) or set DQC_AMD_AUTOBUILD=1; the MI355X path has no CPU fallback" % _LIBPATH)
     lib = ctypes.CDLL(_LIBPATH)
     c_int, c_sz, c_vp, c_dp = ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p
     ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
@@ -81,8 +84,26 @@ def _check(rc, what):
         raise DqcAmdError("%s failed (%d): %s" % (what, rc, load().dqc_last_error().decode()))
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+class _on:
+    """Run a C entry point on the device that owns the tensors: the library launches on (and hipMallocs from) the CURRENT
+    HIP device and on the stream it is handed, so both are taken from `dev`, not from whatever device happens to be
+    current (Mol(..., device="cuda:1") while cuda:0 is current)."""
+
+    def __init__(self, dev):
+        dev = torch.device(dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.idx = idx
+        self.guard = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.idx).cuda_stream)
+
+    def __exit__(self, *a):
+        if self.guard is not None:
+            self.guard.__exit__(*a)
+        return False
 
 
 def _ptr(t):
@@ -121,14 +142,16 @@ def int1e(which, tab, device, zs=None):
     if zs is not None:
         zs = np.ascontiguousarray(zs, dtype=np.float64)
         zp = zs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    _check(load().dqc_int1e(code, _ptr(out), *tab.args(), zp, _stream()), "dqc_int1e")
+    with _on(device) as st_:
+        _check(load().dqc_int1e(code, _ptr(out), *tab.args(), zp, st_), "dqc_int1e")
     return out
 
 
 def eri_tiles(tab, device):
     ntile = load().dqc_eri_tile_count(tab.nao)
     tiles = torch.empty(ntile * 4096, dtype=torch.float64, device=device)
-    _check(load().dqc_eri_fill_tiles(_ptr(tiles), *tab.args(), _stream()), "dqc_eri_fill_tiles")
+    with _on(device) as st_:
+        _check(load().dqc_eri_fill_tiles(_ptr(tiles), *tab.args(), st_), "dqc_eri_fill_tiles")
     return tiles
 
 
@@ -141,7 +164,8 @@ def int3c2e(tab, orb_range, aux_range, device):
     (s0, s1), (k0, k1) = orb_range, aux_range
     nao, naux = _range_nao(tab, s0, s1), _range_nao(tab, k0, k1)
     out = torch.zeros((nao, nao, naux), dtype=torch.float64, device=device)
-    _check(load().dqc_int3c2e(_ptr(out), *tab.args(), s0, s1, k0, k1, _stream()), "dqc_int3c2e")
+    with _on(device) as st_:
+        _check(load().dqc_int3c2e(_ptr(out), *tab.args(), s0, s1, k0, k1, st_), "dqc_int3c2e")
     return out
 
 
@@ -150,7 +174,8 @@ def int2c2e(tab, aux_range, device):
     k0, k1 = aux_range
     naux = _range_nao(tab, k0, k1)
     out = torch.zeros((naux, naux), dtype=torch.float64, device=device)
-    _check(load().dqc_int2c2e(_ptr(out), *tab.args(), k0, k1, _stream()), "dqc_int2c2e")
+    with _on(device) as st_:
+        _check(load().dqc_int2c2e(_ptr(out), *tab.args(), k0, k1, st_), "dqc_int2c2e")
     return out
 
 
@@ -160,8 +185,9 @@ def df_coulomb(j3c, inv_j2c, dm_ao, work=None):
     if work is None:
         work = torch.empty(2 * naux, dtype=torch.float64, device=j3c.device)
     out = torch.empty((nao, nao), dtype=torch.float64, device=j3c.device)
-    _check(load().dqc_df_coulomb(_ptr(out), _ptr(j3c), _ptr(inv_j2c), _ptr(dm_ao), nao, naux, _ptr(work), _stream()),
-           "dqc_df_coulomb")
+    with _on(j3c.device) as st_:
+        _check(load().dqc_df_coulomb(_ptr(out), _ptr(j3c), _ptr(inv_j2c), _ptr(dm_ao), nao, naux, _ptr(work), st_),
+               "dqc_df_coulomb")
     return out
 
 
@@ -181,20 +207,23 @@ def int1e_grad(grad, dcart, wcart, tab, zs=None):
     if zs is not None:
         zs = np.ascontiguousarray(zs, dtype=np.float64)
         zp = zs.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    _check(load().dqc_int1e_grad(_ptr(grad), _ptr(dcart), _ptr(wcart), *tab.args(), zp, _stream()), "dqc_int1e_grad")
+    with _on(grad.device) as st_:
+        _check(load().dqc_int1e_grad(_ptr(grad), _ptr(dcart), _ptr(wcart), *tab.args(), zp, st_), "dqc_int1e_grad")
     return grad
 
 
 def eri_grad(grad, dcart, kscale, tab, jscale=1.0):
     """grad (natm, 3) += two-electron derivative term  sum (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]"""
-    _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(jscale), float(kscale), *tab.args(), _stream()), "dqc_eri_grad")
+    with _on(grad.device) as st_:
+        _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(jscale), float(kscale), *tab.args(), st_), "dqc_eri_grad")
     return grad
 
 
 def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
     """in-place TC2 purification of the zero-padded (ld, ld) matrix x_pad (spectrum in [0, 1]); state: 2 (iters + 2)"""
-    _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
-                                 _stream()), "dqc_purify_tc2")
+    with _on(x_pad.device) as st_:
+        _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
+                                     st_), "dqc_purify_tc2")
     return x_pad
 
 
@@ -202,7 +231,8 @@ def orth_factor(y, g):
     """y (n, r) = P Omega, g (r, r) = y^T y -> (n, r) orthonormal basis of range(P) (Cholesky QR in one launch)"""
     n, r = y.shape
     q = torch.empty_like(y)
-    _check(load().dqc_orth_factor(_ptr(q), _ptr(y.contiguous()), _ptr(g.contiguous()), n, r, _stream()), "dqc_orth_factor")
+    with _on(y.device) as st_:
+        _check(load().dqc_orth_factor(_ptr(q), _ptr(y.contiguous()), _ptr(g.contiguous()), n, r, st_), "dqc_orth_factor")
     return q
 
 
@@ -210,13 +240,15 @@ def df_grad(grad, dcart, ccart, tab, orb_range, aux_range):
     """grad (natm, 3) += gradient of the density-fitted Coulomb energy; dcart (ncart, ncart), ccart (ncart) over the
     Cartesian basis of the whole concatenated table"""
     (s0, s1), (k0, k1) = orb_range, aux_range
-    _check(load().dqc_df_grad(_ptr(grad), _ptr(dcart), _ptr(ccart), *tab.args(), s0, s1, k0, k1, _stream()), "dqc_df_grad")
+    with _on(grad.device) as st_:
+        _check(load().dqc_df_grad(_ptr(grad), _ptr(dcart), _ptr(ccart), *tab.args(), s0, s1, k0, k1, st_), "dqc_df_grad")
     return grad
 
 
 def eri_dense(tiles, nao):
     out = torch.empty((nao,) * 4, dtype=torch.float64, device=tiles.device)
-    _check(load().dqc_eri_tiles_to_dense(_ptr(out), _ptr(tiles), nao, _stream()), "dqc_eri_tiles_to_dense")
+    with _on(tiles.device) as st_:
+        _check(load().dqc_eri_tiles_to_dense(_ptr(out), _ptr(tiles), nao, st_), "dqc_eri_tiles_to_dense")
     return out
 
 
@@ -229,8 +261,9 @@ def jk(tiles, dm_ao, work, with_k=True):
     nao = dm_ao.shape[-1]
     J = torch.empty((nao, nao), dtype=torch.float64, device=dm_ao.device)
     K = torch.empty_like(J) if with_k else None
-    _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
-                                    _stream()), "dqc_jk_from_tiles")
+    with _on(dm_ao.device) as st_:
+        _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
+                                        st_), "dqc_jk_from_tiles")
     return J, K
 
 
@@ -241,8 +274,9 @@ def eval_gto(tab, rgrid, deriv):
     ld = padded_nao(tab.nao)
     shape = (ngrid, ld) if deriv == 0 else ({1: 4, 2: 5, 3: 10}[deriv], ngrid, ld)
     out = torch.empty(shape, dtype=torch.float64, device=rgrid.device)
-    _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), _stream()),
-           "dqc_eval_gto")
+    with _on(rgrid.device) as st_:
+        _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), st_),
+               "dqc_eval_gto")
     return out
 
 
@@ -261,8 +295,9 @@ def grid_density(ao, nao, dm_pad, gga):
     ngrid = ao.shape[-2]
     rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
     grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
-    _check(load().dqc_grid_density(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(dm_pad), _stream()),
-           "dqc_grid_density")
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_density(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(dm_pad), st_),
+               "dqc_grid_density")
     return rho, grho
 
 
@@ -289,8 +324,9 @@ def grid_density_lr(ao, nao, factor, gga):
     ngrid = ao.shape[-2]
     rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
     grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
-    _check(load().dqc_grid_density_lr(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(orb), _ptr(orbt),
-                                      orb.shape[1], _stream()), "dqc_grid_density_lr")
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_density_lr(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(orb), _ptr(orbt),
+                                          orb.shape[1], st_), "dqc_grid_density_lr")
     return rho, grho
 
 
@@ -302,8 +338,9 @@ def xc_eval(terms, rho, grho, want_e=True, want_v=True):
     e = torch.empty_like(rho) if want_e else None
     v = torch.empty_like(rho) if want_v else None
     vg = torch.empty((3, n), dtype=torch.float64, device=rho.device) if (want_v and grho is not None) else None
-    _check(load().dqc_xc_eval(_ptr(e), _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), n, ids, cfs, len(terms), _stream()),
-           "dqc_xc_eval")
+    with _on(rho.device) as st_:
+        _check(load().dqc_xc_eval(_ptr(e), _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), n, ids, cfs, len(terms), st_),
+               "dqc_xc_eval")
     return e, v, vg
 
 
@@ -318,8 +355,9 @@ def xc_eval_pol(terms, rho_u, rho_d, grho_u, grho_d, want_e=True, want_v=True):
     vd = torch.empty_like(rho_u) if want_v else None
     gu = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if (want_v and gga) else None
     gd = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if (want_v and gga) else None
-    _check(load().dqc_xc_eval_pol(_ptr(e), _ptr(vu), _ptr(vd), _ptr(gu), _ptr(gd), _ptr(rho_u), _ptr(rho_d),
-                                  _ptr(grho_u), _ptr(grho_d), n, ids, cfs, len(terms), _stream()), "dqc_xc_eval_pol")
+    with _on(rho_u.device) as st_:
+        _check(load().dqc_xc_eval_pol(_ptr(e), _ptr(vu), _ptr(vd), _ptr(gu), _ptr(gd), _ptr(rho_u), _ptr(rho_d),
+                                      _ptr(grho_u), _ptr(grho_d), n, ids, cfs, len(terms), st_), "dqc_xc_eval_pol")
     return e, (vu, vd), (gu, gd)
 
 
@@ -332,8 +370,9 @@ def xc_eval_mgga(terms, rho, grho, tau, want_e=True, want_v=True):
     v = torch.empty_like(rho) if want_v else None
     vg = torch.empty((3, n), dtype=torch.float64, device=rho.device) if want_v else None
     vt = torch.empty_like(rho) if want_v else None
-    _check(load().dqc_xc_eval_mgga(_ptr(e), _ptr(v), _ptr(vg), _ptr(vt), _ptr(rho), _ptr(grho), _ptr(tau), n, ids, cfs,
-                                   len(terms), _stream()), "dqc_xc_eval_mgga")
+    with _on(rho.device) as st_:
+        _check(load().dqc_xc_eval_mgga(_ptr(e), _ptr(v), _ptr(vg), _ptr(vt), _ptr(rho), _ptr(grho), _ptr(tau), n, ids, cfs,
+                                       len(terms), st_), "dqc_xc_eval_mgga")
     return e, v, vg, vt
 
 
@@ -341,8 +380,9 @@ def grid_density_pair(ao_a, ao_b, nao, dm_pad):
     """sum_ij a_gi D_ij b_gj on single-component (ngrid, ld) arrays"""
     ngrid = ao_a.shape[0]
     out = torch.empty(ngrid, dtype=torch.float64, device=ao_a.device)
-    _check(load().dqc_grid_density_pair(_ptr(out), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(dm_pad), _stream()),
-           "dqc_grid_density_pair")
+    with _on(ao_a.device) as st_:
+        _check(load().dqc_grid_density_pair(_ptr(out), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(dm_pad), st_),
+               "dqc_grid_density_pair")
     return out
 
 
@@ -350,8 +390,9 @@ def grid_vxc_pair(ao_a, ao_b, nao, w, v):
     """sym( sum_g w_g v_g a_ga b_gb ) -> (ld, ld)"""
     ngrid, ld = ao_a.shape
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao_a.device)
-    _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), _stream()),
-           "dqc_grid_vxc_pair")
+    with _on(ao_a.device) as st_:
+        _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), st_),
+               "dqc_grid_vxc_pair")
     return vm
 
 
@@ -361,14 +402,16 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
     ngrid = ao.shape[-2]
     ld = ao.shape[-1]
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
-    _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), _stream()),
-           "dqc_grid_vxc")
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), st_),
+               "dqc_grid_vxc")
     return vm
 
 
 def probe_stream_read(buf):
     out = torch.zeros(1, dtype=torch.float64, device=buf.device)
-    _check(load().dqc_probe_stream_read(_ptr(buf), buf.numel(), _ptr(out), _stream()), "dqc_probe_stream_read")
+    with _on(buf.device) as st_:
+        _check(load().dqc_probe_stream_read(_ptr(buf), buf.numel(), _ptr(out), st_), "dqc_probe_stream_read")
     return out
 
 
@@ -376,10 +419,12 @@ def probe_mfma_f64_tflops(device, iters=4000):
     """measured fp64 MFMA ceiling of this GPU (TFLOP/s): 2048 waves x 8 independent accumulators"""
     out = torch.empty(512 * 256, dtype=torch.float64, device=device)
     L = load()
-    _check(L.dqc_probe_mfma_f64(_ptr(out), 100, _stream()), "dqc_probe_mfma_f64")
+    with _on(device) as st_:
+        _check(L.dqc_probe_mfma_f64(_ptr(out), 100, st_), "dqc_probe_mfma_f64")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _check(L.dqc_probe_mfma_f64(_ptr(out), iters, _stream()), "dqc_probe_mfma_f64")
+    with _on(device) as st_:
+        _check(L.dqc_probe_mfma_f64(_ptr(out), iters, st_), "dqc_probe_mfma_f64")
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * 16 * 16 * 4 * 8 * iters * 2048 / (e0.elapsed_time(e1) * 1e-3) / 1e12

@@ -11,6 +11,7 @@ as in the reference.  The fixed-point solver is Pulay DIIS on the commutator [F,
 gives the same fixed point; only converged energies are compared).  Restricted closed-shell and
 unrestricted (UHF/UKS, SpinParam densities, stacked Fock matrices) are implemented."""
 import os
+import warnings
 from typing import Optional
 
 import numpy as np
@@ -30,7 +31,9 @@ class _Engine:
         self.polarized = bool(system.spin != 0) if restricted is None else (not restricted)
         if system.spin != 0 and not self.polarized:
             raise NotImplementedError("restricted open-shell is not implemented (the reference treats it via orb weights)")
-        if is_ks:
+        # hf.py:55-57 / ks.py:69-71: the grid is needed by KS always and by HF when the system carries an external
+        # potential (vext is integrated on the grid inside build())
+        if is_ks or system.requires_grid():
             system.setup_grid()
             self.hamilton.setup_grid(system.get_grid(), self.xc)
         self.hamilton.build()
@@ -92,7 +95,8 @@ class _Engine:
 
     def energy_parts(self, dm):
         h = self.hamilton
-        p = {"e_core": float(h.get_e_hcore(dm)), "e_elrep": float(h.get_e_elrep(dm)),
+        tot = SpinParam.sum(dm)  # hf.py:166-172: core and Coulomb terms see the total density
+        p = {"e_core": float(h.get_e_hcore(tot)), "e_elrep": float(h.get_e_elrep(tot)),
              "e_nuc": float(self._system.get_nuclei_energy())}
         p["e_xc" if self.is_ks else "e_exch"] = float(h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
         p["e_tot"] = sum(p.values())
@@ -104,7 +108,15 @@ class SCF_QCCalc:
         self._engine = engine
         self._has_run = False
         self.niter = 0
-        self.converged = False
+        self.converged = False   # max|[F, D]| < f_tol
+        self.stalled = False     # stopped at the round-off floor of the Fock build, above f_tol (see run())
+        self.scf_error = float("inf")  # max|[F, D]| of the returned iterate -- the achieved error, whatever the exit
+
+    @property
+    def accepted(self):
+        """the run ended at a fixed point: either `converged` (f_tol met) or `stalled` at the round-off floor with
+        `scf_error` < 100 f_tol; `scf_error` says what was achieved"""
+        return self.converged or self.stalled
 
     def get_system(self):
         return self._engine.get_system()
@@ -144,7 +156,7 @@ class SCF_QCCalc:
         perr = None
         gram = np.zeros((0, 0))
         best_err, best_it = float("inf"), 0
-        self.converged = False
+        self.converged = self.stalled = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
             if pol:
@@ -171,12 +183,17 @@ class SCF_QCCalc:
                 grow = (torch.stack(hist + [ev]) * ev).sum(-1).cpu().numpy()
             self.scf_error = emax  # max |[F, D]| of the last iterate
             # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,
-            # growing with the matrix size): accept an iterate that is within 100 f_tol and has not improved for 8 steps
+            # growing with the matrix size): an iterate that is within 100 f_tol and has not improved for 8 steps ends the
+            # loop as `stalled` -- `converged` keeps meaning f_tol, `scf_error` reports what was achieved
             if emax < best_err * 0.9:
                 best_err, best_it = emax, it
-            stalled = emax < 100 * opts["f_tol"] and it - best_it >= 8
-            if emax < opts["f_tol"] or stalled:
+            if emax < opts["f_tol"]:
                 self.converged = True
+                break
+            if emax < 100 * opts["f_tol"] and it - best_it >= 8:
+                self.stalled = True
+                warnings.warn("SCF stopped at the round-off floor of the Fock build: max|[F,D]| = %.2e (f_tol %.1e)"
+                              % (emax, opts["f_tol"]))
                 break
             fs.append(fock)
             es.append(ev)
@@ -222,6 +239,10 @@ class SCF_QCCalc:
         self._dm = dm
         self._fock = fock
         self._has_run = True
+        if not self.accepted:  # the reference's xitorch solver emits a ConvergenceWarning here
+            warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e); energy() and "
+                          "nuclear_gradient() of this object refer to a non-stationary density"
+                          % (self.niter, self.scf_error, opts["f_tol"]))
         return self
 
     def energy(self):
@@ -236,6 +257,9 @@ class SCF_QCCalc:
         """dE/dR (natm, 3) of the converged energy -- what the reference gets from torch.autograd.grad(energy, atompos)
         (test_hf.py:78-111, test_ks.py:114-137); restricted HF and LDA (dqc_amd/gradient.py)"""
         assert self._has_run
+        if not self.accepted:  # the analytic gradient has no orbital-response terms: it is only valid at a fixed point
+            warnings.warn("nuclear_gradient() of an unconverged SCF (max|[F,D]| = %.2e) is not the derivative of its energy"
+                          % self.scf_error)
         from .gradient import nuclear_gradient
         return nuclear_gradient(self)
 

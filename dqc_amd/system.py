@@ -23,6 +23,11 @@ class Mol:
         self._atomzs, self._atompos = atomzs, atompos
         self._atombases = make_atombases(atomzs, atompos, basis)
         nelecs = float(torch.sum(atomzs.to(torch.float64))) - charge
+        if abs(nelecs - round(nelecs)) > 1e-9:
+            # the reference fills fractional occupations (mol.py:421-443 via occnumber); the MI355X driver occupies whole
+            # orbitals only -- fractional nuclear charges are fine as long as `charge` makes the electron count integral
+            raise NotImplementedError("non-integer electron count %g: choose `charge` so that sum(Z) - charge is an integer"
+                                      % nelecs)
         if spin is None:
             spin = int(round(nelecs)) % 2
         if (int(round(nelecs)) - spin) % 2 != 0 or spin < 0:
@@ -31,6 +36,8 @@ class Mol:
         self._nelecs = nelecs
         self._nup = (int(round(nelecs)) + spin) // 2
         self._ndn = (int(round(nelecs)) - spin) // 2
+        if vext is not None:
+            vext = vext.to(device=self._device, dtype=dtype)
         self._efield, self._vext = efield, vext
         self._orthogonalize_basis, self._aoparamzer = orthogonalize_basis, ao_parameterizer
         self._hamilton = HamiltonMI355(self._atombases, spherical=True, efield=efield, vext=vext,
@@ -80,7 +87,8 @@ class Mol:
         return self._hamilton
 
     def requires_grid(self):
-        return True
+        """mol.py:285-286: only an external potential needs the grid outside KS"""
+        return self._vext is not None
 
     def setup_grid(self):
         if self._grid is None:

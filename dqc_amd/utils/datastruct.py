@@ -79,9 +79,16 @@ class ValGrad:
     lapl: Optional[torch.Tensor] = None
     kin: Optional[torch.Tensor] = None
 
+    # all four fields, None = absent = zero (datastruct.py:151-174 of the reference)
     def __add__(self, b):
-        return ValGrad(self.value + b.value,
-                       None if self.grad is None else self.grad + b.grad)
+        def add(x, y):
+            return y if x is None else (x if y is None else x + y)
+        return ValGrad(value=add(self.value, b.value), grad=add(self.grad, b.grad), lapl=add(self.lapl, b.lapl),
+                       kin=add(self.kin, b.kin))
 
     def __mul__(self, f):
-        return ValGrad(self.value * f, None if self.grad is None else self.grad * f)
+        def mul(x):
+            return None if x is None else x * f
+        return ValGrad(value=mul(self.value), grad=mul(self.grad), lapl=mul(self.lapl), kin=mul(self.kin))
+
+    __rmul__ = __mul__

@@ -144,9 +144,9 @@ class _SumXC(BaseXC):
         return self.a.get_edensityxc(densinfo) + self.b.get_edensityxc(densinfo)
 
     def get_vxc(self, densinfo):
+        # every ValGrad field (value, grad, lapl, kin), restricted or SpinParam (base_xc.py:147-160 AddBaseXC)
         va, vb = self.a.get_vxc(densinfo), self.b.get_vxc(densinfo)
-        g = va.grad if vb.grad is None else (vb.grad if va.grad is None else va.grad + vb.grad)
-        return ValGrad(value=va.value + vb.value, grad=g)
+        return SpinParam.apply_fcn(lambda x, y: x + y, va, vb)
 
 
 class _MulXC(BaseXC):
@@ -161,8 +161,8 @@ class _MulXC(BaseXC):
         return self.a.get_edensityxc(densinfo) * self.f
 
     def get_vxc(self, densinfo):
-        v = self.a.get_vxc(densinfo)
-        return ValGrad(value=v.value * self.f, grad=None if v.grad is None else v.grad * self.f)
+        v = self.a.get_vxc(densinfo)  # base_xc.py:175-186 MulBaseXC
+        return SpinParam.apply_fcn(lambda x: x * self.f, v)
 
 
 def get_libxc(name):

@@ -268,7 +268,7 @@ def test_scf_driver_diis_on_a_model_problem_cpu():
     for pol in (False, True):
         eng = Engine(pol)
         qc = SCF_QCCalc(eng).run(fwd_options={"graph": False, "history": 4, "f_tol": 1e-11, "maxiter": 60})
-        assert qc.converged and qc.niter < 40
+        assert qc.accepted and qc.niter < 40
         # reference: damped fixed point to convergence
         z = torch.zeros((n, n), dtype=torch.float64)
         dm = eng.scp2dm(eng.dm2scp(SpinParam(u=z, d=z) if pol else z))
@@ -280,3 +280,47 @@ def test_scf_driver_diis_on_a_model_problem_cpu():
             assert float((got.u - dm.u).abs().max()) < 1e-8 and float((got.d - dm.d).abs().max()) < 1e-8
         else:
             assert float((got - dm).abs().max()) < 1e-8
+
+
+def test_xc_combinators_keep_every_valgrad_field_and_spin():
+    """'+' and scalar '*' on non-LibXC functionals (AddBaseXC / MulBaseXC, dqc/xc/base_xc.py:120-186) combine value, grad,
+    lapl and kin -- restricted ValGrad and SpinParam alike; None means 'absent'"""
+    import torch
+    from dqc_amd.xc import BaseXC
+    from dqc_amd.utils.datastruct import ValGrad, SpinParam
+
+    class Fake(BaseXC):
+        def __init__(self, fam, scale, with_lapl):
+            self._fam, self._s, self._l = fam, scale, with_lapl
+
+        @property
+        def family(self):
+            return self._fam
+
+        def get_edensityxc(self, d):
+            return SpinParam.sum(SpinParam.apply_fcn(lambda x: x.value, d)) * self._s
+
+        def get_vxc(self, d):
+            def one(x):
+                return ValGrad(value=x.value * self._s, grad=None if self._fam < 2 else x.grad * self._s,
+                               lapl=(x.lapl * self._s) if self._l else None,
+                               kin=None if self._fam < 4 else x.kin * self._s)
+            return SpinParam.apply_fcn(one, d)
+
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: ValGrad(value=torch.rand(5, generator=g), grad=torch.rand(3, 5, generator=g),  # noqa: E731
+                         lapl=torch.rand(5, generator=g), kin=torch.rand(5, generator=g))
+    a, b = Fake(4, 2.0, True), Fake(1, 3.0, False)
+    xc = a + 0.5 * b
+    assert xc.family == 4
+    d = mk()
+    v = xc.get_vxc(d)
+    assert torch.allclose(v.value, d.value * 3.5) and torch.allclose(v.grad, d.grad * 2.0)
+    assert torch.allclose(v.lapl, d.lapl * 2.0) and torch.allclose(v.kin, d.kin * 2.0)
+    ds = SpinParam(u=mk(), d=mk())
+    vs = (b * 2.0 + a).get_vxc(ds)
+    assert torch.allclose(vs.u.value, ds.u.value * 8.0) and torch.allclose(vs.d.kin, ds.d.kin * 2.0)
+    assert torch.allclose(vs.d.grad, ds.d.grad * 2.0) and torch.allclose(vs.u.lapl, ds.u.lapl * 2.0)
+    s = ValGrad(value=d.value) + d
+    assert torch.allclose(s.value, 2 * d.value) and s.grad is d.grad and s.kin is d.kin
+    assert (3.0 * ValGrad(value=d.value)).grad is None

@@ -431,3 +431,18 @@ def test_df_restatement_vs_reference_generated_golden(golden_dir):
             assert np.allclose(J, g["probe%d_J_ao" % k], rtol=1e-10, atol=1e-11)
         with pytest.raises(RuntimeError):
             eng.h.get_exchange(dmo)
+
+
+def test_listed_shell_quartets_equal_the_packed_tensor():
+    """orc_int2e_quartets (used by the C4 GPU test, whose packed matrix would be 58 GB) returns the numbers
+    orc_int2e_s4 scatters (molintor.py:667-688 + symmetry.py:55-64), f shells included"""
+    import numpy as np
+    from oracle import basis as ob, natives as nat
+    from tests import molecules as M
+    t = ob.make_tables(M.CH4, "cc-pvtz")
+    full = nat.int2e(t)
+    q = np.random.default_rng(0).integers(0, t.nbas, (150, 4))
+    al = t.ao_loc
+    for (i, j, k, l), b in zip(q, nat.int2e_quartets(t, q)):
+        ref = full[al[i]:al[i + 1], al[j]:al[j + 1], al[k]:al[k + 1], al[l]:al[l + 1]]
+        assert np.abs(ref - b).max() < 1e-14
