@@ -1,23 +1,29 @@
 """bench.py -- SCF iterations/sec (Fock build + XC grid) per GPU, cc-pVDZ 20-atom  (BASELINE.json metric).
 
-A "step" is one pass of the hot path over this rank's batch: for every local molecule one evaluation of
+A "step" is one pass of the hot path over the batch: for every molecule one evaluation of
 engine.dm2scp(D) = J (ERI tiles -> Coulomb matrix) + density on the grid + XC functional + Vxc matrix, i.e.
 exactly the per-SCF-iteration Fock build of the reference's _KSEngine (dqc/qccalc/ks.py:176-187), float64,
 with the one-off setup (ERI fill, AO-on-grid, Becke grid) excluded and reported separately.  Inputs are the
 C5 set of SURVEY.md 8(d): vitamin C (the reference's own 20-atom cc-pVDZ benchmark molecule,
-dqc/test/benchmark.py:7-26) plus seeded 0.05-Bohr jitters, RKS PBE, grid sg3; each GPU holds
---molecules-per-gpu of them (4 x 8 GPUs = the 32-molecule batch), so per-GPU work is fixed as N grows
-(weak scaling) and there is no data-path collective -- only the closing barrier / max-reduce of the timing.
+dqc/test/benchmark.py:7-26) plus seeded 0.05-Bohr jitters, RKS PBE, grid sg3.
 
-Usage: python bench.py [--gpus N --steps K --warmup W --molecules-per-gpu M --no-cpu-baseline]
+The workload is the north-star's 32-molecule batch: at --gpus 1 all 32 molecules (141 GB resident) run on the one
+GPU; at N GPUs the SAME batch is sharded 32/N per rank (strong scaling over a fixed batch, no data-path collective --
+only the closing barrier / max-reduce of the timing).  value = molecules x steps / max-over-ranks time.
+
+Usage: python bench.py [--gpus N --steps K --warmup W --molecules M --no-cpu-baseline --profile-mode]
 For N>1 launch with torch.distributed.run (one rank per GPU, RCCL); prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
+import hashlib
 import json
+import math
 import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,16 +31,32 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 F64_MFMA_PEAK_TF = 78.6  # MI355X dense fp64 matrix peak (vendor figure; the guide lists no fp64 row)
+XC = "gga_x_pbe+gga_c_pbe"
+
+
+def source_sha16():
+    """identity of what a profile was taken with: the kernel sources and this file"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dqc_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if f.endswith("rys_tables.inc"):
+            continue
+        h.update(open(f, "rb").read())
+    return {"csrc_sha16": h.hexdigest()[:16],
+            "bench_py_sha16": hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--molecules-per-gpu", type=int, default=4)
+    ap.add_argument("--molecules", type=int, default=32, help="size of the batch (whole job; sharded over the ranks)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="a step is repeated `repeats` times so that the timed region of K steps lasts at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--profile-mode", action="store_true",
+                    help="only setup + warmup + the timed steps (for rocprofv3 passes: no extra legs, no CPU work)")
     ap.add_argument("--df", default=None, metavar="AUXBASIS",
                     help="density-fitted Coulomb operator (Mol.densityfit, e.g. --df etb) instead of the exact-J tile stream; "
                          "a different formulation, labelled as such in config")
@@ -69,24 +91,26 @@ def main():
     from dqc_amd.batch import shard_lpt, molecule_cost
     from tests import molecules as M
 
-    M_per = args.molecules_per_gpu
-    nmol = M_per * world
+    nmol = args.molecules
     costs = [molecule_cost(208, 353400)] * nmol
     mine = shard_lpt(costs, world)[rank]
+    extras = not args.profile_mode
 
     # ---------------- one-off setup (not timed as part of the metric) ----------------
     t0 = time.perf_counter()
-    engines, dms, orbs = [], [], []
+    qcs, engines, dms, orbs = [], [], [], []
     for i in mine:
         zs, pos = M.c5_molecule(i)
         mol = dqc_amd.Mol((zs, pos), basis="cc-pvdz", grid="sg3", device=dev)
         if args.df:
             mol.densityfit(method="coulomb", auxbasis=args.df)
-        eng = dqc_amd.KS(mol, xc="gga_x_pbe+gga_c_pbe")._engine
+        qc = dqc_amd.KS(mol, xc=XC)
+        eng = qc._engine
         n = eng.shape[-1]
         # density of the core-Hamiltonian guess ("1e", reference scf_qccalc.py:88-91) after one SCF update
         dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64, device=dev)))
         orb = eng.scp2orb(eng.dm2scp(dm)).contiguous()  # occupied orbitals of the second SCF iterate
+        qcs.append(qc)
         engines.append(eng)
         orbs.append(orb)
         dms.append(eng.hamilton.ao_orb2dm(orb, eng.orb_weight))
@@ -95,8 +119,10 @@ def main():
     h0 = engines[0].hamilton
     nao, ngrid, ld = h0._nao_ao, h0.rgrid.shape[0], h0._ld
 
-    def step(record=None, dense_dm=False):
-        for eng, dm, orb in zip(engines, dms, orbs):
+    def step(record=None, dense_dm=False, sel=None):
+        for k, (eng, dm, orb) in enumerate(zip(engines, dms, orbs)):
+            if sel is not None and k >= sel:
+                break
             # a fresh density-matrix tensor every step (defeats the J/K memoisation: everything is recomputed).
             # Default: D = ao_orb2dm(C_occ, n) exactly as scp2dm produces it in every SCF iteration (hf.py:105-113), so
             # the Hamiltonian knows its rank-n_occ factor; --dense-dm hands over an anonymous full matrix instead.
@@ -104,34 +130,7 @@ def main():
             if record is None:
                 eng.dm2scp(d)
             else:
-                h = eng.hamilton
-                fac = h._factor_of(d)
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
-                dmdmt = (d + d.transpose(-2, -1)) * 0.5
-                dao_n = h._unconvert_dm(dmdmt).contiguous()
-                ev[0].record()
-                if h.df is None:
-                    Jao, _ = lib.jk(h._tiles, dao_n, h._jkwork, False)   # the same calls get_elrep / get_vxc make,
-                else:                                                    # unrolled so each kernel gets its own events
-                    Jao = lib.df_coulomb(h.df.j3c, h.df._inv_j2c, dao_n, h.df._work)
-                ev[1].record()
-                J = h._convert2(Jao)
-                J = (J + J.transpose(-2, -1)) * 0.5
-                dao = lib.pad_matrix(dao_n, h._ld)
-                ev[2].record()
-                if fac is not None:
-                    rho, grho = lib.grid_density_lr(h._ao, h._nao_ao, fac[0], True)  # C5: one panel (r = 46 -> 48)
-                else:
-                    rho, grho = lib.grid_density(h._ao, h._nao_ao, dao, True)
-                ev[3].record()
-                _, v, vg = lib.xc_eval(h.xc.terms, rho, grho, want_e=False, want_v=True)
-                ev[4].record()
-                vm = lib.grid_vxc(h._ao, h._nao_ao, h.dvolume, v, vg)
-                ev[5].record()
-                mat = h._convert2(vm[:h._nao_ao, :h._nao_ao])
-                fock = eng.knvext.fullmatrix() + J + (mat + mat.transpose(-2, -1)) * 0.5
-                ev[6].record()
-                record.append(ev)
+                record.append(eng.hamilton.timed_fock_kernels(d, eng.knvext.fullmatrix()))
 
     dense = args.dense_dm
     for _ in range(args.warmup):
@@ -142,103 +141,148 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- timed region: exactly K steps ----------------
+    # a step is repeated so that the timed region is long enough for the driver's samplers (>= --min-seconds)
+    barrier()
+    t0 = time.perf_counter()
+    step(dense_dm=dense)
+    barrier()
+    est = time.perf_counter() - t0
+    repeats = max(1, int(math.ceil(args.min_seconds / max(est * args.steps, 1e-9))))
+    if world > 1:
+        tr = torch.tensor([repeats], dtype=torch.int64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        repeats = int(tr)
+
+    # ---------------- timed region: exactly K steps (each = `repeats` passes over the batch) ----------------
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(dense_dm=dense)
+        for _ in range(repeats):
+            step(dense_dm=dense)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
+    passes = args.steps * repeats
 
-    # ---------------- per-kernel HIP-event timing over K more steps (same stream as the launches) ----------------
+    # ---------------- per-kernel HIP-event timing (same stream as the launches), first 4 local molecules ----------------
     rec = []
-    for _ in range(args.steps):
-        step(rec, dense_dm=dense)
+    nsel = min(4, len(engines))
+    for _ in range(max(3, min(args.steps, 10))):
+        step(rec, dense_dm=dense, sel=nsel)
     torch.cuda.synchronize()
-    # the same K steps with an anonymous full density matrix (no factor): the rate a caller that bypasses ao_orb2dm gets
-    elapsed_other = None
-    if not dense:
-        step(dense_dm=True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(dense_dm=True)
-        barrier()
-        elapsed_other = time.perf_counter() - t0
-    norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
-    # SURVEY.md 8(d) metric (ii): the full SCF iteration F -> eigh -> ao_orb2dm -> dm2scp (scp2scp), same K steps
-    focks = [eng.dm2scp(eng.hamilton.ao_orb2dm(orb, eng.orb_weight)) for eng, orb in zip(engines, orbs)]
-    for eng, f in zip(engines, focks):
-        eng.scp2scp(f)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    names = rec[0][0]
+    ktime = {nm: sum(e[1][i].elapsed_time(e[1][i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
+
+    out_extra = {}
+    if extras:
+        K = max(3, min(args.steps, 10))
+        # the same steps with an anonymous full density matrix (no factor): the rate a caller that bypasses ao_orb2dm gets
+        if not dense:
+            step(dense_dm=True, sel=nsel)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step(dense_dm=True, sel=nsel)
+            barrier()
+            out_extra["value_full_matrix_dm_per_gpu"] = nsel * K / (time.perf_counter() - t0)
+        # SURVEY.md 8(d) metric (ii): the full SCF iteration F -> eigh -> ao_orb2dm -> dm2scp (scp2scp)
+        focks = [eng.dm2scp(eng.hamilton.ao_orb2dm(orb, eng.orb_weight)) for eng, orb in zip(engines[:nsel], orbs)]
         for eng, f in zip(engines, focks):
             eng.scp2scp(f)
-    barrier()
-    elapsed_full_eigh = time.perf_counter() - t0
-    # the same with the eigensolver-free step: purification + Fock build replayed as one hipGraph (dqc_amd/graph.py)
-    from dqc_amd.graph import GraphedSCFStep
-    steps_g = [GraphedSCFStep(eng) for eng in engines]
-    for st, f in zip(steps_g, focks):
-        st(f)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            for eng, f in zip(engines, focks):
+                eng.scp2scp(f)
+        barrier()
+        out_extra["full_scf_iterations_per_s_eigh_per_gpu"] = nsel * K / (time.perf_counter() - t0)
+        # the same with the eigensolver-free step: purification + Fock build replayed as one hipGraph (dqc_amd/graph.py)
+        from dqc_amd.graph import GraphedSCFStep
+        steps_g = [GraphedSCFStep(eng) for eng in engines[:nsel]]
         for st, f in zip(steps_g, focks):
             st(f)
-    barrier()
-    elapsed_full = time.perf_counter() - t0
-    names = ["jk_tiles", "orth_transforms", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"]
-    ktime = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec) for i, nm in enumerate(names)}  # ms / launch
-
-    # the Hartree-Fock flavour of the J/K pass (get_elrep + get_exchange, hf.py:198-199): one fused J + K launch over the same
-    # tiles, timed on molecule 0 (reported next to the kernel times; not part of `value`)
-    jk_hf_ms = None
-    if h0.df is None:
-        dao0 = h0._unconvert_dm(dms[0]).contiguous()
-        lib.jk(h0._tiles, dao0, h0._jkwork, True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            for st, f in zip(steps_g, focks):
+                st(f)
+        barrier()
+        out_extra["full_scf_iterations_per_s_per_gpu"] = nsel * K / (time.perf_counter() - t0)
+        del steps_g
+        # the Hartree-Fock flavour of the J/K pass (get_elrep + get_exchange, hf.py:198-199): one fused J + K launch
+        if h0.df is None:
+            dao0 = h0._unconvert_dm(dms[0]).contiguous()
             lib.jk(h0._tiles, dao0, h0._jkwork, True)
-        e1.record()
-        torch.cuda.synchronize()
-        jk_hf_ms = e0.elapsed_time(e1) / args.steps
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(K):
+                lib.jk(h0._tiles, dao0, h0._jkwork, True)
+            e1.record()
+            torch.cuda.synchronize()
+            out_extra["jk_with_exchange_ms"] = e0.elapsed_time(e1) / K
+            out_extra["eri_fill"] = eri_fill_stats(h0, dev)
+        # SURVEY.md 8(d) metric (iv): time to the converged energies of the batch -- KS(...).run().energy() from the core guess
+        # for every molecule of this rank, one after the other (setup above excluded, reported beside it)
+        barrier()
+        t0 = time.perf_counter()
+        es, nit, nacc = [], 0, 0
+        for qc in qcs:
+            qc.run()
+            es.append(float(qc.energy()))
+            nit += qc.niter
+            nacc += int(qc.accepted)
+        barrier()
+        scf_s = time.perf_counter() - t0
+        tab = torch.tensor([scf_s, float(nit), float(nacc), float(len(qcs)), setup_s], dtype=torch.float64, device=dev)
+        if world > 1:
+            tmx = tab.clone()
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tab, op=dist.ReduceOp.SUM)
+            tab[0], tab[4] = tmx[0], tmx[4]
+        out_extra["batch_scf"] = {"time_to_converged_energy_s": float(tab[0]), "setup_s_max_rank": float(tab[4]),
+                                  "molecules": int(tab[3]), "accepted": int(tab[2]), "scf_iterations_total": int(tab[1]),
+                                  "energy_molecule0_ha": es[0] if rank == 0 else None,
+                                  "note": "KS(mol, xc).run().energy() per molecule from the core guess, DIIS + purification "
+                                          "hipGraph step; one-off setup (ERI fill, AO on grid) listed separately"}
 
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components
+        norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
+        fused = "grid_fused" in ktime
         alg_bytes = {
             # AO read once per pass + per-point in/outs + the (n,n) matrix; see DESIGN.md
             "grid_density": 8.0 * c * ngrid * nao + 8.0 * ngrid * 4 + 8.0 * nao * nao,
             "grid_vxc": 8.0 * c * ngrid * nao + 8.0 * ngrid * 5 + 8.0 * nao * nao,
+            "grid_fused": 8.0 * c * ngrid * nao + 8.0 * ngrid * 2 + 2 * 8.0 * nao * nao,
             "jk_tiles": float(nao) ** 4 + 3 * 8.0 * nao * nao,
         }
         if args.df:  # two passes over the i >= j rows of j3c (dqc_df_coulomb) + inv_j2c
             naux = int(h0.df.j2c.shape[0])
             alg_bytes["jk_tiles"] = 2 * 4.0 * nao * (nao + 1) * naux + 8.0 * naux * naux + 2 * 8.0 * nao * nao
+        f_den = (2.0 * ngrid * ld * ld if dense else 4.0 * ngrid * ld * norb_pad) + 2.0 * c * ngrid * nao
+        f_vxc = 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao
         alg_flops = {
             # 2 G n^2 per GEMM pass (+ the row dots / Psi combination); J: 2 n^4 dense-equivalent
             # density: Phi . D (full matrix) or the two chained rank-n_occ GEMMs Phi . L, (Phi L) . L^T (factor form)
-            "grid_density": (2.0 * ngrid * ld * ld if dense else 4.0 * ngrid * ld * norb_pad) + 2.0 * c * ngrid * nao,
-            "grid_vxc": 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao,
-            "jk_tiles": 2.0 * float(nao) ** 4,
+            "grid_density": f_den, "grid_vxc": f_vxc, "grid_fused": f_den + f_vxc, "jk_tiles": 2.0 * float(nao) ** 4,
         }
+        alg_bytes = {k: v for k, v in alg_bytes.items() if k in ktime}
         # HBM bytes per launch from the committed rocprofv3 PMC pass of this same command (bench.py cannot sample
-        # counters itself); only used when the workload matches
-        traffic = {}
+        # counters itself): only reported when that pass was taken with these very sources (kernel code + this file)
+        traffic, traffic_note = {}, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tj["workload"] == {"nao": nao, "ngrid": ngrid, "xc": "gga"}:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            sha = source_sha16()
+            if tj.get("csrc_sha16") != sha["csrc_sha16"] or tj.get("bench_py_sha16") != sha["bench_py_sha16"]:
+                traffic_note = "profiles/pmc_traffic.json was taken with other sources (%s / %s): not reported" % (
+                    tj.get("csrc_sha16"), tj.get("bench_py_sha16"))
+            elif tj["workload"] == {"nao": nao, "ngrid": ngrid, "xc": "gga"}:
                 traffic = dict(tj["hbm_read_bytes_per_launch"])
-                if not dense and "grid_density_lr" in traffic:  # the factor-form density kernel was profiled separately
-                    traffic["grid_density"] = traffic["grid_density_lr"]
-        except Exception:
-            pass
+        except Exception as e:  # noqa: BLE001
+            traffic_note = "no usable profiles/pmc_traffic.json (%s)" % type(e).__name__
         mfma_ceiling = lib.probe_mfma_f64_tflops(dev)
         hbm_ceiling = lib.probe_hbm_read_gbs(dev)
 
@@ -250,80 +294,188 @@ def main():
                 return {"bound": "mfma", "kernel": k, "achieved": tfs, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": tfs / F64_MFMA_PEAK_TF, "traffic": traffic.get(k), "algorithmic_flops_per_launch": alg_flops[k],
                         "algorithmic_bytes_per_launch": alg_bytes[k], "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
-                        "measured_mfma_f64_ceiling_tflops": mfma_ceiling, "frac_of_measured_ceiling": tfs / mfma_ceiling}
+                        "measured_mfma_f64_ceiling_tflops": mfma_ceiling, "frac_of_measured_ceiling": tfs / mfma_ceiling,
+                        "avg_launch_ms": ktime[k]}
             return {"bound": "hbm", "kernel": k, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(k), "algorithmic_bytes_per_launch": alg_bytes[k],
-                    "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": gbs / hbm_ceiling}
+                    "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": gbs / hbm_ceiling,
+                    "avg_launch_ms": ktime[k]}
 
         dom = max(alg_bytes, key=lambda k: ktime[k])
         out = {
             "metric": "SCF iterations/sec (Fock build + XC grid) per GPU, cc-pVDZ 20-atom",
-            "value": nmol * args.steps / elapsed,
+            "value": nmol * passes / elapsed,
             "unit": "SCF Fock-build iterations/s (whole job)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timed_region_s": elapsed,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C5: %d x 20-atom vitamin-C-like organics (nao 208, 353400 grid pts) RKS PBE/cc-pVDZ sg3, "
-                                   "%d per GPU" % (nmol, M_per),
+            "config": {"workload": "C5: batch of %d x 20-atom vitamin-C-like organics (nao 208, 353400 grid pts) RKS PBE/cc-pVDZ "
+                                   "sg3, %d per GPU; a step = %d pass(es) over the batch" % (nmol, len(mine), repeats),
                        "coulomb": ("density-fitted J, auxbasis %s (naux %d)" % (args.df, int(h0.df.j2c.shape[0]))) if args.df
                                   else "exact J from stored ERI tiles",
-                       "molecules_per_gpu": M_per, "global_batch": nmol, "nao": nao, "ngrid": ngrid,
+                       "molecules_per_gpu": len(mine), "global_batch": nmol, "nao": nao, "ngrid": ngrid,
+                       "grid_pass": "fused density+XC+Vxc kernel" if fused else "density, XC, Vxc kernels",
                        "parallelism": "molecule-sharded x%d, no data-path collective" % world},
-            "per_gpu_value": M_per * args.steps / elapsed,
+            "per_gpu_value": nmol * passes / elapsed / world,
             "density_matrix_input": "full matrix (no factor)" if dense else
                                     "ao_orb2dm(C_occ, n): rank-%d factor known to the Hamiltonian" % norb_pad,
-            "value_full_matrix_dm": None if elapsed_other is None else nmol * args.steps / elapsed_other,
-            # SURVEY 8(d) metric (ii), rank 0's clock: F -> D -> F'.  "purify": GEMM-only projector + Fock build in one
-            # hipGraph; "eigh": torch.linalg.eigh (rocSOLVER) + ao_orb2dm + eager Fock build
-            "full_scf_iterations_per_s": nmol * args.steps / elapsed_full,
-            "full_scf_iterations_per_s_eigh": nmol * args.steps / elapsed_full_eigh,
             "setup_s_per_rank": setup_s,
             "kernel_ms_per_molecule": ktime,
-            "jk_with_exchange_ms": jk_hf_ms,
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
+            "traffic_note": traffic_note,
+            "sources": source_sha16(),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+        out.update(out_extra)
+        if world == 1 and extras and not args.no_cpu_baseline:
+            out["cpu_baseline"], par = cpu_baseline(args.cpu_steps, engines[0], dms[0])
+            out.update(par)
+            out["cpu_baseline_reference_shape"] = cpu_baseline_dense_benzene(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(nsteps):
-    """the oracle (CPU restatement of DQC's algorithm, kind = "port") timed on this box's host cores on a bounded
-    sample of the same workload: molecule 0 of the C5 set, `nsteps` dm2scp evaluations after one warm-up"""
-    from oracle import basis as ob, hamilton as oh, natives as nat
-    from tests import molecules as M
-    t = ob.make_tables(M.c5_molecule(0), "cc-pvdz")
-    t0 = time.perf_counter()
-    eng = oh.Engine(t, xc="gga_x_pbe+gga_c_pbe", grid="sg3", eri_mode="s4")
-    setup = time.perf_counter() - t0
-    n = eng.h.nao
-    dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64)))
-    # torch's intra-op pool collapses when oversubscribed (256 threads: 70 s per call on the 64-core EPYC box),
-    # so the thread count is calibrated: one call each at 16/32/64 threads (capped by the core count), best kept
+def eri_fill_stats(h, dev):
+    """the one-off ERI fill of one C5 molecule, warm (second call), into a scratch tile store"""
+    from dqc_amd import lib
+    tab = h._tab
+    lib.eri_tiles(tab, dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    tiles = lib.eri_tiles(tab, dev)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    nbytes = tiles.numel() * 8
+    del tiles
+    # shell-pair classes i >= j; quartets (ij|kl) with ij >= kl: what the kernel evaluates (8-fold symmetry)
+    ls, npr = tab.bas[:, 1].astype(np.int64), tab.bas[:, 2].astype(np.int64)
+    ii, jj = np.tril_indices(tab.nbas)
+    pl = np.stack([ls[ii], ls[jj]], 1)
+    pp = npr[ii] * npr[jj]
+    npair = len(ii)
+    nquart = npair * (npair + 1) // 2
+    nprimq = (float(pp.sum()) ** 2 + float((pp.astype(np.float64) ** 2).sum())) / 2
+    # flop MODEL (not a counter): per primitive quartet and Rys root ~ 3 (la+lb+1)(lc+ld+1) * 8 for the 2D recurrences,
+    # + 3 flops per Cartesian integral and root for the assembly; roots = L/2 + 1
+    ncart = lambda l: (l + 1) * (l + 2) // 2  # noqa: E731
+    lb_, cb_ = pl.sum(1), ncart(pl[:, 0]) * ncart(pl[:, 1])
+    flops = 0.0
+    # class-pair sums without forming the npair^2 table: group pairs by (la, lb)
+    keys = {}
+    for k in range(npair):
+        key = (int(pl[k, 0]), int(pl[k, 1]))
+        keys[key] = keys.get(key, 0.0) + float(pp[k])
+    items = list(keys.items())
+    for (a, wa) in items:
+        for (b, wb) in items:
+            L = sum(a) + sum(b)
+            roots = L // 2 + 1
+            per = roots * (24.0 * (sum(a) + 1) * (sum(b) + 1) + 3.0 * ncart(a[0]) * ncart(a[1]) * ncart(b[0]) * ncart(b[1]))
+            flops += 0.5 * wa * wb * per
+    return {"ms": ms, "shell_quartets": int(nquart), "shell_quartets_per_s": nquart / (ms * 1e-3),
+            "primitive_quartets_per_s": nprimq / (ms * 1e-3), "tile_bytes": nbytes,
+            "tile_write_gbs": nbytes / (ms * 1e-3) / 1e9, "fp64_gflops_model": flops / (ms * 1e-3) / 1e9,
+            "flop_model": "per primitive quartet and Rys root: 24 (la+lb+1)(lc+ld+1) for the 2D recurrences + 3 per Cartesian "
+                          "integral; an estimate, not a hardware counter"}
+
+
+def _calibrated_threads(fn):
+    """torch's intra-op pool collapses when oversubscribed (256 threads: 70 s per call on the 64-core EPYC box), so the
+    thread count is calibrated: one call each at 16/32/64 threads (capped by the core count), best kept"""
     best = None
     for nt in sorted({min(c, os.cpu_count() or 1) for c in (16, 32, 64)}):
         torch.set_num_threads(nt)
-        eng.dm2scp(dm)
+        fn()
         t0 = time.perf_counter()
-        eng.dm2scp(dm)
+        fn()
         dt1 = time.perf_counter() - t0
         if best is None or dt1 < best[0]:
             best = (dt1, nt)
     torch.set_num_threads(best[1])
+    return best[1]
+
+
+def cpu_baseline(nsteps, gpu_eng, gpu_dm):
+    """the oracle (CPU restatement of DQC's algorithm, kind = "port") timed on this box's host cores on a bounded
+    sample of the same workload: molecule 0 of the C5 set, `nsteps` dm2scp evaluations after one warm-up.  The Fock
+    matrix and energy the oracle produces for the GPU's own density of that molecule are compared with the GPU's
+    (parity_* fields): the checker checks, it is never the thing measured as the product."""
+    from oracle import basis as ob, hamilton as oh
+    from tests import molecules as M
+    t = ob.make_tables(M.c5_molecule(0), "cc-pvdz")
+    t0 = time.perf_counter()
+    eng = oh.Engine(t, xc=XC, grid="sg3", eri_mode="s4")
+    setup = time.perf_counter() - t0
+    # the GPU's density of molecule 0, carried over through the AO basis: D_ao = X_g D X_g^T = X_o D_o X_o^T
+    hg = gpu_eng.hamilton
+    S = hg._ovlp_ao.cpu()
+    Dao = (hg._orthozer @ gpu_dm @ hg._orthozer.T).cpu()
+    Xo = eng.h.X
+    Xinv = Xo.T @ S
+    dm = Xinv @ Dao @ Xinv.T
+    dm = (dm + dm.T) * 0.5
+    nt = _calibrated_threads(lambda: eng.dm2scp(dm))
     t0 = time.perf_counter()
     for _ in range(nsteps):
-        eng.dm2scp(dm)
+        F_o = eng.dm2scp(dm)
     dt = time.perf_counter() - t0
-    return {"value": nsteps / dt, "unit": "SCF Fock-build iterations/s", "cores": torch.get_num_threads(),
-            "kind": "port", "setup_s": setup,
-            "sample": "molecule 0 of the C5 set, %d dm2scp calls after 1 warm-up; J from the packed-s4 ERI matrix "
-                      "(3.8 GB) instead of the reference's dense 15 GB einsum (faster than the reference shape), "
-                      "density/Vxc passes chunked at 16 MiB like the reference" % nsteps}
+    SXo = S @ Xo
+    F_cpu = SXo @ F_o @ SXo.T
+    SXg = hg._ovlp_ao @ hg._orthozer
+    F_gpu = (SXg @ gpu_eng.dm2scp(gpu_dm) @ SXg.T).cpu()
+    e_cpu, e_gpu = float(eng.dm2energy(dm)), float(gpu_eng.dm2energy(gpu_dm))
+    par = {"parity_max_abs_fock": float((F_gpu - F_cpu).abs().max()), "parity_energy_diff_ha": e_gpu - e_cpu,
+           "parity_note": "C5 molecule 0: Fock matrix (AO representation S X F X^T S) and total energy of the GPU's own "
+                          "second-iterate density, GPU dm2scp / dm2energy vs the oracle engine timed as cpu_baseline"}
+    return ({"value": nsteps / dt, "unit": "SCF Fock-build iterations/s", "cores": nt,
+             "kind": "port", "setup_s": setup,
+             "sample": "molecule 0 of the C5 set, %d dm2scp calls after 1 warm-up; J from the packed-s4 ERI matrix "
+                       "(3.8 GB) instead of the reference's dense 15 GB einsum (faster than the reference shape), "
+                       "density/Vxc passes chunked at 16 MiB like the reference" % nsteps}, par)
+
+
+def cpu_baseline_dense_benzene(dev):
+    """second CPU leg in the reference's EXACT shape -- dense (nao,)^4 ERI tensor and the einsum of hcgto.py:204-214 -- on
+    the largest BASELINE config whose dense tensor fits comfortably: benzene RKS PBE/cc-pVDZ sg3 (nao 114, 1.35 GB), with
+    the GPU rate on that same molecule beside it"""
+    import dqc_amd
+    from oracle import basis as ob, hamilton as oh
+    from tests import molecules as M
+    mol = M.benzene()
+    t = ob.make_tables(mol, "cc-pvdz")
+    eng = oh.Engine(t, xc=XC, grid="sg3", eri_mode="dense")
+    n = eng.h.nao
+    dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64)))
+    nt = _calibrated_threads(lambda: eng.dm2scp(dm))
+    t0 = time.perf_counter()
+    k = 0
+    while k < 3 or time.perf_counter() - t0 < 5.0:
+        eng.dm2scp(dm)
+        k += 1
+    cpu_rate = k / (time.perf_counter() - t0)
+    g = dqc_amd.KS(dqc_amd.Mol(mol, basis="cc-pvdz", grid="sg3", device=dev), xc=XC)._engine
+    gn = g.shape[-1]
+    gd = g.scp2dm(g.dm2scp(torch.zeros((gn, gn), dtype=torch.float64, device=dev)))
+    orb = g.scp2orb(g.dm2scp(gd)).contiguous()
+    for _ in range(3):
+        g.dm2scp(g.hamilton.ao_orb2dm(orb, g.orb_weight))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        g.dm2scp(g.hamilton.ao_orb2dm(orb, g.orb_weight))
+    torch.cuda.synchronize()
+    gpu_rate = 200 / (time.perf_counter() - t0)
+    return {"value": cpu_rate, "unit": "SCF Fock-build iterations/s", "cores": nt, "kind": "port",
+            "sample": "benzene RKS PBE/cc-pVDZ sg3 (nao %d, %d grid points), %d dm2scp calls: dense (nao,)^4 ERI tensor + "
+                      "torch.einsum exactly as the reference's get_elrep (hcgto.py:204-214), 16 MiB grid chunks" % (
+                          n, eng.h.basis.shape[0], k),
+            "gpu_value_same_workload": gpu_rate}
 
 
 if __name__ == "__main__":

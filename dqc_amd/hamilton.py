@@ -397,6 +397,46 @@ class HamiltonMI355:
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
 
+    def timed_fock_kernels(self, dm, core):
+        """measurement aid (bench.py): the restricted KS Fock build `core + get_elrep_plus_vxc(dm)` unrolled -- the same
+        library calls in the same order -- with a HIP event on the launch stream between its kernels.
+        Returns (names, events) with len(events) == len(names) + 1."""
+        assert self.xc is not None and dm.dim() == 2 and self.xcfamily == 2
+        n = self._nao_ao
+        fac = self._factor_of(dm)
+        dao_n = self._unconvert_dm((dm + dm.transpose(-2, -1)) * 0.5).contiguous()
+        ev = []
+
+        def mark():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            ev.append(e)
+
+        mark()
+        if self._df is None:
+            jao, _ = lib.jk(self._tiles, dao_n, self._jkwork, False)
+        else:
+            jao = lib.df_coulomb(self._df.j3c, self._df._inv_j2c, dao_n, self._df._work)
+        mark()
+        dao = lib.pad_matrix(dao_n, self._ld)
+        mark()
+        names = ["jk_tiles", "orth_transforms"]
+        if fac is not None and len(fac) == 1:
+            rho, grho = lib.grid_density_lr(self._ao, n, fac[0], True)
+        else:
+            rho, grho = lib.grid_density(self._ao, n, dao, True)
+        mark()
+        _, v, vg = lib.xc_eval(self.xc.terms, rho, grho, want_e=False, want_v=True)
+        mark()
+        vm = lib.grid_vxc(self._ao, n, self.dvolume, v, vg)
+        mark()
+        names += ["grid_density", "xc_eval", "grid_vxc"]
+        mat = self._convert2(jao + vm[:n, :n])
+        fock = core + (mat + mat.transpose(-2, -1)) * 0.5  # noqa: F841
+        mark()
+        names.append("fock_assemble")
+        return names, ev
+
     def getparamnames(self, methodname: str, prefix: str = "") -> List[str]:
         table = {
             "get_kinnucl": ["kinnucl_mat"], "get_nuclattr": ["nucl_mat"], "get_overlap": ["olp_mat"],
