@@ -1121,6 +1121,186 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Vxc, ONE block per slab (bases with 10 <= T <= 13 tile rows, i.e. 145 <= nao <= 208: the 20-atom cc-pVDZ molecules).
+// vxc_ws_kernel needs two blocks per slab there (T^2 = 169 tiles > 8 waves x 11), so every chunk travels L2 -> CU twice
+// and the chunk period is set by the producers' loads (2.7 us), not by the MFMAs (2.5 us).  Here the block owns the
+// UPPER-TRIANGULAR tiles only (T (T + 1) / 2 = 91 <= 8 x 12) and accumulates the symmetrised matrix directly:
+//     acc_ij = Phi_i^T Psi_j + Psi_i^T Phi_j = M_ij + (M_ji)^T = 2 V_ij         (two MFMAs per tile and k-group; GGA)
+//     acc_ij = Phi_i^T Psi_j                 = M_ij = V_ij                      (one operand, no gradient term: M symmetric)
+// -- 182 instead of 169 MFMAs per k-group (+8 %), but half the L2 -> CU traffic, half the producers (4 waves: one per
+// SIMD, 12 waves per block => 168 VGPRs per wave for the 12 accumulator tiles) and one combine window per 2 x the MFMA
+// work.  Chunk layout, buffer loads, the two-barrier combine window and the hand-pipelined fragment reads are those of
+// vxc_ws_kernel; the fragment of tile row i is  Phi: pi[t] + kk GS 8,  Psi: pi[t] + (XS + kk GS) 8  (immediates).
+// ---------------------------------------------------------------------------------------------
+constexpr int VWU_PROD = 256, VWU_NT = 512 + VWU_PROD;
+
+template <int MAXT, int NTL, bool TWO, int D = 2>
+__device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsigned (&pj)[MAXT], v4d (&acc)[MAXT]) {
+    // NTL <= MAXT: tiles actually looped over (waves that own one tile fewer skip the dummy MFMAs)
+    constexpr int H = TWO ? 2 : 1, NS = 4 * NTL * H;
+    double fa[D + 1], fb[D + 1];
+    auto rd = [&](int s) {
+        const int kk = s / (NTL * H), t = (s % (NTL * H)) / H, h = s % H;
+        // h = 0: A = Phi_i, B = Psi_j;   h = 1: A = Psi_i, B = Phi_j
+        fa[s % (D + 1)] = *(lds_cdouble_t *)(pi[t] + (kk * VWS_GS + (h ? VWS_XS : 0)) * 8);
+        fb[s % (D + 1)] = *(lds_cdouble_t *)(pj[t] + (kk * VWS_GS + (h ? 0 : VWS_XS)) * 8);
+    };
+#pragma unroll
+    for (int s = 0; s < D && s < NS; s++) rd(s);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {  // tiles past the wave's count are clamped duplicates, discarded later
+        if (s + D < NS) rd(s + D);
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = (s % (NTL * H)) / H;
+        acc[t] = mfma_f64(fa[s % (D + 1)], fb[s % (D + 1)], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int MAXT, int NLP, bool GGA>
+__global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
+                                                           int ld, const double *__restrict__ w, const double *__restrict__ vrho,
+                                                           const double *__restrict__ vgrad, int slab) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int KCH = 16;
+    const int LS = ld;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t cs = (size_t)ngrid * ld;
+    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int nchunk = (ge - gs + KCH - 1) / KCH;
+
+    if (wave >= VXC_WAVES) {
+        // ------------------------------------------------------------------ producers (see vxc_ws_kernel)
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int TPR = VWU_PROD / KCH;  // 16 threads per chunk row
+        const int pt = tid - 512;
+        const int prow = pt / TPR, pcol = pt % TPR;
+        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+        unsigned wlds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds +
+                        8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);
+        typedef double vd2 __attribute__((ext_vector_type(2)));
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        constexpr int BUF_FLAGS = 0x00020000;
+        v4u raw[NLP][GGA ? 4 : 1];
+        double cf[GGA ? 4 : 1], wg = 0.0;
+        auto as_d = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+        auto prefetch = [&](int c) {
+            const int g0 = gs + c * KCH;
+            const int rows = ge - g0;
+            auto rsrc = [&](const double *base, size_t bytes) {
+                return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, BUF_FLAGS);
+            };
+            const v2u xw = __builtin_amdgcn_raw_buffer_load_b64(rsrc(w + g0, (size_t)rows * 8), prow * 8, 0, 0);
+            wg = as_d(xw[0], xw[1]);
+            const v2u xr = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vrho + g0, (size_t)rows * 8), prow * 8, 0, 0);
+            cf[0] = as_d(xr[0], xr[1]);
+            if (GGA) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const v2u xg = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vgrad + (size_t)d * ngrid + g0, (size_t)rows * 8), prow * 8, 0, 0);
+                    cf[d + 1] = as_d(xg[0], xg[1]);
+                }
+            }
+            const size_t nb = (size_t)rows * ld * 8;
+#pragma unroll
+            for (int d = 0; d < (GGA ? 4 : 1); d++) {
+                const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
+#pragma unroll
+                for (int i = 0; i < NLP; i++)
+                    if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
+            }
+        };
+        auto stage = [&]() {
+            // GGA: acc = 2 V, so Psi = w (vrho Phi + sum_d 2 vgrad_d dPhi_d) as in vxc_ws_kernel and the epilogue halves
+            cf[0] *= wg;
+            if (GGA) {
+#pragma unroll
+                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * wg;
+            }
+#pragma unroll
+            for (int i = 0; i < NLP; i++) {
+                if ((pcol + i * TPR) * 2 < ld) {
+                    vd2 ps = {cf[0] * as_d(raw[i][0][0], raw[i][0][1]), cf[0] * as_d(raw[i][0][2], raw[i][0][3])};
+                    if (GGA) {
+#pragma unroll
+                        for (int d = 1; d < 4; d++) {
+                            ps.x += cf[d] * as_d(raw[i][d][0], raw[i][d][1]);
+                            ps.y += cf[d] * as_d(raw[i][d][2], raw[i][d][3]);
+                        }
+                    }
+                    *(__attribute__((address_space(3))) v4u *)(wlds + i * TPR * 16) = raw[i][0];
+                    *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16 + VWS_XS * 8) = ps;
+                }
+            }
+        };
+        prefetch(0);
+        stage();
+        if (nchunk > 1) prefetch(1);
+        __syncthreads();
+        for (int c = 0; c < nchunk; c++) {
+            wlds += (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // buffer (c + 1) & 1
+            __syncthreads();  // the consumers have finished chunk c - 1 and wait: the vector ALUs are free for the combine
+            if (c + 1 < nchunk) stage();
+            __syncthreads();  // the consumers start the MFMAs of chunk c
+            if (c + 2 < nchunk) prefetch(c + 2);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: upper-triangular tiles
+    const int lr = lane & 15, lk = lane >> 4;
+    const int T = ld >> 4, ttot = T * (T + 1) / 2;
+    auto tile_ij = [&](int u, int &ti, int &tj) {
+        int i = 0, rem = u;
+        while (rem >= T - i) { rem -= T - i; i++; }  // row i of the upper triangle holds T - i tiles
+        ti = i;
+        tj = i + rem;
+    };
+    // balanced deal: the first ttot % 8 waves own one tile more.  Waves w and w + 4 share a SIMD (a block's waves go to the
+    // SIMDs cyclically), so for T = 13 the SIMDs carry 23, 23, 23, 22 tiles and no dummy MFMA is issued
+    const int tbase = ttot / VXC_WAVES, trem = ttot % VXC_WAVES;
+    const int nt = tbase + (wave < trem ? 1 : 0);
+    const int t0 = wave * tbase + min(wave, trem);
+    v4d acc[MAXT];
+    unsigned pi[MAXT], pj[MAXT];  // LDS byte addresses of the row / column fragments in the Phi part (k-group 0, current buffer)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        int ti, tj;
+        tile_ij(min(t0 + min(t, max(nt - 1, 0)), ttot - 1), ti, tj);
+        pi[t] = lds0 + 8u * (unsigned)(lk * LS + ti * 16 + lr);
+        pj[t] = lds0 + 8u * (unsigned)(lk * LS + tj * 16 + lr);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
+        __syncthreads();  // ... and closes
+        if (nt == MAXT) wsu_chunk<MAXT, MAXT, GGA>(pi, pj, acc);
+        else wsu_chunk<MAXT, MAXT - 1, GGA>(pi, pj, acc);
+        const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) { pi[t] += delta; pj[t] += delta; }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (t < nt) {
+            int ti, tj;
+            tile_ij(t0 + t, ti, tj);
+            const int ia = ti * 16 + lk, ib = tj * 16 + lr;
+            // symmetrize_kernel forms (m_ij + m_ji) / 2 over the whole matrix and the lower tiles stay zero:
+            //   GGA: acc = 2 V -> off-diagonal tiles store acc (-> acc / 2 = V), diagonal tiles acc / 2 (already symmetric)
+            //   one operand: acc = V -> off-diagonal tiles 2 acc, diagonal tiles acc
+            const double sc = (GGA ? 1.0 : 2.0) * (ti != tj ? 1.0 : 0.5);
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
+        }
+    }
+}
+
 // V = (M + M^T) / 2 on the zero-padded (ld, ld) matrix
 __global__ void symmetrize_kernel(double *m, int ld) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
@@ -1166,6 +1346,22 @@ static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hi
 #undef DQC_VWS_CASE
     set_error("vxc_ws: internal dispatch error");
     return DQC_EINVAL;
+}
+
+template <int MAXT, int NLP, bool GGA>
+static void launch_vxc_wsu_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
+                                const double *w, const double *vrho, const double *vgrad, int slab) {
+    auto kern = vxc_wsu_kernel<MAXT, NLP, GGA>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
+}
+
+template <bool GGA>
+static int launch_vxc_wsu(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
+                          const double *w, const double *vrho, const double *vgrad, int slab) {
+    if (maxt <= 9) launch_vxc_wsu_inst<9, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
+    else launch_vxc_wsu_inst<12, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
+    return 0;
 }
 
 template <int MAXT, int NLA, int NLB, bool GGA>
@@ -1315,6 +1511,24 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             dim3 grid2(nslab * nsplit2);
             int rc = gga ? launch_vxc_ws2<true>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob)
                          : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob);
+            if (rc) return rc;
+            DQC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            DQC_CHECK_LAUNCH();
+            return DQC_OK;
+        }
+        // 145 <= nao <= 208 (10 <= T <= 13): one block per slab over the upper-triangular tiles (vxc_wsu_kernel) instead of two
+        // blocks that each stage the whole slab.  One operand, symmetric result; DQC_VXC_IMPL=split keeps the two-block form.
+        if (ws_shape && T >= 10 && T * (T + 1) / 2 <= 12 * VXC_WAVES && d_aob == d_ao && !(impl_env && impl_env[0] == 's')) {
+            int ncu = 256;
+            int nslab = ncu;
+            int slab = (ngrid + nslab - 1) / nslab;
+            slab = (slab + 15) / 16 * 16;
+            nslab = (ngrid + slab - 1) / slab;
+            const int need = (T * (T + 1) / 2 + VXC_WAVES - 1) / VXC_WAVES;
+            const size_t shmem_u = sizeof(double) * 2 * VWS_BUF;
+            int rc = gga ? launch_vxc_wsu<true>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
+                         : launch_vxc_wsu<false>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
             hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
