@@ -223,6 +223,22 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out_extra["jk_with_exchange_ms"] = e0.elapsed_time(e1) / K
+            # unrestricted Hartree-Fock trio J[D_u + D_d], K[2 D_u], K[2 D_d] in ONE tile pass (dqc_jk_from_tiles_multi)
+            du = torch.stack([dao0 * 0.6, dao0 * 0.4])
+            lib.jk_multi(h0._tiles, dao0.unsqueeze(0), du)
+            e0.record()
+            for _ in range(K):
+                lib.jk_multi(h0._tiles, dao0.unsqueeze(0), du)
+            e1.record()
+            torch.cuda.synchronize()
+            out_extra["jk_unrestricted_j_2k_one_pass_ms"] = e0.elapsed_time(e1) / K
+            lib.jk_multi(h0._tiles, dao0.unsqueeze(0), None)
+            e0.record()
+            for _ in range(K):
+                lib.jk_multi(h0._tiles, dao0.unsqueeze(0), None)
+            e1.record()
+            torch.cuda.synchronize()
+            out_extra["jk_multi_j_only_ms"] = e0.elapsed_time(e1) / K
             out_extra["eri_fill"] = eri_fill_stats(h0, dev)
         # SURVEY.md 8(d) metric (iv): time to the converged energies of the batch -- KS(...).run().energy() from the core guess
         # for every molecule of this rank, one after the other (setup above excluded, reported beside it)

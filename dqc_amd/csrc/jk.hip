@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
             // (with the straightforward split every read had 3- to 4-way conflicts and the K part cost as much as the stream)
             const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;
             double k1 = 0, k2 = 0, k3 = 0, k4 = 0;
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
+#pragma unroll 1
+            for (int u = 0; u < 2; u++) {  // rolled: fully unrolled, the hoisted LDS reads spill (128-VGPR budget)
                 const int q = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
 #pragma unroll
                 for (int a = 0; a < 8; a++) {
@@ -167,6 +167,184 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
             }
         }
         __syncthreads();  // s_col / s_g reuse
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several right-hand sides in ONE pass over the tiles.  The reference's callers ask for J and K of different density
+// matrices back to back -- unrestricted Hartree-Fock: J[D_u + D_d], K[2 D_u], K[2 D_d] (hcgto.py:238-241, hf.py:93-103,
+// 198-199); batched density matrices (base_hamilton.py:92-93) -- and each call streamed the whole tile store again.
+// Here a tile is loaded once (non-temporal: it is not read again this pass), its 4 x 4 patch stays in registers / LDS, and
+//   * the Coulomb part loops over `nj` densities (row / column sums per density, registers reused),
+//   * the exchange part contracts NK (1 or 2) densities at once: the tile reads from LDS are shared between them.
+// work layout (n2 = npad^2 doubles each):  Dj[nj] | Dk[NK] | Jacc[nj] | Kacc[NK].
+// ---------------------------------------------------------------------------------------------
+template <int NK>
+__global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ tiles, double *__restrict__ work,
+                                                                   int npad, long long ntiles, int nj) {
+    constexpr int LDT = 68;
+    constexpr int NKD = NK ? NK : 1;
+    __shared__ double s_col[2][4][64];
+    __shared__ __attribute__((aligned(16))) double s_g[NK ? 64 * LDT : 2];
+    __shared__ double s_d[NKD][4][72];
+    const size_t n2 = (size_t)npad * npad;
+    const double *Dj = work, *Dk = work + (size_t)nj * n2;
+    double *Jacc = work + (size_t)(nj + NK) * n2, *Kacc = Jacc + (size_t)nj * n2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+
+    // the NEXT tile's 8 loads are issued before this tile's work (scalar register set: arrays that live across the
+    // back-edge end up in scratch), so a block overlaps its own HBM latency with its LDS / atomic phase
+    double2 na0, na1, na2, na3, nb0, nb1, nb2, nb3;
+#define JKM_LOAD(TT)                                                                     \
+    {                                                                                    \
+        const double *tq_ = tiles + (size_t)(TT) * DQC_TILE_SZ + r0 * 64 + c0;             \
+        na0 = *reinterpret_cast<const double2 *>(tq_);       nb0 = *reinterpret_cast<const double2 *>(tq_ + 2);       \
+        na1 = *reinterpret_cast<const double2 *>(tq_ + 64);  nb1 = *reinterpret_cast<const double2 *>(tq_ + 66);      \
+        na2 = *reinterpret_cast<const double2 *>(tq_ + 128); nb2 = *reinterpret_cast<const double2 *>(tq_ + 130);     \
+        na3 = *reinterpret_cast<const double2 *>(tq_ + 192); nb3 = *reinterpret_cast<const double2 *>(tq_ + 194);     \
+    }
+    if ((long long)blockIdx.x < ntiles) JKM_LOAD(blockIdx.x)
+    for (long long T = blockIdx.x; T < ntiles; T += gridDim.x) {
+        int IJ, KL, I, J, K, L;
+        decode_tri(T, IJ, KL);
+        decode_tri(IJ, I, J);
+        decode_tri(KL, K, L);
+        const double f = (I == J ? 0.5 : 1.0) * (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
+        double g[4][4];
+        g[0][0] = na0.x; g[0][1] = na0.y; g[0][2] = nb0.x; g[0][3] = nb0.y;
+        g[1][0] = na1.x; g[1][1] = na1.y; g[1][2] = nb1.x; g[1][3] = nb1.y;
+        g[2][0] = na2.x; g[2][1] = na2.y; g[2][2] = nb2.x; g[2][3] = nb2.y;
+        g[3][0] = na3.x; g[3][1] = na3.y; g[3][2] = nb3.x; g[3][3] = nb3.y;
+        if (T + gridDim.x < ntiles) JKM_LOAD(T + gridDim.x)
+        if (NK) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                *reinterpret_cast<double2 *>(&s_g[(r0 + r) * LDT + c0]) = make_double2(g[r][0], g[r][1]);
+                *reinterpret_cast<double2 *>(&s_g[(r0 + r) * LDT + c0 + 2]) = make_double2(g[r][2], g[r][3]);
+            }
+            const int blk = t >> 6, e = t & 63, x = e >> 3, y = e & 7;
+            const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
+#pragma unroll
+            for (int q = 0; q < NK; q++) s_d[q][blk][x * 9 + y] = Dk[q * n2 + (size_t)(R * 8 + x) * npad + Cb * 8 + y];
+        }
+        // ---- Coulomb: one density at a time
+        for (int q = 0; q < nj; q++) {
+            const double *dklp = Dj + q * n2 + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
+            const double *dijp = Dj + q * n2 + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+            double dkl[4], dij[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { dkl[c] = dklp[c]; dij[c] = dijp[c]; }
+            double rs[4] = {0, 0, 0, 0}, cs[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    rs[r] += g[r][c] * dkl[c];
+                    cs[c] += g[r][c] * dij[r];
+                }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = rs[r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                rs[r] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = cs[c];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                cs[c] = v;
+            }
+            double *Jq = Jacc + q * n2;
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(&Jq[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * f * rs[r]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_col[q & 1][wave][c0 + c] = cs[c];
+            }
+            __syncthreads();  // (also publishes s_g / s_d on the first round; s_col is double-buffered across densities)
+            if (t < 64) {
+                const double v = s_col[q & 1][0][t] + s_col[q & 1][1][t] + s_col[q & 1][2][t] + s_col[q & 1][3][t];
+                atomicAdd(&Jq[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v);
+            }
+        }
+        if (NK) {
+            if (nj == 0) __syncthreads();
+            // the four exchange contractions (lane mapping and bank analysis: jk_tiles_kernel), NK densities per tile read
+            const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;
+            double k1[NKD], k2[NKD], k3[NKD], k4[NKD];
+#pragma unroll
+            for (int q = 0; q < NK; q++) k1[q] = k2[q] = k3[q] = k4[q] = 0.0;
+            // (rolled outer loop, inner loop in groups of 4: fully unrolled the compiler hoists all 64 + 64 NK LDS reads and spills)
+#pragma unroll 1
+            for (int u = 0; u < 2; u++) {
+                const int qq = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
+#pragma unroll 4
+                for (int a = 0; a < 8; a++) {
+                    const double g1 = s_g[(x * 8 + a) * LDT + qq * 8 + y], g2 = s_g[(a * 8 + x) * LDT + qq * 8 + y];
+                    const double g3 = s_g[(x * 8 + a) * LDT + y * 8 + q4], g4 = s_g[(a * 8 + x) * LDT + y * 8 + q4];
+#pragma unroll
+                    for (int q = 0; q < NK; q++) {
+                        k1[q] += g1 * s_d[q][0][a * 9 + qq];
+                        k2[q] += g2 * s_d[q][1][a * 9 + qq];
+                        k3[q] += g3 * s_d[q][2][a * 9 + q4];
+                        k4[q] += g4 * s_d[q][3][a * 9 + q4];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                double a1 = k1[q], a2 = k2[q], a3 = k3[q], a4 = k4[q];
+                a1 += __shfl_xor(a1, 1); a1 += __shfl_xor(a1, 2);
+                a2 += __shfl_xor(a2, 1); a2 += __shfl_xor(a2, 2);
+                a3 += __shfl_xor(a3, 1); a3 += __shfl_xor(a3, 2);
+                a4 += __shfl_xor(a4, 1); a4 += __shfl_xor(a4, 2);
+                if (pg == 0) {
+                    double *Kq = Kacc + q * n2;
+                    atomicAdd(&Kq[(size_t)(I * 8 + x) * npad + L * 8 + y], f * a1);
+                    atomicAdd(&Kq[(size_t)(J * 8 + x) * npad + L * 8 + y], f * a2);
+                    atomicAdd(&Kq[(size_t)(I * 8 + x) * npad + K * 8 + y], f * a3);
+                    atomicAdd(&Kq[(size_t)(J * 8 + x) * npad + K * 8 + y], f * a4);
+                }
+            }
+        }
+        __syncthreads();  // s_col / s_g / s_d reuse by the next tile
+    }
+}
+
+#undef JKM_LOAD
+// nmat matrices in / out: symmetrise + pad the densities, clear the accumulators
+__global__ void jk_multi_prep_kernel(double *__restrict__ work, const double *__restrict__ dmj, int nj, const double *__restrict__ dmk,
+                                     int nk, int nao, int npad) {
+    const size_t n2 = (size_t)npad * npad, nn = (size_t)nao * nao;
+    const int nd = nj + nk;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2 * nd; e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e / n2;
+        const size_t r = e - (size_t)q * n2;
+        const int i = r / npad, j = r % npad;
+        const double *dm = q < nj ? dmj + (size_t)q * nn : dmk + (size_t)(q - nj) * nn;
+        double v = 0.0;
+        if (i < nao && j < nao) v = 0.5 * (dm[(size_t)i * nao + j] + dm[(size_t)j * nao + i]);
+        work[e] = v;
+        work[n2 * nd + e] = 0.0;
+    }
+}
+
+__global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *__restrict__ K, int nk, const double *__restrict__ work,
+                                       int nao, int npad) {
+    const size_t n2 = (size_t)npad * npad, nn = (size_t)nao * nao;
+    const double *acc = work + (size_t)(nj + nk) * n2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nn * (nj + nk); e += (size_t)gridDim.x * blockDim.x) {
+        const int q = e / nn;
+        const size_t r = e - (size_t)q * nn;
+        const int i = r / nao, j = r % nao;
+        const double v = acc[q * n2 + (size_t)i * npad + j] + acc[q * n2 + (size_t)j * npad + i];
+        if (q < nj) J[e] = v;
+        else K[e - (size_t)nj * nn] = v;
     }
 }
 
@@ -197,6 +375,39 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad);
     DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+size_t dqc_jk_multi_work_doubles(int nao, int nj, int nk) {
+    const size_t npad = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
+    return 2 * (size_t)(nj + (nk > 2 ? 2 : nk)) * npad * npad;
+}
+
+int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_K, const double *d_dmK, int nk,
+                            const double *d_tiles, int nao, double *d_work, void *stream) {
+    using namespace dqc;
+    if (nao <= 0 || (nj <= 0 && nk <= 0)) return DQC_OK;
+    if (nj < 0 || nk < 0) { set_error("dqc_jk_from_tiles_multi: negative matrix count"); return DQC_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    const int npad = (nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
+    const size_t nn = (size_t)nao * nao;
+    const long long ntiles = (long long)dqc_eri_tile_count(nao);
+    const unsigned grid = (unsigned)std::min<long long>(ntiles, 256 * 16);
+    // exchange densities go two per pass (their tile reads from LDS are shared); the Coulomb ones all ride on the first pass
+    int kdone = 0, first = 1;
+    while (first || kdone < nk) {
+        const int njp = first ? nj : 0, nkp = std::min(2, nk - kdone);
+        hipLaunchKernelGGL(jk_multi_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dmJ, njp, d_dmK + (size_t)kdone * nn, nkp, nao, npad);
+        DQC_CHECK_LAUNCH();
+        if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
+        else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
+        else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
+        DQC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(jk_multi_finish_kernel, dim3(64), dim3(256), 0, st, d_J, njp, d_K + (size_t)kdone * nn, nkp, d_work, nao, npad);
+        DQC_CHECK_LAUNCH();
+        kdone += nkp;
+        first = 0;
+    }
     return DQC_OK;
 }
 

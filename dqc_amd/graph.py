@@ -38,6 +38,7 @@ class GraphedFock:
         with torch.cuda.graph(self.graph):
             self.dm, self.fock = self._body()
         h._jk_cache = None     # the memoised tensors belong to the graph's private pool
+        h._jkpol_cache = None
         h._dm_factor = None
 
     def _body(self):
@@ -95,6 +96,7 @@ class GraphedSCFStep:
             self.fock, self.dm, self.err = self._body()
         h = engine.hamilton
         h._jk_cache = None
+        h._jkpol_cache = None
         h._dm_factor = None
 
     def _dm_of_projector(self, p, s_):

@@ -189,25 +189,74 @@ class HamiltonMI355:
         self._jk_cache = (dm, J, K, dm._version)
         return J, K
 
+    def _sym_orth(self, m_ao):
+        m = self._convert2(m_ao)
+        return (m + m.transpose(-2, -1)) * 0.5
+
+    def _multi_work(self, nj, nk):
+        need = lib.load().dqc_jk_multi_work_doubles(self._nao_ao, nj, nk)
+        w = getattr(self, "_jkwork_multi", None)
+        if w is None or w.numel() < need:
+            w = self._jkwork_multi = torch.empty(need, dtype=torch.float64, device=self.device)
+        return w
+
+    def _jk_many(self, dms_j, dms_k):
+        """Coulomb matrices of the stacked (nj, nao, nao) `dms_j` and exchange matrices K of `dms_k`, all from ONE pass over
+        the ERI tiles (dqc_jk_from_tiles_multi); orthogonalised basis in and out."""
+        dj = None if dms_j is None else self._unconvert_dm(dms_j)
+        dk = None if dms_k is None else self._unconvert_dm(dms_k)
+        J, K = lib.jk_multi(self._tiles, dj, dk, self._multi_work(0 if dj is None else dj.shape[0], 0 if dk is None else dk.shape[0]))
+        return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
+
     def get_elrep(self, dm):
         if not self.is_built:
             raise RuntimeError("Please call `build()` before `get_elrep`")
         if self._df is not None:  # hcgto.py:212-214
             return self._df.get_elrep(dm)
-        mat = self._batched(lambda d: self._jk_orth(d, False)[0], dm)
+        if dm.dim() > 2:  # batch dimensions (base_hamilton.py:92-93): every density rides on the same tile pass
+            flat = dm.reshape(-1, *dm.shape[-2:])
+            mat = self._jk_many(flat, None)[0].reshape(dm.shape)
+        else:
+            mat = self._jk_orth(dm, False)[0]
         return LinearOperator.m(mat, is_hermitian=True)
 
     def get_exchange(self, dm):
         """returns -K/2 (hcgto.py:234); SpinParam input uses K(2 D_sigma) per spin (hcgto.py:238-241)"""
         if self._df is not None:  # hcgto.py:229-230
             raise RuntimeError("Exact exchange cannot be computed with density fitting")
-        if isinstance(dm, SpinParam):
-            return SpinParam(u=self.get_exchange(2 * dm.u), d=self.get_exchange(2 * dm.d))
         if not self.is_built:
             raise RuntimeError("Please call `build()` before `get_exchange`")
+        if isinstance(dm, SpinParam):
+            if dm.u.dim() == 2 and dm.d.dim() == 2:  # both spins from one pass (memoised by get_elrep_exchange_pol)
+                ku, kd = self._jk_pol(dm)[1]
+                return SpinParam(u=LinearOperator.m(ku, is_hermitian=True), d=LinearOperator.m(kd, is_hermitian=True))
+            return SpinParam(u=self.get_exchange(2 * dm.u), d=self.get_exchange(2 * dm.d))
         self._fuse_k = True
-        mat = self._batched(lambda d: -0.5 * self._jk_orth(d, True)[1], dm)
+        if dm.dim() > 2:
+            flat = dm.reshape(-1, *dm.shape[-2:])
+            mat = -0.5 * self._jk_many(None, flat)[1].reshape(dm.shape)
+        else:
+            mat = -0.5 * self._jk_orth(dm, True)[1]
         return LinearOperator.m(mat, is_hermitian=True)
+
+    def _jk_pol(self, dm):
+        """unrestricted Hartree-Fock: J[D_u + D_d], -K[2 D_u]/2, -K[2 D_d]/2 (hcgto.py:238-241, hf.py:93-103, 198-199) from
+        one pass over the tiles; memoised on the identity + version of the two spin matrices so that the reference's call
+        sequence get_elrep(dm.u + dm.d), get_exchange(dm) streams the tiles once when routed through here"""
+        c = getattr(self, "_jkpol_cache", None)
+        if c is not None and c[0] is dm.u and c[1] is dm.d and c[2] == (dm.u._version, dm.d._version):
+            return c[3], c[4]
+        J, K = self._jk_many((dm.u + dm.d).unsqueeze(0), torch.stack([dm.u, dm.d]))
+        # K[2 D] = 2 K[D] and the operator is -K/2: the two factors cancel
+        out = (J[0], (-K[0], -K[1]))
+        self._jkpol_cache = (dm.u, dm.d, (dm.u._version, dm.d._version), out[0], out[1])
+        return out
+
+    def get_elrep_exchange_pol(self, dm: SpinParam):
+        """(J[D_u + D_d], SpinParam(-K[2 D_u]/2, -K[2 D_d]/2)) as plain tensors in the orthogonalised basis: the three
+        operators an unrestricted Hartree-Fock Fock build needs (hf.py:93-103), one tile pass"""
+        J, (ku, kd) = self._jk_pol(dm)
+        return J, SpinParam(u=ku, d=kd)
 
     def get_vext(self, vext):
         if not self.is_ao_set:

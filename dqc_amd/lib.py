@@ -62,6 +62,9 @@ def load():
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
+    lib.dqc_jk_multi_work_doubles.argtypes = [c_int, c_int, c_int]
+    lib.dqc_jk_multi_work_doubles.restype = c_sz
+    lib.dqc_jk_from_tiles_multi.argtypes = [c_dp, c_dp, c_int, c_dp, c_dp, c_int, c_dp, c_int, c_dp, c_vp]
     lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
     lib.dqc_grid_density.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_vp]
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
@@ -264,6 +267,25 @@ def jk(tiles, dm_ao, work, with_k=True):
     with _on(dm_ao.device) as st_:
         _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
                                         st_), "dqc_jk_from_tiles")
+    return J, K
+
+
+def jk_multi(tiles, dms_j, dms_k, work=None):
+    """ONE pass over the tiles for several density matrices: dms_j (nj, nao, nao) -> J (nj, nao, nao), dms_k (nk, nao, nao)
+    -> K (nk, nao, nao) (plain K, not -K/2); either may be None.  AO basis, symmetrised."""
+    ref = dms_j if dms_j is not None else dms_k
+    nao, dev = ref.shape[-1], ref.device
+    nj = 0 if dms_j is None else dms_j.shape[0]
+    nk = 0 if dms_k is None else dms_k.shape[0]
+    need = load().dqc_jk_multi_work_doubles(nao, nj, nk)
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.float64, device=dev)
+    J = torch.empty((nj, nao, nao), dtype=torch.float64, device=dev) if nj else None
+    K = torch.empty((nk, nao, nao), dtype=torch.float64, device=dev) if nk else None
+    with _on(dev) as st_:
+        _check(load().dqc_jk_from_tiles_multi(_ptr(J), _ptr(None if dms_j is None else dms_j.contiguous()), nj,
+                                              _ptr(K), _ptr(None if dms_k is None else dms_k.contiguous()), nk,
+                                              _ptr(tiles), nao, _ptr(work), st_), "dqc_jk_from_tiles_multi")
     return J, K
 
 

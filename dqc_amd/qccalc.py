@@ -51,8 +51,14 @@ class _Engine:
         if self.polarized:  # scp = stacked (F_u, F_d)  (hf.py:93-103)
             if not isinstance(dm, SpinParam):
                 dm = SpinParam(u=dm[0], d=dm[1])
-            core = self.knvext + self.hamilton.get_elrep(dm.u + dm.d)
-            v = self.hamilton.get_vxc(dm) if self.is_ks else self.hamilton.get_exchange(dm)
+            h = self.hamilton
+            if not self.is_ks and h.df is None and hasattr(h, "get_elrep_exchange_pol") and dm.u.dim() == 2:
+                # J[D_u + D_d], -K[2 D_u]/2, -K[2 D_d]/2 from ONE pass over the ERI tiles instead of three
+                J, kx = h.get_elrep_exchange_pol(dm)
+                core = self.knvext.fullmatrix() + J
+                return torch.stack([core + kx.u, core + kx.d])
+            core = self.knvext + h.get_elrep(dm.u + dm.d)
+            v = h.get_vxc(dm) if self.is_ks else h.get_exchange(dm)
             return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])
         if self.is_ks and dm.dim() == 2 and hasattr(self.hamilton, "get_elrep_plus_vxc"):
             # J + Vxc with one AO -> orthogonal conversion (the operators' own sum, ks.py:176-187, converts each)

@@ -69,6 +69,15 @@ size_t dqc_jk_work_doubles(int nao);
 int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm,
                       int nao, double *d_work, void *stream);
 
+/* Several density matrices in ONE pass over the tiles (unrestricted HF: J[D_u + D_d], K[2 D_u], K[2 D_d],
+ * hcgto.py:238-241, hf.py:93-103; batched dm, base_hamilton.py:92-93).
+ * d_dmJ (nj, nao, nao) -> d_J (nj, nao, nao);  d_dmK (nk, nao, nao) -> d_K (nk, nao, nao); either count may be 0.
+ * Exchange matrices are processed two per pass (nk > 2: ceil(nk / 2) passes; all Coulomb ones ride on the first).
+ * d_work: dqc_jk_multi_work_doubles(nao, nj, nk) doubles of scratch. */
+size_t dqc_jk_multi_work_doubles(int nao, int nj, int nk);
+int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_K, const double *d_dmK, int nk,
+                            const double *d_tiles, int nao, double *d_work, void *stream);
+
 /* ---- AO values on the grid -----------------------------------------------------------------
  * Replaces GTOval_sph / GTOval_ip_sph (dqc/hamilton/intor/gtoeval.py:196-239) with the
  * to_transpose=True layout of HamiltonCGTO.setup_grid (hcgto.py:168, :179).
