@@ -45,3 +45,60 @@ def run_sharded(nmol: int, costs: Sequence[float], runner: Callable[[int], Seque
         # every row is owned by exactly one rank and zero elsewhere: a sum is a gather
         dist.all_reduce(table, op=dist.ReduceOp.SUM)
     return table
+
+
+def run_concurrent(qcs, max_inflight: int = 16, **run_kwargs):
+    """Run the SCF loops of many (small) molecules AT ONCE on one GPU: one HIP stream per molecule in flight, the
+    per-iteration host read of each loop (max|[F,D]| + the DIIS Gram row, a few hundred bytes) as an asynchronous copy
+    into pinned memory behind an event, and a round-robin over the generators (`SCF_QCCalc._run_gen`).  While the host
+    does the DIIS algebra of one molecule the hipGraph steps of the others are running, so molecules whose kernels fill
+    only a fraction of the 256 CUs (H2O ... benzene: 0.1-0.4 ms of launch-bound work per iteration) share the chip.
+    SURVEY.md 7 step 6 / 8e ("each rank: own HIP streams").  `qcs`: built HF / KS objects on one device; returns them."""
+    if not qcs:
+        return qcs
+    dev = qcs[0]._engine.device
+    n_in = max(1, min(max_inflight, len(qcs)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_in)]
+    main = torch.cuda.current_stream(dev)
+    for s in streams:
+        s.wait_stream(main)
+
+    class _Slot:
+        pass
+
+    def post(slot, req):
+        # the request tensor -> pinned host memory, asynchronously on the molecule's stream
+        if slot.pinned is None or slot.pinned.numel() < req.numel():
+            slot.pinned = torch.empty(max(64, req.numel()), dtype=req.dtype, pin_memory=True)
+        slot.n = req.numel()
+        slot.pinned[:slot.n].copy_(req.reshape(-1), non_blocking=True)
+        slot.ev.record(slot.stream)
+
+    todo = list(qcs)
+    active = []
+    free = list(streams)
+
+    def start():
+        while todo and free:
+            sl = _Slot()
+            sl.qc, sl.stream, sl.pinned, sl.ev = todo.pop(0), free.pop(0), None, torch.cuda.Event()
+            with torch.cuda.stream(sl.stream):
+                sl.gen = sl.qc._run_gen(**run_kwargs)
+                post(sl, next(sl.gen))
+            active.append(sl)
+
+    start()
+    while active:
+        for sl in list(active):
+            sl.ev.synchronize()
+            host = sl.pinned[:sl.n].numpy().copy()
+            with torch.cuda.stream(sl.stream):
+                try:
+                    post(sl, sl.gen.send(host))
+                except StopIteration:
+                    active.remove(sl)
+                    free.append(sl.stream)
+        start()
+    for s in streams:
+        main.wait_stream(s)
+    return qcs

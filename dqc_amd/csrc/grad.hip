@@ -204,7 +204,7 @@ DQC_DEV void nuc_grad_accumulate(double g3[3], int la, int lb, int nb, double a,
     }
 }
 
-__global__ void int1e_grad_kernel(double *__restrict__ grad, DevShells sh, const int *__restrict__ cao,
+__global__ __launch_bounds__(64) void int1e_grad_kernel(double *__restrict__ grad, DevShells sh, const int *__restrict__ cao,
                                   const int *__restrict__ sh_atom, const double *__restrict__ dcart,
                                   const double *__restrict__ wcart, int ncart, int natm,
                                   const double *__restrict__ atom_xyz, const double *__restrict__ atom_z) {

@@ -216,21 +216,24 @@ static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, doubl
                           int ngrid, int ld, const double *dm, int ntile, const double *aoe) {
 #define DQC_DENS_CASE(N)                                                                                           \
     case N:                                                                                                        \
-        (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)density_lds_bytes<N>());                                                    \
-        hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(DEN_NT), density_lds_bytes<N>(), st, rho, grho, ao,    \
-                           ngrid, ld, dm, ntile, aoe);                                                                  \
+        if constexpr (!GGA || N <= 14) { /* GGA panels of 15 / 16 tiles would spill: never instantiated */          \
+            (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)density_lds_bytes<N>());                                                \
+            hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(DEN_NT), density_lds_bytes<N>(), st, rho, grho, ao, \
+                               ngrid, ld, dm, ntile, aoe);                                                          \
+            return 0;                                                                                              \
+        }                                                                                                          \
         break;
     switch (nct) {
         DQC_DENS_CASE(1) DQC_DENS_CASE(2) DQC_DENS_CASE(3) DQC_DENS_CASE(4) DQC_DENS_CASE(5) DQC_DENS_CASE(6)
         DQC_DENS_CASE(7) DQC_DENS_CASE(8) DQC_DENS_CASE(9) DQC_DENS_CASE(10) DQC_DENS_CASE(11) DQC_DENS_CASE(12)
         DQC_DENS_CASE(13) DQC_DENS_CASE(14) DQC_DENS_CASE(15) DQC_DENS_CASE(16)
     default:
-        set_error("density: internal tile-count dispatch error");
-        return DQC_EINVAL;
+        break;
     }
 #undef DQC_DENS_CASE
-    return 0;
+    set_error("density: internal tile-count dispatch error");
+    return DQC_EINVAL;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -490,26 +493,32 @@ static constexpr size_t density_lr_lds_bytes() {
     return sizeof(double) * 2 * (DEN_BM * DEN_SA + DEN_KC * (LSBP > RPS ? LSBP : RPS));
 }
 
+// widest phase-2 column panel per factor width (NRT tiles) that compiles without VGPR spills in GGA mode: 8 NRT phase-1 +
+// 8 NCT phase-2 accumulator registers + the epilogue's 4 NCT load-batch registers share 256; wider bases take more panels
+constexpr int lr_max_nct(int nrt) { return nrt <= 1 ? 16 : (nrt <= 3 ? 14 : (nrt <= 4 ? 13 : (nrt <= 6 ? 10 : 11))); }
+
 template <int NRT, bool GGA>
 static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao, int ngrid,
                                int ld, const double *orb, const double *orbt, int ntile) {
 #define DQC_DLR_CASE(N)                                                                                          \
-    case N: {                                                                                                    \
-        constexpr size_t shm = density_lr_lds_bytes<NRT, N>();                                                   \
-        auto kern = density_lr_kernel<NRT, N, GGA>;                                                              \
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);     \
-        hipLaunchKernelGGL(kern, grid, dim3(DEN_NT), shm, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);       \
-        break;                                                                                                   \
-    }
+    case N:                                                                                                      \
+        if constexpr (!GGA || N <= lr_max_nct(NRT)) { /* wider panels would spill: never instantiated */         \
+            constexpr size_t shm = density_lr_lds_bytes<NRT, N>();                                               \
+            auto kern = density_lr_kernel<NRT, N, GGA>;                                                          \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+            hipLaunchKernelGGL(kern, grid, dim3(DEN_NT), shm, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);   \
+            return 0;                                                                                            \
+        }                                                                                                        \
+        break;
     switch (nct) {  // ld / 16 is odd; panels of a split matrix may be even
         DQC_DLR_CASE(1) DQC_DLR_CASE(3) DQC_DLR_CASE(5) DQC_DLR_CASE(7) DQC_DLR_CASE(9) DQC_DLR_CASE(10)
         DQC_DLR_CASE(11) DQC_DLR_CASE(12) DQC_DLR_CASE(13) DQC_DLR_CASE(14) DQC_DLR_CASE(15) DQC_DLR_CASE(16)
     default:
-        set_error("density_lr: internal tile-count dispatch error");
-        return DQC_EINVAL;
+        break;
     }
 #undef DQC_DLR_CASE
-    return 0;
+    set_error("density_lr: internal tile-count dispatch error");
+    return DQC_EINVAL;
 }
 
 template <bool GGA>
@@ -1342,8 +1351,7 @@ static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hi
     DQC_VWS_CASE(2, 1) DQC_VWS_CASE(4, 1) DQC_VWS_CASE(6, 1) DQC_VWS_CASE(8, 1) DQC_VWS_CASE(11, 1)
     DQC_VWS_CASE(2, 2) DQC_VWS_CASE(4, 2) DQC_VWS_CASE(6, 2) DQC_VWS_CASE(8, 2) DQC_VWS_CASE(11, 2)
     DQC_VWS_CASE(2, 4) DQC_VWS_CASE(4, 4) DQC_VWS_CASE(6, 4) DQC_VWS_CASE(8, 4) DQC_VWS_CASE(11, 4)
-    DQC_VWS_CASE(6, 7) DQC_VWS_CASE(8, 7) DQC_VWS_CASE(11, 7)
-#undef DQC_VWS_CASE
+#undef DQC_VWS_CASE  // (ld <= 256 with 32 producer threads per row needs at most 4 pieces per thread)
     set_error("vxc_ws: internal dispatch error");
     return DQC_EINVAL;
 }
@@ -1404,8 +1412,7 @@ static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStr
     DQC_VXC_CASE(2, 1) DQC_VXC_CASE(4, 1) DQC_VXC_CASE(8, 1) DQC_VXC_CASE(11, 1)
     DQC_VXC_CASE(2, 2) DQC_VXC_CASE(4, 2) DQC_VXC_CASE(8, 2) DQC_VXC_CASE(11, 2)
     DQC_VXC_CASE(2, 4) DQC_VXC_CASE(4, 4) DQC_VXC_CASE(8, 4) DQC_VXC_CASE(11, 4)
-    DQC_VXC_CASE(8, 8) DQC_VXC_CASE(11, 8)
-#undef DQC_VXC_CASE
+#undef DQC_VXC_CASE  // (this kernel only sees ld <= 208: wider bases take vxc_ws2_kernel)
     set_error("vxc: internal dispatch error");
     return DQC_EINVAL;
 }
@@ -1422,7 +1429,8 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
     const bool gga = d_grho != nullptr;
     if (gga && ncomp < 4) { set_error("dqc_grid_density: gradient requested but ao has < 4 components"); return DQC_EINVAL; }
     const int ld = dqc_padded_nao(nao), ntile = ld / 16;
-    const int nchunk = (ntile + 15) / 16;
+    // column panels: <= 16 tiles (LDA) / <= 14 (GGA: 15 and 16 tiles of accumulators + the epilogue's load batches spill)
+    const int nchunk = (ntile + (gga ? 13 : 15)) / (gga ? 14 : 16);
     const int nct = (ntile + nchunk - 1) / nchunk;
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
     int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao)
@@ -1451,7 +1459,8 @@ int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int n
         return DQC_EINVAL;
     }
     const int ld = dqc_padded_nao(nao), ntile = ld / 16;
-    const int nchunk = (ntile + 15) / 16;
+    const int lim = gga ? dqc::lr_max_nct(norb_pad / 16) : 16;
+    const int nchunk = (ntile + lim - 1) / lim;
     int nct = (ntile + nchunk - 1) / nchunk;
     if (nct < 9 && (nct & 1) == 0) nct++;  // instantiated panel widths
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);

@@ -55,7 +55,7 @@ DQC_DEV void nuc_accumulate(double *cart, int la, int lb, int na, int nb, double
     }
 }
 
-__global__ void int1e_kernel(int which, double *__restrict__ out, int nao, DevShells sh, int natm,
+__global__ __launch_bounds__(64) void int1e_kernel(int which, double *__restrict__ out, int nao, DevShells sh, int natm,
                              const double *__restrict__ atom_xyz, const double *__restrict__ atom_z) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= sh.nsh * sh.nsh) return;

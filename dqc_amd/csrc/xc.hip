@@ -85,7 +85,7 @@ struct XcTerms {
     double c[8];
 };
 
-__global__ void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
+__global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                           const double *__restrict__ rho, const double *__restrict__ grho, int n, XcTerms terms,
                           int gga) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -174,7 +174,7 @@ DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s) {
 }
 
 
-__global__ void xc_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
+__global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
                               double *__restrict__ vgu, double *__restrict__ vgd, const double *__restrict__ ru_,
                               const double *__restrict__ rd_, const double *__restrict__ gu_,
                               const double *__restrict__ gd_, int n, XcTerms terms, int gga) {
@@ -300,7 +300,7 @@ DQC_DEV D5 f_mgga_x_scan(D5 r, D5 sg, D5 ta) {
     return (-0.75 * 0.98474502184269641) * (r * cbrt5(r)) * Fx;
 }
 
-__global__ void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
+__global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                                double *__restrict__ vtau, const double *__restrict__ rho,
                                const double *__restrict__ grho, const double *__restrict__ tau, int n, XcTerms terms) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

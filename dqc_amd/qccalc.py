@@ -128,6 +128,20 @@ class SCF_QCCalc:
         return self._engine.get_system()
 
     def run(self, dm0="1e", eigen_options=None, fwd_options=None, bck_options=None):
+        """the SCF loop, driven synchronously: every host read of the generator below is a blocking device -> host copy.
+        dqc_amd.batch.run_concurrent drives many of these generators at once, one stream per molecule."""
+        gen = self._run_gen(dm0, fwd_options)
+        try:
+            req = next(gen)
+            while True:
+                req = gen.send(req.cpu().numpy())
+        except StopIteration:
+            pass
+        return self
+
+    def _run_gen(self, dm0="1e", fwd_options=None):
+        """generator form of run(): yields the (small) device tensor it needs on the host -- ONE per SCF iteration -- and is
+        resumed with that tensor's numpy copy; everything else is enqueued on the current stream without synchronising"""
         opts = {"maxiter": 50, "f_tol": 1e-9, "history": 12}
         opts.update(fwd_options or {})
         eng = self._engine
@@ -176,7 +190,7 @@ class SCF_QCCalc:
             hist = es[-(int(opts["history"]) - 1):] if int(opts["history"]) > 1 else []
             row = (torch.stack(hist + [ev]) * ev).sum(-1)
             head = torch.stack([err.abs().max(), perr if perr is not None else torch.zeros((), dtype=fock.dtype, device=fock.device)])
-            host = torch.cat([head, row]).cpu().numpy()
+            host = yield torch.cat([head, row])
             emax, pe, grow = float(host[0]), float(host[1]), host[2:]
             if perr is not None and not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
                 dm = eng.scp2dm(fprev)
@@ -185,8 +199,8 @@ class SCF_QCCalc:
                 dmm = torch.stack([dm.u, dm.d]) if pol else dm
                 err = fock @ dmm - dmm @ fock
                 ev = err.reshape(-1)
-                emax = float(err.abs().max())
-                grow = (torch.stack(hist + [ev]) * ev).sum(-1).cpu().numpy()
+                h2 = yield torch.cat([err.abs().max().reshape(1), (torch.stack(hist + [ev]) * ev).sum(-1)])
+                emax, grow = float(h2[0]), h2[1:]
             self.scf_error = emax  # max |[F, D]| of the last iterate
             # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,
             # growing with the matrix size): an iterate that is within 100 f_tol and has not improved for 8 steps ends the
@@ -249,7 +263,6 @@ class SCF_QCCalc:
             warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e); energy() and "
                           "nuclear_gradient() of this object refer to a non-stationary density"
                           % (self.niter, self.scf_error, opts["f_tol"]))
-        return self
 
     def energy(self):
         assert self._has_run
