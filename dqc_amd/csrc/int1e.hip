@@ -107,6 +107,19 @@ __global__ __launch_bounds__(64) void int1e_kernel(int which, double *__restrict
                                 double v;
                                 if (which == 0) {
                                     v = sx * sy * sz;
+                                } else if (which >= 3) {
+                                    // multipole moments about the origin 0 (libcint int1e_r_sph / int1e_rr_sph; reference
+                                    // intor.int1e("r0" * n), hcgto.py:117-125): x = (x - B) + B on the ket raises j,
+                                    //   <i|x|j> = S(j+1) + B S(j),   <i|x^2|j> = S(j+2) + 2 B S(j+1) + B^2 S(j)
+                                    int e[3] = {0, 0, 0};
+                                    if (which < 6) e[which - 3] = 1;
+                                    else { e[(which - 6) / 3] += 1; e[(which - 6) % 3] += 1; }
+                                    const int bj[3] = {bx, by, bz}, ai[3] = {ax, ay, az};
+                                    v = 1.0;
+                                    for (int d = 0; d < 3; d++) {
+                                        const double s0 = s[d][ai[d]][bj[d]], s1 = s[d][ai[d]][bj[d] + 1], s2 = s[d][ai[d]][bj[d] + 2];
+                                        v *= e[d] == 0 ? s0 : (e[d] == 1 ? s1 + B[d] * s0 : s2 + 2.0 * B[d] * s1 + B[d] * B[d] * s0);
+                                    }
                                 } else {
                                     // -1/2 d2/dx2 on the ket: -2b^2 S(j+2) + b(2j+1) S(j) - j(j-1)/2 S(j-2)
                                     const double tx = -2.0 * b * b * s[0][ax][bx + 2] + b * (2 * bx + 1) * sx -
@@ -144,7 +157,10 @@ __global__ __launch_bounds__(64) void int1e_kernel(int which, double *__restrict
 extern "C" int dqc_int1e(int which, double *d_out, const int *atm, int natm, const int *bas, int nbas,
                          const double *env, int nenv, const double *zs, void *stream) {
     using namespace dqc;
-    if (which < 0 || which > 2) { set_error("dqc_int1e: which must be 0 (ovlp), 1 (kin) or 2 (nuc)"); return DQC_EINVAL; }
+    if (which < 0 || which > 14) {
+        set_error("dqc_int1e: which must be 0 (ovlp), 1 (kin), 2 (nuc), 3-5 (r0: x, y, z) or 6-14 (r0r0: 6 + 3 d1 + d2)");
+        return DQC_EINVAL;
+    }
     hipStream_t st = (hipStream_t)stream;
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, zs);

@@ -27,15 +27,28 @@ from .utils.datastruct import AtomCGTOBasis, SpinParam, ValGrad
 from .xc import LibXC
 
 
-class HamiltonMI355:
+try:  # inside a DQC installation the class IS a BaseHamilton (isinstance checks of dqc.qccalc / dqc.system pass)
+    from dqc.hamilton.base_hamilton import BaseHamilton as _Base
+except Exception:  # dqc (or one of its dependencies: xitorch, dqclibs) is absent: stand alone
+    _Base = object
+
+
+class HamiltonMI355(_Base):
     def __init__(self, atombases: List[AtomCGTOBasis], spherical: bool = True, df=None, efield=None,
                  vext: Optional[torch.Tensor] = None, cache=None, orthozer: bool = True,
                  aoparamzer: str = "qr", device="cuda"):
         if not spherical:
             raise NotImplementedError("only spherical AOs (the reference default) are implemented on MI355X")
         self._dfoptions = df
+        # efield: tuple of flattened tensors (E_d,), (E_d, dE_{d1 d2}) as Mol passes them (mol.py:456-474); hcgto.py:117-125
         if efield is not None:
-            raise NotImplementedError("electric-field integrals are outside the MI355X hot path")
+            if isinstance(efield, torch.Tensor):
+                efield = (efield,)
+            if len(efield) > 2:
+                raise NotImplementedError("electric-field terms beyond the field gradient (int1e r0r0r0...) are not implemented")
+            for i, ef in enumerate(efield):
+                assert ef.numel() == 3 ** (i + 1), "The %d-th tuple element of efield must have %d elements" % (i, 3 ** (i + 1))
+        self._efield = efield
         if aoparamzer not in ("qr", "matexp"):
             raise RuntimeError("Unknown ao parameterizer: %s. Available options are: ['qr', 'matexp']" % aoparamzer)
         lib.load()  # fail loudly if the HIP library is missing
@@ -104,6 +117,12 @@ class HamiltonMI355:
         kin = lib.int1e("kin", tab, dev)
         nuc = lib.int1e("nuc", tab, dev, self._zs)
         self.olp_mat = self._convert2(self._ovlp_ao)
+        if self._efield is not None:  # hcgto.py:117-125: sum_n  (1/n!) E^(n) . <mu| r0^n |nu>
+            fac = 1.0
+            for i, ef in enumerate(self._efield):
+                fac *= i + 1
+                mats = lib.int1e("r0" * (i + 1), tab, dev)  # (3^(i+1), nao, nao)
+                kin = kin + torch.einsum("dab,d->ab", mats, ef.reshape(-1).to(device=dev, dtype=self.dtype)) / fac
         self.kinnucl_mat = self._convert2(kin + nuc)
         self.nucl_mat = self._convert2(nuc)
         if self._df is None:

@@ -138,8 +138,11 @@ def padded_nao(nao):
 
 
 def int1e(which, tab, device, zs=None):
-    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao) device tensor"""
-    code = {"ovlp": 0, "kin": 1, "nuc": 2}[which]
+    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao) device tensor; 'r0' -> (3, nao, nao), 'r0r0' -> (9, nao, nao): multipole
+    moments about the origin (the reference's intor.int1e("r0" * n), hcgto.py:117-125)"""
+    if which in ("r0", "r0r0"):
+        return torch.stack([int1e(c, tab, device) for c in (range(3, 6) if which == "r0" else range(6, 15))])
+    code = which if isinstance(which, int) else {"ovlp": 0, "kin": 1, "nuc": 2}[which]
     out = torch.zeros((tab.nao, tab.nao), dtype=torch.float64, device=device)
     zp = None
     if zs is not None:

@@ -29,8 +29,8 @@ class _Engine:
         self.xc = get_xc(xc) if is_ks else None
         # hf.py:49-53: polarised iff spin != 0 unless `restricted` says otherwise
         self.polarized = bool(system.spin != 0) if restricted is None else (not restricted)
-        if system.spin != 0 and not self.polarized:
-            raise NotImplementedError("restricted open-shell is not implemented (the reference treats it via orb weights)")
+        # spin != 0 with restricted=True: one set of orbitals with occupations [2, ..., 2, 1, ..., 1] (mol.py:421-443) -- the
+        # reference's restricted open-shell treatment; non-uniform occupations take the eigh step (no purification)
         # hf.py:55-57 / ks.py:69-71: the grid is needed by KS always and by HF when the system carries an external
         # potential (vext is integrated on the grid inside build())
         if is_ks or system.requires_grid():

@@ -38,6 +38,13 @@ class Mol:
         self._ndn = (int(round(nelecs)) - spin) // 2
         if vext is not None:
             vext = vext.to(device=self._device, dtype=dtype)
+        # mol.py:445-474: a tensor -> 1-tuple; every element flattened ((3,), (3, 3) -> (9,), ...)
+        if isinstance(efield, torch.Tensor):
+            efield = (efield,)
+        if efield is not None:
+            for i, ef in enumerate(efield):
+                assert ef.numel() == 3 ** (i + 1), "The %d-th tuple element of efield must have %d elements" % (i, 3 ** (i + 1))
+            efield = tuple(ef.reshape(-1) for ef in efield)
         self._efield, self._vext = efield, vext
         self._orthogonalize_basis, self._aoparamzer = orthogonalize_basis, ao_parameterizer
         self._hamilton = HamiltonMI355(self._atombases, spherical=True, efield=efield, vext=vext,
@@ -64,6 +71,10 @@ class Mol:
     @property
     def numel(self):
         return self._nelecs
+
+    @property
+    def efield(self):
+        return self._efield
 
     def densityfit(self, method=None, auxbasis=None):
         """dqc/system/mol.py:170-204: switch the Hamiltonian to the density-fitted Coulomb operator.

@@ -296,7 +296,33 @@ static void int1e_pair(int which, Shell A, Shell B, int natm, const int *atm, co
             hermite_E(la, lb + 2, a, b, AB[0], Ex);
             hermite_E(la, lb + 2, a, b, AB[1], Ey);
             hermite_E(la, lb + 2, a, b, AB[2], Ez);
-            if (which == 0 || which == 1) {
+            if (which >= 3) {
+                /* int1e_r / int1e_rr about the common origin 0 (libcint int1e_r_sph, int1e_rr_sph; reference call site
+                 * intor.int1e("r0" * n), dqc/hamilton/hcgto.py:117-125).  1D: <i| x^e |j> = sum_t E_t^{ij} M_t^e with the
+                 * Hermite moments about 0: M_0^0 = 1, M_0^1 = P, M_1^1 = 1, M_0^2 = P^2 + 1/(2p), M_1^2 = 2 P, M_2^2 = 2
+                 * (times sqrt(pi/p)).  which = 3 + d (x, y, z) or 6 + 3 d1 + d2 (second moments). */
+                int e[3] = {0, 0, 0};
+                if (which < 6) e[which - 3] = 1;
+                else { e[(which - 6) / 3] += 1; e[(which - 6) % 3] += 1; }
+                double P[3] = {(a * A.r[0] + b * B.r[0]) / p, (a * A.r[1] + b * B.r[1]) / p,
+                               (a * A.r[2] + b * B.r[2]) / p};
+                double pref = cc * pow(M_PI / p, 1.5);
+                for (int ca = 0; ca < na; ca++)
+                    for (int cb = 0; cb < nb; cb++) {
+                        double v = 1.0;
+                        for (int d = 0; d < 3; d++) {
+                            int i = pa[ca][d], j = pb[cb][d];
+                            double (*E)[LMAX1 + 2][EDIM] = d == 0 ? Ex : (d == 1 ? Ey : Ez);
+                            double e0 = E[i][j][0], e1 = (i + j >= 1) ? E[i][j][1] : 0.0, e2 = (i + j >= 2) ? E[i][j][2] : 0.0;
+                            double m;
+                            if (e[d] == 0) m = e0;
+                            else if (e[d] == 1) m = P[d] * e0 + e1;
+                            else m = (P[d] * P[d] + 0.5 / p) * e0 + 2.0 * P[d] * e1 + 2.0 * e2;
+                            v *= m;
+                        }
+                        cart[ca * nb + cb] += pref * v;
+                    }
+            } else if (which == 0 || which == 1) {
                 double pref = cc * pow(M_PI / p, 1.5);
                 for (int ca = 0; ca < na; ca++)
                     for (int cb = 0; cb < nb; cb++) {

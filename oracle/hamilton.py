@@ -41,8 +41,9 @@ def chunkify(a, dim, maxnumel):
 class Hamilton:
     """Restatement of HamiltonCGTO for isolated molecules (no DF, no efield/vext)."""
 
-    def __init__(self, tables, orthozer=True, eri_mode="dense", df=None):
+    def __init__(self, tables, orthozer=True, eri_mode="dense", df=None, efield=None):
         self.t = tables
+        self.efield = efield  # tuple of flattened arrays (E,), (E, dE): hcgto.py:117-125
         self.eri_mode = eri_mode  # "dense": reference formulation; "s4": packed variant for big nao
         # df = (concatenated tables, orbital shell range, auxiliary shell range): density-fitted J (dqc/df/dfmol.py)
         self.df = df
@@ -74,6 +75,12 @@ class Hamilton:
         kin = torch.as_tensor(natives.int1e("kin", t))
         nuc = torch.as_tensor(natives.int1e("nuc", t))
         self.olp_mat = self.convert2(olp)
+        if self.efield is not None:
+            fac = 1.0
+            for i, ef in enumerate(self.efield):
+                fac *= i + 1
+                mats = torch.as_tensor(natives.int1e("r0" * (i + 1), t))
+                kin = kin + torch.einsum("dab,d->ab", mats, torch.as_tensor(np.asarray(ef, dtype=np.float64).reshape(-1))) / fac
         self.kinnucl_mat = self.convert2(kin + nuc)
         self.nucl_mat = self.convert2(nuc)
         if self.df is not None:  # DFMol.build, dfmol.py:24-58 (method "coulomb")
@@ -257,18 +264,21 @@ def nuclei_energy(zs, pos):
 class Engine:
     """RHF (xc=None) / RKS engine: dm2scp, scp2dm, dm2energy as in hf.py / ks.py."""
 
-    def __init__(self, tables, xc=None, grid="sg3", hf=None, eri_mode="dense", df=None):
+    def __init__(self, tables, xc=None, grid="sg3", hf=None, eri_mode="dense", df=None, efield=None, spin=0):
         self.t = tables
         self.is_hf = (xc is None) if hf is None else hf
         self.xc = None if self.is_hf else (oxc.get_xc(xc) if isinstance(xc, str) else xc)
-        self.h = Hamilton(tables, eri_mode=eri_mode, df=df).build()
+        self.h = Hamilton(tables, eri_mode=eri_mode, df=df, efield=efield).build()
         if not self.is_hf:
             rgrid, dvol = ogrid.get_predefined_grid(grid, tables.atomzs, tables.atompos)
             self.h.setup_grid(rgrid, dvol, self.xc)
         nel = int(round(float(np.sum(tables.atomzs))))
-        assert nel % 2 == 0, "restricted closed-shell only"
-        self.norb = nel // 2
-        self.orb_weight = torch.full((self.norb,), 2.0, dtype=torch.float64)
+        assert (nel - spin) % 2 == 0, "spin inconsistent with the electron count"
+        # restricted occupations [2, ..., 2, 1, ..., 1] (mol.py:421-443): closed shell for spin 0, the reference's
+        # restricted open-shell treatment otherwise
+        nup, ndn = (nel + spin) // 2, (nel - spin) // 2
+        self.norb = nup
+        self.orb_weight = torch.cat([torch.full((ndn,), 2.0, dtype=torch.float64), torch.ones(nup - ndn, dtype=torch.float64)])
         self.enuc = nuclei_energy(tables.atomzs, tables.atompos)
 
     def dm2scp(self, dm):
@@ -333,10 +343,10 @@ class Engine:
         return self.dm2energy(self.dm)
 
 
-def run_scf(moldesc, basis, xc=None, grid="sg3", auxbasis=None, **kw):
+def run_scf(moldesc, basis, xc=None, grid="sg3", auxbasis=None, efield=None, spin=0, **kw):
     t = obasis.make_tables(moldesc, basis)
     df = obasis.make_tables_df(moldesc, basis, auxbasis) if auxbasis is not None else None
-    eng = Engine(t, xc=xc, grid=grid, df=df)
+    eng = Engine(t, xc=xc, grid=grid, df=df, efield=efield, spin=spin)
     e = eng.run(**kw)
     return e, eng
 

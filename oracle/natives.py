@@ -39,8 +39,12 @@ def _tab(t):
 
 
 def int1e(which, t, zs=None):
-    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao)"""
-    code = {"ovlp": 0, "kin": 1, "nuc": 2}[which]
+    """which: 'ovlp' | 'kin' | 'nuc' -> (nao, nao); 'r0' -> (3, nao, nao), 'r0r0' -> (9, nao, nao): multipole moments about
+    the origin (intor.int1e("r0" * n), hcgto.py:117-125)"""
+    if which in ("r0", "r0r0"):
+        codes = range(3, 6) if which == "r0" else range(6, 15)
+        return np.stack([int1e(c, t) for c in codes])
+    code = which if isinstance(which, int) else {"ovlp": 0, "kin": 1, "nuc": 2}[which]
     out = np.zeros((t.nao, t.nao))
     zp = None
     if zs is not None:
