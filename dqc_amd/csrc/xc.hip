@@ -273,6 +273,7 @@ DQC_DEV D5 exp5c(D5 a) {  // exp with the argument clipped at 50 (only active in
     return chain(a, f, f);
 }
 DQC_DEV D5 operator*(D5 a, double b) { return b * a; }
+DQC_DEV D5 operator/(D5 a, double b) { return (1.0 / b) * a; }
 DQC_DEV D5 operator+(D5 a, double b) { a.v += b; return a; }
 DQC_DEV D5 operator-(D5 a, double b) { a.v -= b; return a; }
 
@@ -300,6 +301,121 @@ DQC_DEV D5 f_mgga_x_scan(D5 r, D5 sg, D5 ta) {
     return (-0.75 * 0.98474502184269641) * (r * cbrt5(r)) * Fx;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SCAN correlation (mgga_c_scan): Sun, Ruzsinszky, Perdew, PRL 115, 036402, eqs. (9)-(17) + supplementary material, libxc's
+// constants.  eps_c = eps_c^1 + f_c(alpha) (eps_c^0 - eps_c^1):
+//   eps_c^1 = eps_LSDA + gamma phi^3 ln[1 + w1 (1 - (1 + 4 A t^2)^(-1/4))],  w1 = exp(-eps_LSDA / (gamma phi^3)) - 1,
+//             A = beta(rs) / (gamma w1),  beta(rs) = 0.066725 (1 + 0.1 rs) / (1 + 0.1778 rs),  LSDA = modified PW92
+//   eps_c^0 = (eps_LDA0 + b1c ln[1 + w0 (1 - (1 + 4 chi_inf s^2)^(-1/4))]) Gc(zeta),  eps_LDA0 = -b1c / (1 + b2c sqrt(rs) + b3c rs)
+//   alpha = (tau - tau_W) / (tau_unif ds(zeta)),  f_c = exp(-c1c alpha / (1 - alpha)) (alpha < 1), -dc exp(c2c / (1 - alpha)) (alpha > 1)
+// Two separate codings: the closed zeta = 0 form (slots 0 = rho, 1 = sigma, 2 = tau) and the general spin-polarised form
+// (slots 0 = rho_u, 1 = rho_d, 2 = sigma_total, 3 = tau_total); the oracle codes the general form once more in numpy.
+// No literal of this functional exists in the reference: parity against libxc is UNPINNED (like gga_c_pbe).
+// ---------------------------------------------------------------------------------------------
+struct ScanC {
+    static constexpr double b1c = 0.0285764, b2c = 0.0889, b3c = 0.125541, c1c = 0.64, c2c = 1.5, dc = 0.7;
+    static constexpr double chi_inf = 0.12802585262625815, gcnst = 2.3631, gamma = 0.031090690869654895;
+};
+
+DQC_DEV D5 scan_c_switch(D5 alpha) {
+    D5 oma = 1.0 - alpha;
+    if (fabs(oma.v) < 1e-12) return c5(0.0);
+    if (alpha.v < 1.0) return exp5c((-ScanC::c1c) * alpha / oma);
+    return (-ScanC::dc) * exp5c(ScanC::c2c / oma);
+}
+
+DQC_DEV D5 pw92_mod_unpol5(D5 rho) {  // modified-PW92 paramagnetic branch
+    const double a = 0.0310906908696548950, alpha1 = 0.21370, b1 = 7.5957, b2 = 3.5876, b3 = 1.6382, b4 = 0.49294;
+    D5 rs = cbrt5((3.0 / (4.0 * kPi)) / rho);
+    D5 sq = sqrt5(rs);
+    D5 q1 = (2.0 * a) * (b1 * sq + b2 * rs + b3 * (rs * sq) + b4 * (rs * rs));
+    return (-2.0 * a) * (1.0 + alpha1 * rs) * log1p5(1.0 / q1);
+}
+
+// unpolarised closed form (zeta = 0: phi = dx = ds = Gc = 1)
+DQC_DEV D5 f_mgga_c_scan(D5 r, D5 sg, D5 ta) {
+    D5 rs = cbrt5((3.0 / (4.0 * kPi)) / r);
+    D5 kf = cbrt5((3.0 * kPi * kPi) * r);
+    D5 kf2 = kf * kf;
+    D5 s2 = sg / (4.0 * kf2 * (r * r));
+    D5 alpha = (ta - sg / (8.0 * r)) / (0.3 * kf2 * r);
+    D5 fc = scan_c_switch(alpha);
+    D5 eps = pw92_mod_unpol5(r);
+    D5 beta = 0.066725 * (1.0 + 0.1 * rs) / (1.0 + 0.1778 * rs);
+    D5 t2 = sg / (4.0 * ((4.0 / kPi) * kf) * (r * r));
+    D5 w1 = expm15(c5(0.0) - eps / ScanC::gamma);
+    D5 A = beta / (ScanC::gamma * w1);
+    D5 g = 1.0 / p5(1.0 + 4.0 * (A * t2), 0.25);
+    D5 eps1 = eps + ScanC::gamma * log1p5(w1 * (1.0 - g));
+    D5 e0 = c5(-ScanC::b1c) / (1.0 + ScanC::b2c * sqrt5(rs) + ScanC::b3c * rs);
+    D5 w0 = expm15(c5(0.0) - e0 / ScanC::b1c);
+    D5 ginf = 1.0 / p5(1.0 + (4.0 * ScanC::chi_inf) * s2, 0.25);
+    D5 eps0 = e0 + ScanC::b1c * log1p5(w0 * (1.0 - ginf));
+    return r * (eps1 + fc * (eps0 - eps1));
+}
+
+// general spin-polarised form
+DQC_DEV D5 f_mgga_c_scan_pol(D5 u, D5 d, D5 sg, D5 ta) {
+    const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
+    D5 rho = u + d;
+    D5 zeta = (u - d) / rho;
+    zeta.v = fmin(fmax(zeta.v, -1.0 + 1e-10), 1.0 - 1e-10);
+    D5 zp = 1.0 + zeta, zm = 1.0 - zeta;
+    D5 rs = cbrt5((3.0 / (4.0 * kPi)) / rho);
+    D5 kf = cbrt5((3.0 * kPi * kPi) * rho);
+    D5 kf2 = kf * kf;
+    D5 s2 = sg / (4.0 * kf2 * (rho * rho));
+    D5 phi = 0.5 * (p5(zp, 2.0 / 3.0) + p5(zm, 2.0 / 3.0));
+    D5 phi3 = phi * phi * phi;
+    D5 dxz = 0.5 * (p5(zp, 4.0 / 3.0) + p5(zm, 4.0 / 3.0));
+    D5 dsz = 0.5 * (p5(zp, 5.0 / 3.0) + p5(zm, 5.0 / 3.0));
+    D5 alpha = (ta - sg / (8.0 * rho)) / (0.3 * kf2 * rho * dsz);
+    D5 fc = scan_c_switch(alpha);
+    D5 eps = pw92_pol_eps(rho, zeta, a3);
+    D5 beta = 0.066725 * (1.0 + 0.1 * rs) / (1.0 + 0.1778 * rs);
+    D5 t2 = sg / (4.0 * (phi * phi) * ((4.0 / kPi) * kf) * (rho * rho));
+    D5 w1 = expm15(c5(0.0) - eps / (ScanC::gamma * phi3));
+    D5 A = beta / (ScanC::gamma * w1);
+    D5 g = 1.0 / p5(1.0 + 4.0 * (A * t2), 0.25);
+    D5 eps1 = eps + ScanC::gamma * phi3 * log1p5(w1 * (1.0 - g));
+    D5 e0 = c5(-ScanC::b1c) / (1.0 + ScanC::b2c * sqrt5(rs) + ScanC::b3c * rs);
+    D5 w0 = expm15(c5(0.0) - e0 / ScanC::b1c);
+    D5 ginf = 1.0 / p5(1.0 + (4.0 * ScanC::chi_inf) * s2, 0.25);
+    D5 z2 = zeta * zeta, z6 = z2 * z2 * z2;
+    D5 gc = (1.0 - ScanC::gcnst * (dxz - 1.0)) * (1.0 - z6 * z6);
+    D5 eps0 = (e0 + ScanC::b1c * log1p5(w0 * (1.0 - ginf))) * gc;
+    return rho * (eps1 + fc * (eps0 - eps1));
+}
+
+__global__ __launch_bounds__(256) void xc_mgga_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
+                                                          double *__restrict__ vgrad, double *__restrict__ vtau,
+                                                          const double *__restrict__ ru_, const double *__restrict__ rd_,
+                                                          const double *__restrict__ gu_, const double *__restrict__ gd_,
+                                                          const double *__restrict__ tu_, const double *__restrict__ td_, int n,
+                                                          XcTerms terms) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double ru = ru_[i], rd = rd_[i];
+        double gt[3];
+        for (int k = 0; k < 3; k++) gt[k] = gu_[(size_t)k * n + i] + gd_[(size_t)k * n + i];
+        double e = 0, dv[4] = {0, 0, 0, 0};
+        if (ru + rd > 1e-15) {
+            ru = fmax(ru, 0.5e-15);
+            rd = fmax(rd, 0.5e-15);
+            const double sig = fmax(gt[0] * gt[0] + gt[1] * gt[1] + gt[2] * gt[2], 1e-40), tk = fmax(tu_[i] + td_[i], 1e-20);
+            for (int t = 0; t < terms.n; t++) {
+                const D5 f = f_mgga_c_scan_pol(var5(ru, 0), var5(rd, 1), var5(sig, 2), var5(tk, 3));
+                e += terms.c[t] * f.v;
+                for (int k = 0; k < 4; k++) dv[k] += terms.c[t] * f.d[k];
+            }
+        }
+        if (edens) edens[i] = e;
+        if (vru) { vru[i] = dv[0]; vrd[i] = dv[1]; }
+        if (vgrad)
+            for (int k = 0; k < 3; k++) vgrad[(size_t)k * n + i] = 2.0 * dv[2] * gt[k];
+        if (vtau) vtau[i] = dv[3];
+    }
+}
+
 __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                                double *__restrict__ vtau, const double *__restrict__ rho,
                                const double *__restrict__ grho, const double *__restrict__ tau, int n, XcTerms terms) {
@@ -312,8 +428,9 @@ __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens
             const Dual dr = mk(r, 1.0, 0.0), ds = mk(sig, 0.0, 1.0);
             for (int t = 0; t < terms.n; t++) {
                 double fv, fr, fs, ft = 0.0;
-                if (terms.id[t] == DQC_XC_MGGA_X_SCAN) {
-                    D5 f = f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                if (terms.id[t] == DQC_XC_MGGA_X_SCAN || terms.id[t] == DQC_XC_MGGA_C_SCAN) {
+                    const D5 f = terms.id[t] == DQC_XC_MGGA_X_SCAN ? f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2))
+                                                                   : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
                     fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
                 } else {
                     Dual f;
@@ -353,7 +470,8 @@ extern "C" int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad
         t.id[i] = ids[i];
         t.c[i] = coefs[i];
         switch (ids[i]) {
-        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: case DQC_XC_MGGA_X_SCAN: break;
+        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: case DQC_XC_MGGA_X_SCAN:
+        case DQC_XC_MGGA_C_SCAN: break;
         default: set_error("dqc_xc_eval_mgga: unknown functional id"); return DQC_EINVAL;
         }
     }
@@ -392,6 +510,30 @@ extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(xc_pol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
                        d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_xc_eval_mgga_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad, double *d_vtau,
+                                    const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
+                                    const double *d_tau_u, const double *d_tau_d, int n, const int *ids, const double *coefs,
+                                    int nterm, void *stream) {
+    using namespace dqc;
+    if (nterm < 0 || nterm > 8) { set_error("dqc_xc_eval_mgga_pol: at most 8 functional terms"); return DQC_EINVAL; }
+    if (!d_grho_u || !d_grho_d || !d_tau_u || !d_tau_d) { set_error("dqc_xc_eval_mgga_pol: needs both density gradients and both tau"); return DQC_EINVAL; }
+    if ((d_vrho_u == nullptr) != (d_vrho_d == nullptr)) { set_error("dqc_xc_eval_mgga_pol: give both vrho outputs or none"); return DQC_EINVAL; }
+    XcTerms t;
+    t.n = nterm;
+    for (int i = 0; i < nterm; i++) {
+        t.id[i] = ids[i];
+        t.c[i] = coefs[i];
+        if (ids[i] != DQC_XC_MGGA_C_SCAN) { set_error("dqc_xc_eval_mgga_pol: only meta-GGA correlation ids (DQC_XC_MGGA_C_SCAN)"); return DQC_EINVAL; }
+    }
+    if (n <= 0) return DQC_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xc_mgga_pol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d, d_vgrad,
+                       d_vtau, d_rho_u, d_rho_d, d_grho_u, d_grho_d, d_tau_u, d_tau_d, n, t);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

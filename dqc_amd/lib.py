@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("DQC_AMD_LIB") or os.path.join(_HERE, "libdqc_amd.so")  # override: perf-bisection variants
 _lib = None
 
-XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130, "mgga_x_scan": 263}
+XC_IDS = {"lda_x": 1, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_c_pbe": 130, "mgga_x_scan": 263, "mgga_c_scan": 267}
 
 
 class DqcAmdError(RuntimeError):
@@ -70,6 +70,7 @@ def load():
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_xc_eval_mgga_pol.argtypes = [c_dp] * 11 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
@@ -399,6 +400,23 @@ def xc_eval_mgga(terms, rho, grho, tau, want_e=True, want_v=True):
         _check(load().dqc_xc_eval_mgga(_ptr(e), _ptr(v), _ptr(vg), _ptr(vt), _ptr(rho), _ptr(grho), _ptr(tau), n, ids, cfs,
                                        len(terms), st_), "dqc_xc_eval_mgga")
     return e, v, vg, vt
+
+
+def xc_eval_mgga_pol(terms, rho_u, rho_d, grho_u, grho_d, tau_u, tau_d, want_e=True, want_v=True):
+    """spin-polarised meta-GGA correlation terms -> edens, (vrho_u, vrho_d), vgrad (3,n) shared by both spins, vtau shared"""
+    n = rho_u.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    e = torch.empty_like(rho_u) if want_e else None
+    vu = torch.empty_like(rho_u) if want_v else None
+    vd = torch.empty_like(rho_u) if want_v else None
+    vg = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if want_v else None
+    vt = torch.empty_like(rho_u) if want_v else None
+    with _on(rho_u.device) as st_:
+        _check(load().dqc_xc_eval_mgga_pol(_ptr(e), _ptr(vu), _ptr(vd), _ptr(vg), _ptr(vt), _ptr(rho_u), _ptr(rho_d), _ptr(grho_u),
+                                           _ptr(grho_d), _ptr(tau_u), _ptr(tau_d), n, ids, cfs, len(terms), st_),
+               "dqc_xc_eval_mgga_pol")
+    return e, (vu, vd), vg, vt
 
 
 def grid_density_pair(ao_a, ao_b, nao, dm_pad):

@@ -11,7 +11,7 @@ import torch
 from . import lib
 from .utils.datastruct import ValGrad, SpinParam
 
-_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "mgga_x_scan": 4}
+_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "mgga_x_scan": 4, "mgga_c_scan": 4}
 
 
 class BaseXC:
@@ -64,19 +64,36 @@ class LibXC(BaseXC):
         """spin-polarised meta-GGA (libxc_wrapper.py polarised family-4 branch).  Exchange functionals obey the spin-scaling
         relation E_x[rho_u, rho_d] = 1/2 E_x[2 rho_u] + 1/2 E_x[2 rho_d], so mgga_x_* terms run through the unpolarised
         kernel on (2 rho_s, 2 grad rho_s, 2 tau_s); d e / d rho_s, d e / d grad rho_s, d e / d tau_s are then exactly the
-        kernel's outputs at the scaled arguments.  LDA / GGA terms go through the polarised kernel.  Returns
+        kernel's outputs at the scaled arguments.  mgga_c_* terms run through the polarised correlation kernel
+        (dqc_xc_eval_mgga_pol), LDA / GGA terms through the polarised LDA / GGA kernel.  Returns
         (edens, [ValGrad_u, ValGrad_d])"""
         mx = [(c, n) for c, n in self.terms if n.startswith("mgga_x_")]
+        mc = [(c, n) for c, n in self.terms if n.startswith("mgga_c_")]
         rest = [(c, n) for c, n in self.terms if _FAMILY[n] != 4]
-        if len(mx) + len(rest) != len(self.terms):
-            raise NotImplementedError("spin-polarised meta-GGA correlation functionals are not implemented")
         e, pots = 0.0, []
         for d in (densinfo.u, densinfo.d):
-            es, v, vg, vt = lib.xc_eval_mgga(mx, (2.0 * d.value).contiguous(), (2.0 * d.grad).contiguous(),
-                                             (2.0 * d.kin).contiguous(), want_e=want_e, want_v=want_v)
+            if mx:
+                es, v, vg, vt = lib.xc_eval_mgga(mx, (2.0 * d.value).contiguous(), (2.0 * d.grad).contiguous(),
+                                                 (2.0 * d.kin).contiguous(), want_e=want_e, want_v=want_v)
+                if want_e:
+                    e = e + 0.5 * es
+            else:
+                v = vg = vt = None
+            z = torch.zeros_like
+            pots.append(ValGrad(value=v if v is not None else z(d.value), grad=vg if vg is not None else z(d.grad), lapl=None,
+                                kin=vt if vt is not None else z(d.value)) if want_v else None)
+        if mc:  # correlation: the general polarised form (depends on rho_u, rho_d, |grad rho|^2, tau_u + tau_d)
+            u, d = densinfo.u, densinfo.d
+            ec, (vu, vd), vgc, vtc = lib.xc_eval_mgga_pol(mc, u.value.contiguous(), d.value.contiguous(), u.grad.contiguous(),
+                                                          d.grad.contiguous(), u.kin.contiguous(), d.kin.contiguous(),
+                                                          want_e=want_e, want_v=want_v)
             if want_e:
-                e = e + 0.5 * es
-            pots.append(ValGrad(value=v, grad=vg, lapl=None, kin=vt) if want_v else None)
+                e = e + ec
+            if want_v:
+                for p_, v_ in zip(pots, (vu, vd)):
+                    p_.value = p_.value + v_
+                    p_.grad = p_.grad + vgc
+                    p_.kin = p_.kin + vtc
         if rest:
             gga = max(_FAMILY[n] for _, n in rest) == 2
             gu = densinfo.u.grad.contiguous() if gga else None

@@ -105,6 +105,7 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
 #define DQC_XC_GGA_X_PBE 101
 #define DQC_XC_GGA_C_PBE 130
 #define DQC_XC_MGGA_X_SCAN 263
+#define DQC_XC_MGGA_C_SCAN 267
 int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
                 const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
                 void *stream);
@@ -118,10 +119,19 @@ int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double 
 
 /* meta-GGA variant (CalcMGGALibXCUnpol, dqc/xc/libxc_wrapper.py; inputs rho, grad rho, tau -- the supported
  * functionals do not depend on the laplacian, so vlapl = 0): adds d_vtau (n).  Terms may mix LDA/GGA ids with
- * DQC_XC_MGGA_X_SCAN. */
+ * DQC_XC_MGGA_X_SCAN and DQC_XC_MGGA_C_SCAN. */
 int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d_vtau, const double *d_rho,
                      const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
                      int nterm, void *stream);
+
+/* spin-polarised meta-GGA CORRELATION terms (CalcMGGALibXCPol, libxc_wrapper.py:221-378; DQC_XC_MGGA_C_SCAN): they depend
+ * on rho_u, rho_d, |grad(rho_u + rho_d)|^2 and tau_u + tau_d only, so vsigma = (v, 2 v, v) for (uu, ud, dd) and both spins
+ * share  d_vgrad (3,n) = 2 v grad(rho_u + rho_d)  (= 2 vsigma_ss grad_s + vsigma_ud grad_s', libxc.py:205-215) and
+ * d_vtau (n).  (Polarised meta-GGA EXCHANGE goes through dqc_xc_eval_mgga by the spin-scaling relation.) */
+int dqc_xc_eval_mgga_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad, double *d_vtau,
+                         const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
+                         const double *d_tau_u, const double *d_tau_d, int n, const int *ids, const double *coefs, int nterm,
+                         void *stream);
 
 /* ---- density-fitting integrals  (DFMol.build, dqc/df/dfmol.py:24-58) --------------------------
  * intor.coul2c(auxbw) = int2c2e_sph and intor.coul3c(basisw, basisw, auxbw) = int3c2e_sph

@@ -427,7 +427,82 @@ def mgga_x_scan(rho, sigma, tau):
     return z(e.v), z(e.d[0]), z(e.d[1]), z(e.d[2])
 
 
-_FUNCS_MGGA = {"mgga_x_scan": mgga_x_scan}
+# =====================================================================================================
+# SCAN correlation (mgga_c_scan): Sun, Ruzsinszky, Perdew, PRL 115, 036402 (2015), eqs. (9)-(17) and the supplementary
+# material, with libxc's constants (b1c, b2c, b3c, chi_infinity, beta(rs), the modified-PW92 LSDA part).  General
+# spin-polarised form in the four quantities it depends on -- rho_u, rho_d, sigma = |grad(rho_u + rho_d)|^2,
+# tau = tau_u + tau_d -- differentiated with dual arrays.  The reference reaches it through pylibxc
+# (dqc/xc/libxc.py:105-115, libxc_wrapper.py:221-378); no closed form or literal exists in the reference:
+# PARITY UNPINNED against libxc (as gga_c_pbe); pinned by its exact constraints (uniform gas, one-electron
+# limit, spin symmetry) and finite differences in tests/.
+# =====================================================================================================
+_SCAN_C = dict(b1c=0.0285764, b2c=0.0889, b3c=0.125541, c1c=0.64, c2c=1.5, dc=0.7, chi_inf=0.12802585262625815,
+               gcnst=2.3631, gamma=0.031090690869654895)
+
+
+def _scan_c_energy(u, d, sg, ta):
+    """rho * eps_c as a Dual; u, d, sg, ta: Duals of rho_u, rho_d, sigma_total, tau_total"""
+    c = _SCAN_C
+    rho, zeta = _safe_zeta(u, d)
+    rs = ((3.0 / (4.0 * np.pi)) / rho).pow(1.0 / 3)
+    kf = ((3.0 * np.pi ** 2) * rho).pow(1.0 / 3)
+    s2 = sg / (4.0 * kf * kf * rho * rho)                     # reduced gradient squared (total density)
+    phi = 0.5 * ((1.0 + zeta).pow(2.0 / 3) + (1.0 - zeta).pow(2.0 / 3))
+    phi3 = phi * phi * phi
+    dx = 0.5 * ((1.0 + zeta).pow(4.0 / 3) + (1.0 - zeta).pow(4.0 / 3))
+    ds = 0.5 * ((1.0 + zeta).pow(5.0 / 3) + (1.0 - zeta).pow(5.0 / 3))
+    # ---- alpha and the switching function
+    tau_w = sg / (8.0 * rho)
+    tau_unif = 0.3 * (kf * kf) * rho * ds
+    alpha = (ta - tau_w) / tau_unif
+    av = alpha.v
+    near1 = np.abs(1.0 - av) < 1e-12
+    al = Dual(np.where(near1, 0.5, av), alpha.d)
+    om = 1.0 - al
+    f_lo = _dexp((-c["c1c"]) * al / om)
+    f_hi = (-c["dc"]) * _dexp(c["c2c"] / om)
+    sel = lambda a, b: np.where(near1, 0.0, np.where(av < 1.0, a, b))  # noqa: E731
+    fc = Dual(sel(f_lo.v, f_hi.v), [sel(p_, q_) for p_, q_ in zip(f_lo.d, f_hi.d)])
+    # ---- eps_c^1: PBE-like with beta(rs) and g(A t^2) = (1 + 4 A t^2)^(-1/4)
+    eps_lsda = _pw92_pol_eps(rho, zeta, _PW_A_MOD3)
+    beta = 0.066725 * (1.0 + 0.1 * rs) / (1.0 + 0.1778 * rs)
+    t2 = sg / (4.0 * phi * phi * ((4.0 / np.pi) * kf) * rho * rho)
+    w1 = (-eps_lsda / (c["gamma"] * phi3)).expm1()
+    A = beta / (c["gamma"] * w1)
+    g = 1.0 / (1.0 + 4.0 * A * t2).pow(0.25)
+    eps1 = eps_lsda + c["gamma"] * phi3 * (w1 * (1.0 - g)).log1p()
+    # ---- eps_c^0: the alpha = 0 (single-orbital) limit
+    eps_lda0 = (-c["b1c"]) / (1.0 + c["b2c"] * rs.sqrt() + c["b3c"] * rs)
+    w0 = (-eps_lda0 / c["b1c"]).expm1()
+    ginf = 1.0 / (1.0 + 4.0 * c["chi_inf"] * s2).pow(0.25)
+    h0 = c["b1c"] * (w0 * (1.0 - ginf)).log1p()
+    z2 = zeta * zeta
+    z12 = (z2 * z2 * z2) * (z2 * z2 * z2)
+    gc = (1.0 - c["gcnst"] * (dx - 1.0)) * (1.0 - z12)
+    eps0 = (eps_lda0 + h0) * gc
+    return rho * (eps1 + fc * (eps0 - eps1))
+
+
+def mgga_c_scan_pol(ru, rd, sigma, tau):
+    """-> e (= rho eps_c), (d/drho_u, d/drho_d), d/dsigma_total, d/dtau_total.  In libxc's polarised outputs
+    vsigma = (d, 2 d, d)/dsigma_total for (uu, ud, dd) and vtau_u = vtau_d = d/dtau_total."""
+    mask, ru_, rd_ = _masked(ru, rd)
+    sg_ = np.where(mask, np.maximum(np.asarray(sigma, float), 1e-40), 1.0)
+    ta_ = np.where(mask, np.maximum(np.asarray(tau, float), 1e-20), 1.0)
+    u, d, sg, ta = (Dual.var(x, i, 4) for i, x in enumerate((ru_, rd_, sg_, ta_)))
+    e = _scan_c_energy(u, d, sg, ta)
+    z = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+    return z(e.v), (z(e.d[0]), z(e.d[1])), z(e.d[2]), z(e.d[3])
+
+
+def mgga_c_scan(rho, sigma, tau):
+    """unpolarised: E[rho/2, rho/2]; d/drho = (d_u + d_d)/2 -> e, vrho, vsigma, vtau"""
+    rho = np.asarray(rho, float)
+    e, (vu, vd), vs, vt = mgga_c_scan_pol(0.5 * rho, 0.5 * rho, sigma, tau)
+    return e, 0.5 * (vu + vd), vs, vt
+
+
+_FUNCS_MGGA = {"mgga_x_scan": mgga_x_scan, "mgga_c_scan": mgga_c_scan}
 
 
 class XCM(XC):

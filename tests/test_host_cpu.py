@@ -126,8 +126,9 @@ def test_xc_parser():
     y = dqc_amd.get_xc("lda_x") + dqc_amd.get_xc("gga_x_pbe") * 2
     assert y.terms == [(1.0, "lda_x"), (2.0, "gga_x_pbe")]
     assert dqc_amd.get_xc("mgga_x_scan + gga_c_pbe").family == 4
+    assert dqc_amd.get_xc("mgga_x_scan + mgga_c_scan").family == 4
     with pytest.raises(ValueError):
-        dqc_amd.get_xc("mgga_c_scan")  # not in the kernel set: loud, no fallback
+        dqc_amd.get_xc("mgga_c_tpss")  # not in the kernel set: loud, no fallback
     assert dqc_amd.get_xc(None).terms == []
 
 

@@ -446,3 +446,40 @@ def test_listed_shell_quartets_equal_the_packed_tensor():
     for (i, j, k, l), b in zip(q, nat.int2e_quartets(t, q)):
         ref = full[al[i]:al[i + 1], al[j]:al[j + 1], al[k]:al[k + 1], al[l]:al[l + 1]]
         assert np.abs(ref - b).max() < 1e-14
+
+
+def test_scan_correlation_oracle_constraints_and_derivatives():
+    """oracle mgga_c_scan (no literal exists in the reference: parity against libxc is unpinned, see oracle/xc.py): the exact
+    constraints SCAN correlation was built on -- uniform-gas limit = modified PW92 for every zeta, no one-electron
+    self-correlation (zeta = 1, alpha = 0), spin symmetry -- and the dual-number derivatives against central differences"""
+    import numpy as np
+    from oracle import xc as ox
+    rng = np.random.default_rng(0)
+    n = 500
+    ru = np.exp(rng.uniform(-6, 2, n))
+    rd = ru * np.exp(rng.uniform(-2, 2, n))
+    rho = ru + rd
+    sg = (rho ** (4 / 3) * np.exp(rng.uniform(-3, 1, n))) ** 2
+    ta = sg / (8 * rho) * (1 + np.exp(rng.uniform(-2, 2, n)))
+    e, (vu, vd), vs, vt = ox.mgga_c_scan_pol(ru, rd, sg, ta)
+    x0 = [ru, rd, sg, ta]
+    for k, an in enumerate((vu, vd, vs, vt)):
+        h = 1e-5 * x0[k]
+        xp, xm = [a.copy() for a in x0], [a.copy() for a in x0]
+        xp[k] += h
+        xm[k] -= h
+        fd = (ox.mgga_c_scan_pol(*xp)[0] - ox.mgga_c_scan_pol(*xm)[0]) / (2 * h)
+        assert np.max(np.abs(fd - an) / (np.abs(an) + 1e-6 * np.abs(e / x0[k]))) < 2e-3, k
+    e2, (vu2, vd2), _, _ = ox.mgga_c_scan_pol(rd, ru, sg, ta)
+    assert np.abs(e - e2).max() == 0 and np.abs(vu - vd2).max() == 0
+    r, z = np.exp(rng.uniform(-5, 2, 50)), rng.uniform(-0.9, 0.9, 50)
+    ds = 0.5 * ((1 + z) ** (5 / 3) + (1 - z) ** (5 / 3))
+    eu = ox.mgga_c_scan_pol(r * (1 + z) / 2, r * (1 - z) / 2, np.full(50, 1e-30), 0.3 * (3 * np.pi ** 2 * r) ** (2 / 3) * r * ds)[0]
+    R, Z = ox.Dual.var(r, 0, 1), ox.Dual(z, [np.zeros_like(z)])
+    assert np.abs(eu - r * ox._pw92_pol_eps(R, Z, ox._PW_A_MOD3).v).max() < 1e-14
+    s1 = (r ** (4 / 3)) ** 2 * rng.uniform(0.1, 3, 50)
+    assert np.abs(ox.mgga_c_scan_pol(r, np.zeros(50), s1, s1 / (8 * r))[0] / r).max() < 1e-9
+    # unpolarised wrapper = polarised at zeta = 0
+    eu, vr, vsu, vtu = ox.mgga_c_scan(rho, sg, ta)
+    ep, (a, b), c, d = ox.mgga_c_scan_pol(rho / 2, rho / 2, sg, ta)
+    assert np.array_equal(eu, ep) and np.allclose(vr, a) and np.array_equal(vsu, c) and np.array_equal(vtu, d)
