@@ -15,6 +15,8 @@
 // 4x4 patch rows 4(t/16).., cols 4(t%16).. (16-byte loads, 512-byte rows per 16 lanes).  J needs row sums
 // (16-lane DPP reduce) and column sums (2 shuffles + a 4-wave LDS combine).  For K the patch is parked in
 // LDS (row stride 65) and the four contractions re-read it with output-major lane mappings.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace dqc {
@@ -348,6 +350,93 @@ __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Coulomb only (the Kohn-Sham Fock build), one density: every block streams a CONTIGUOUS range of tiles.  Tiles are ordered
+// T = IJ (IJ + 1) / 2 + KL, so consecutive tiles share the bra block pair IJ: the row sums  J[I,J] += g . D[K,L]  stay in
+// registers (per thread, un-reduced) until IJ changes and only then take the 16-lane reduce and their 64 atomics -- half
+// of the kernel's fp64 atomics (7.9 M per 20-atom molecule, device scope: each one is a trip to the memory side) and the
+// same-address contention of concurrently running neighbouring blocks (grid-stride order made them all hit J[I,J] at once)
+// disappear; D[I,J] is reloaded only when IJ changes.  The column sums J[K,L] += g . D[I,J] change target every tile and
+// keep the 2-shuffle + 4-wave LDS combine of jk_tiles_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ tiles, double *__restrict__ work, int npad,
+                                                         long long ntiles, long long per_block) {
+    __shared__ double s_col[2][4][64];
+    const size_t n2 = (size_t)npad * npad;
+    const double *Dp = work;
+    double *Jacc = work + n2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+    const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
+    const long long T0 = (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
+    if (T0 >= T1) return;
+    int IJ, KL, I, J, K, L;
+    decode_tri(T0, IJ, KL);
+    decode_tri(IJ, I, J);
+    double rsacc[4] = {0, 0, 0, 0}, dij[4];
+    {
+        const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+    }
+    auto flush_rows = [&]() {
+        const double fI = (I == J ? 0.5 : 1.0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = rsacc[r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if ((lane & 15) == 0) atomicAdd(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * fI * v);
+            rsacc[r] = 0.0;
+        }
+    };
+    int par = 0;
+    for (long long T = T0; T < T1; T++, KL++) {
+        if (KL > IJ) {  // next bra block pair
+            flush_rows();
+            IJ++;
+            KL = 0;
+            decode_tri(IJ, I, J);
+            const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+        }
+        decode_tri(KL, K, L);
+        // factors of the unique-tile weights: (I == J) is applied at the flush, (K == L) and (IJ == KL) here
+        const double fk = (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const double *tp = tiles + (size_t)T * DQC_TILE_SZ;
+        const double *dklp = Dp + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
+        double dkl[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) dkl[q] = fk * dklp[q];
+        double cs[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double2 a = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0);
+            const double2 b = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0 + 2);
+            const double g0 = a.x, g1 = a.y, g2 = b.x, g3 = b.y;
+            rsacc[r] += g0 * dkl[0] + g1 * dkl[1] + g2 * dkl[2] + g3 * dkl[3];
+            cs[0] += g0 * dij[r]; cs[1] += g1 * dij[r]; cs[2] += g2 * dij[r]; cs[3] += g3 * dij[r];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double v = cs[c];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            cs[c] = v;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_col[par][wave][c0 + c] = cs[c];
+        }
+        __syncthreads();  // one barrier per tile: s_col is double-buffered
+        if (t < 64) {
+            const double v = s_col[par][0][t] + s_col[par][1][t] + s_col[par][2][t] + s_col[par][3][t];
+            atomicAdd(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * (I == J ? 0.5 : 1.0) * fk * v);
+        }
+        par ^= 1;
+    }
+    flush_rows();
+}
+
 }  // namespace dqc
 
 extern "C" {
@@ -368,10 +457,17 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     hipLaunchKernelGGL(jk_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dm, nao, npad, with_k);
     DQC_CHECK_LAUNCH();
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 256 * 16);
-    if (with_k)
+    static const char *jimpl = getenv("DQC_J_IMPL");  // "stride": the grid-stride kernel of round 1 (A/B runs)
+    if (with_k) {
         hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles);
-    else
+    } else if (jimpl && jimpl[0] == 's') {
         hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles);
+    } else {
+        // contiguous tile ranges: ~6 resident blocks per CU x 2 rounds
+        const long long nblk = std::min<long long>(ntiles, 256 * 12);
+        const long long per = (ntiles + nblk - 1) / nblk;
+        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, per);
+    }
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad);
     DQC_CHECK_LAUNCH();

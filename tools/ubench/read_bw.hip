@@ -41,6 +41,17 @@ __global__ __launch_bounds__(256) void tile(const v2d *__restrict__ buf, long lo
     if (s == 1.2345) out[0] = s;
 }
 
+__global__ void fill_random(double *buf, size_t n, int kind) {
+    // kind 1: uniform random mantissas in [-1, 1) (the round-1 probe's data);  kind 2: ERI-like (mostly tiny magnitudes)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = i * 6364136223846793005ull + 1442695040888963407ull;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33;
+        double u = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+        if (kind == 2) { const double m = (double)((x >> 3) & 0xff) / 255.0; u *= exp(-30.0 * m * m); }
+        buf[i] = u;
+    }
+}
+
 template <typename F>
 static double timeit(F f, int reps) {
     hipEvent_t a, b;
@@ -59,10 +70,14 @@ static double timeit(F f, int reps) {
 int main() {
     double *out;
     hipMalloc(&out, 8);
+    for (int kind = 0; kind < 3; kind++)
     for (size_t bytes : {(size_t)4 << 30, (size_t)96 << 20}) {
+        if (kind > 0 && bytes < ((size_t)1 << 30)) continue;
         double *buf;
         hipMalloc(&buf, bytes);
-        hipMemset(buf, 0, bytes);
+        if (kind == 0) hipMemset(buf, 0, bytes);
+        else hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, buf, bytes / 8, kind);
+        printf("data kind %d (0 zeros, 1 random, 2 mostly-tiny random)\n", kind);
         const size_t n2 = bytes / 16;
         const long long ntile = bytes / 32768;
         const int reps = bytes > ((size_t)1 << 30) ? 5 : 200;
