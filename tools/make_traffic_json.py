@@ -10,8 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import source_sha16  # noqa: E402
 
-KEYS = [("grid_fused", "fused_grid_kernel"), ("jk_tiles", "jk_tiles_kernel"), ("grid_density", "density_lr_kernel"),
-        ("grid_density_dense", "density_kernel"), ("grid_vxc", "vxc_ws_kernel"), ("grid_vxc_ws2", "vxc_ws2_kernel")]
+KEYS = [("grid_fused", ("fused_grid_kernel",)), ("jk_tiles", ("j_stream_kernel", "jk_tiles_kernel")),
+        ("grid_density", ("density_lr_kernel",)), ("grid_density_dense", ("density_kernel",)),
+        ("grid_vxc", ("vxc_wsu_kernel", "vxc_ws_kernel")), ("grid_vxc_ws2", ("vxc_ws2_kernel",))]
 
 
 def main():
@@ -22,8 +23,8 @@ def main():
         m = re.search(r"FETCH_SIZE\s+n=(\d+)\s+avg=([0-9.e+-]+)", ln)
         if not m:
             continue
-        for key, sub in KEYS:
-            if sub in ln and key not in out:
+        for key, subs in KEYS:
+            if any(sub in ln for sub in subs) and key not in out:
                 # FETCH_SIZE is in KB and, on gfx950, reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section)
                 out[key] = int(float(m.group(2)) * 1024 * 2)
                 break
