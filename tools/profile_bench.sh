@@ -19,3 +19,7 @@ python $repo/tools/pmc_summary.py $(find /tmp/prof_w -name '*.db' | head -1) WRI
 rocprofv3 --kernel-trace --pmc MfmaUtil -d /tmp/prof_m -- python $repo/bench.py --profile-mode --molecules 4 --steps 3 --warmup 1 --min-seconds 0 > /dev/null 2> /tmp/m.err
 python $repo/tools/pmc_summary.py $(find /tmp/prof_m -name '*.db' | head -1) MfmaUtil > $out/${tag}_pmc_MfmaUtil_bench_steps3.txt 2>&1
 head -12 $out/${tag}_kernel_stats_bench_steps10.txt; head -6 $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt; cat $out/${tag}_pmc_traffic.json
+# per-shape kernel times by the profiler: the shape sweep under the kernel trace
+rm -rf /tmp/prof_sw
+rocprofv3 --kernel-trace --stats -d /tmp/prof_sw -- python $repo/tools/shape_sweep.py $out/${tag}_shape_sweep_events.txt > /dev/null 2> /tmp/sw.err
+python $repo/tools/rocpd_summary.py $(find /tmp/prof_sw -name '*.db' | head -1) | grep -E "kernel|vxc|density" | head -40 > $out/${tag}_shape_sweep_rocprof.txt 2>&1
