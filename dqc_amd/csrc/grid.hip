@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "xc_funcs.hpp"
 
 namespace dqc {
 
@@ -1144,13 +1145,14 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int VWU_PROD = 256, VWU_NT = 512 + VWU_PROD;
 
-template <int MAXT, int NTL, bool TWO, int D = 2>
+template <int MAXT, int NTL, bool TWO, int D = 2, int KG0 = 0, int NKG = 4>
 __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsigned (&pj)[MAXT], v4d (&acc)[MAXT]) {
-    // NTL <= MAXT: tiles actually looped over (waves that own one tile fewer skip the dummy MFMAs)
-    constexpr int H = TWO ? 2 : 1, NS = 4 * NTL * H;
+    // NTL <= MAXT: tiles actually looped over (waves that own one tile fewer skip the dummy MFMAs);
+    // k-groups KG0 .. KG0 + NKG - 1 of the 16-point chunk (the fused kernel runs a chunk in two halves)
+    constexpr int H = TWO ? 2 : 1, NS = NKG * NTL * H;
     double fa[D + 1], fb[D + 1];
     auto rd = [&](int s) {
-        const int kk = s / (NTL * H), t = (s % (NTL * H)) / H, h = s % H;
+        const int kk = KG0 + s / (NTL * H), t = (s % (NTL * H)) / H, h = s % H;
         // h = 0: A = Phi_i, B = Psi_j;   h = 1: A = Psi_i, B = Phi_j
         fa[s % (D + 1)] = *(lds_cdouble_t *)(pi[t] + (kk * VWS_GS + (h ? VWS_XS : 0)) * 8);
         fb[s % (D + 1)] = *(lds_cdouble_t *)(pj[t] + (kk * VWS_GS + (h ? 0 : VWS_XS)) * 8);
@@ -1304,6 +1306,299 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
             //   GGA: acc = 2 V -> off-diagonal tiles store acc (-> acc / 2 = V), diagonal tiles acc / 2 (already symmetric)
             //   one operand: acc = V -> off-diagonal tiles 2 acc, diagonal tiles acc
             const double sc = (GGA ? 1.0 : 2.0) * (ti != tj ? 1.0 : 0.5);
+#pragma unroll
+            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FUSED grid pass (restricted GGA / LDA-type functionals, density matrix in factor form, 145 <= nao <= 208):
+//     rho, grad rho  ->  XC potentials  ->  Vxc matrix      from ONE read of the AO matrix.
+// Reference: HamiltonCGTO.get_vxc = _dm2densinfo -> xc.get_vxc -> _get_vxc_from_potinfo (hcgto.py:260-269, 371-495).
+// The block is vxc_wsu_kernel's: 8 consumer waves own the upper-triangular tiles of V and run a chunk's MFMAs in two
+// halves (k-groups 0-1, 2-3); all that is new lives in the 4 producer waves (one per SIMD), which used to idle during the
+// MFMA phases.  Per 16-point chunk c (consumers on chunk c, producers one chunk ahead):
+//   phase A  consumers: V += (chunk c, k-groups 0, 1)        producers: wait for the loads of chunk c+1, Phi(c+1) -> LDS
+//   phase B  consumers: V += (chunk c, k-groups 2, 3)        producers: density GEMMs of chunk c+1 on the matrix pipe
+//            D1  A'^T = L^T Phi^T   (K = nao split over the 4 producer waves, partial tiles summed with ds_add_f64)
+//            D2  B = A' L^T         (column tiles dealt to the producers, written into the Psi slot of the next buffer)
+//   window   consumers wait                                  producers: row dots rho = B.Phi, grad rho = 2 B.dPhi with the
+//            gradient components still in their registers, the functional at the row's point (every lane of a 16-lane row
+//            group evaluates it: no exchange), Psi(c+1) = w (vrho Phi + 4 vsigma grad rho . dPhi) over B, loads of chunk c+2
+// L and L^T fragments come straight from L2 (80 KB each, shared by all blocks); the A' tiles pass between D1 and D2 through
+// 2 KB x NRT of LDS in MFMA fragment order (the transposed-GEMM trick of density_lr_kernel: D1's accumulator registers ARE
+// D2's A fragments).  Between D1 and D2 only the producers synchronise (an LDS counter; the consumers are mid-burst).
+// An fp64 MFMA occupies the vector ALU of its SIMD, so the producers' VALU work is confined to the window.
+// ---------------------------------------------------------------------------------------------
+constexpr int FG_ABUF = 16 * 64;   // doubles: A' fragments, [4 NRT][64 lanes], NRT <= 4
+
+#ifdef FG_TRACE  // per-phase timeline of block 0 (100 MHz ticks): role 0 = consumer wave 0, role 1 = producer wave 8
+constexpr int FG_TRACE_N = 8 * 64;
+__device__ long long g_fg_trace[2 * FG_TRACE_N];
+#define FG_STAMP(role, slot) \
+    if (blockIdx.x == 0 && lane == 0 && (slot) < FG_TRACE_N) g_fg_trace[(role) * FG_TRACE_N + (slot)] = wall_clock64()
+#else
+#define FG_STAMP(role, slot)
+#endif
+
+DQC_DEV void fg_prod_sync(int *cnt, int &epoch) {  // barrier among the 4 producer waves only
+    epoch += 4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// XCS: functional set evaluated in the window -- 1: terms 0, 1 are (gga_x_pbe, gga_c_pbe), 2: (lda_x, lda_c_pw), 0: any list (the
+// generic evaluator keeps all four functionals' duals live: 121 VGPRs on top of the chunk's gradient registers -> scratch)
+template <int MAXT, int NLP, int NRT, int XCS>
+__global__ __launch_bounds__(VWU_NT, 3) void fused_grid_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
+                                                              int ld, const double *__restrict__ w,
+                                                              const double *__restrict__ orb, const double *__restrict__ orbt,
+                                                              int slab, XcTerms terms, double *__restrict__ rho_out,
+                                                              double *__restrict__ grho_out, double *__restrict__ exc_out) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int KCH = 16, RP = 16 * NRT;
+    const int LS = ld;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const size_t cs = (size_t)ngrid * ld;
+    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int nchunk = (ge - gs + KCH - 1) / KCH;
+    double *abuf = lds + 2 * VWS_BUF;
+    int *pcnt = (int *)(abuf + FG_ABUF);
+    if (tid == 0) *pcnt = 0;
+
+    if (wave >= VXC_WAVES) {
+        // ------------------------------------------------------------------ producers
+        constexpr int TPR = VWU_PROD / KCH;  // 16 threads per chunk row
+        const int pt = tid - 512, pw = wave - VXC_WAVES;
+        const int prow = pt / TPR, pcol = pt % TPR;
+        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+        unsigned wlds = lds0 + 8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);  // Phi slot, buffer 0
+        typedef double vd2 __attribute__((ext_vector_type(2)));
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        constexpr int BUF_FLAGS = 0x00020000;
+        v4u raw[NLP][3];   // the three gradient components of the chunk one ahead: held from their load to its Psi combine
+        v4u rphi[NLP];     // its Phi: only from the load to the staging (the window re-reads Phi from LDS)
+        double wg = 0.0, exc_acc = 0.0;
+        int epoch = 0;
+        auto as_d = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+        auto prefetch = [&](int c) __attribute__((always_inline)) {
+            const int g0 = gs + c * KCH;
+            const int rows = ge - g0;
+            auto rsrc = [&](const double *base, size_t bytes) {
+                return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, BUF_FLAGS);
+            };
+            const v2u xw = __builtin_amdgcn_raw_buffer_load_b64(rsrc(w + g0, (size_t)rows * 8), prow * 8, 0, 0);
+            wg = as_d(xw[0], xw[1]);
+            const size_t nb = (size_t)rows * ld * 8;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
+#pragma unroll
+                for (int i = 0; i < NLP; i++)
+                    if ((pcol + i * TPR) * 2 < ld) {
+                        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
+                        if (d == 0) rphi[i] = x;
+                        else raw[i][d - 1] = x;
+                    }
+            }
+        };
+        auto stage_phi = [&]() __attribute__((always_inline)) {  // Phi of the chunk in the registers -> Phi slot of the buffer wlds points into
+#pragma unroll
+            for (int i = 0; i < NLP; i++)
+                if ((pcol + i * TPR) * 2 < ld) *(__attribute__((address_space(3))) v4u *)(wlds + i * TPR * 16) = rphi[i];
+        };
+        auto zero_abuf = [&]() __attribute__((always_inline)) {
+            for (int e = pt; e < 4 * NRT * 64; e += VWU_PROD) abuf[e] = 0.0;
+        };
+        // density GEMMs of the chunk whose Phi sits in buffer `nbuf`
+        auto density = [&](int nbuf) __attribute__((always_inline)) {
+            const double *phi = lds + nbuf * VWS_BUF;
+            {   // D1: a1[t][q] = A'^T[r = 16 t + 4 q + lk][pt = lr], K range of this wave
+                const int nk = ld >> 2, per = (nk + 3) >> 2;
+                const int s0 = pw * per, s1 = min(s0 + per, nk);
+                v4d a1[NRT];
+#pragma unroll
+                for (int t = 0; t < NRT; t++) a1[t] = v4d{0, 0, 0, 0};
+                const double *bp = phi + (lr >> 2) * VWS_GS + (lr & 3) * LS + lk;          // Phi[pt = lr][ao = 4 s + lk]
+                const double *ap = orb + (size_t)lk * RP + lr;                             // L[ao = 4 s + lk][r = 16 t + lr]
+#pragma unroll 4
+                for (int s_ = s0; s_ < s1; s_++) {
+                    const double bv = bp[4 * s_];
+#pragma unroll
+                    for (int t = 0; t < NRT; t++) a1[t] = mfma_f64(ap[(size_t)s_ * 4 * RP + 16 * t], bv, a1[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < NRT; t++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) atomicAdd(&abuf[(4 * t + q) * 64 + lane], a1[t][q]);  // ds_add_f64
+            }
+            fg_prod_sync(pcnt, epoch);
+            {   // D2: B[pt][16 j + ..] = sum_r A'[pt][r] L[ao][r]; column tiles j = pw, pw + 4, ...
+                double af[4 * NRT];
+#pragma unroll
+                for (int s_ = 0; s_ < 4 * NRT; s_++) af[s_] = abuf[s_ * 64 + lane];
+                const int T = ld >> 4;
+                double *bout = lds + nbuf * VWS_BUF + VWS_XS + lk * LS + lr;              // B[pt = lk + 4 q][col]: + q GS + 16 j
+                const double *lp = orbt + (size_t)lk * ld + lr;                           // L^T[r = 4 s + lk][ao = 16 j + lr]
+                for (int j = pw; j < T; j += 4) {
+                    v4d acc = v4d{0, 0, 0, 0};
+#pragma unroll
+                    for (int s_ = 0; s_ < 4 * NRT; s_++) acc = mfma_f64(af[s_], lp[(size_t)s_ * 4 * ld + 16 * j], acc);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) bout[q * VWS_GS + 16 * j] = acc[q];
+                }
+            }
+            fg_prod_sync(pcnt, epoch);
+        };
+        // row dots + functional + Psi for the chunk in the registers (its B tiles in the Psi slot wlds + XS); g0: first point
+        auto window = [&](int g0) __attribute__((always_inline)) {
+            double s0_ = 0, s1_ = 0, s2_ = 0, s3_ = 0;
+#pragma unroll
+            for (int i = 0; i < NLP; i++) {
+                if ((pcol + i * TPR) * 2 < ld) {
+                    const vd2 b = *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16 + VWS_XS * 8);
+                    const vd2 ph = *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16);
+                    s0_ += b.x * ph.x + b.y * ph.y;
+                    s1_ += b.x * as_d(raw[i][0][0], raw[i][0][1]) + b.y * as_d(raw[i][0][2], raw[i][0][3]);
+                    s2_ += b.x * as_d(raw[i][1][0], raw[i][1][1]) + b.y * as_d(raw[i][1][2], raw[i][1][3]);
+                    s3_ += b.x * as_d(raw[i][2][0], raw[i][2][1]) + b.y * as_d(raw[i][2][2], raw[i][2][3]);
+                }
+            }
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) {
+                s0_ += __shfl_xor(s0_, m); s1_ += __shfl_xor(s1_, m); s2_ += __shfl_xor(s2_, m); s3_ += __shfl_xor(s3_, m);
+            }
+            const double rho = s0_, gx = 2.0 * s1_, gy = 2.0 * s2_, gz = 2.0 * s3_;
+            const double sigma = gx * gx + gy * gy + gz * gz;
+            double e = 0.0, vr = 0.0, vs = 0.0;
+            if (XCS == 0) {
+                xc_point(terms, rho, sigma, e, vr, vs);
+            } else if (rho > 1e-15) {  // (the density threshold of xc_point)
+                const Dual dr = mk(rho, 1.0, 0.0), ds = mk(sigma, 0.0, 1.0);
+                const Dual f = XCS == 1 ? terms.c[0] * f_gga_x_pbe(dr, ds) + terms.c[1] * f_gga_c_pbe(dr, ds)
+                                        : terms.c[0] * f_lda_x(dr) + terms.c[1] * f_lda_c_pw(dr);
+                e = f.v; vr = f.r; vs = f.s;
+            }
+            if (pcol == 0 && g0 + prow < ge) {
+                exc_acc += wg * e;
+                if (rho_out) rho_out[g0 + prow] = rho;
+                if (grho_out) {
+                    grho_out[g0 + prow] = gx;
+                    grho_out[(size_t)ngrid + g0 + prow] = gy;
+                    grho_out[2 * (size_t)ngrid + g0 + prow] = gz;
+                }
+            }
+            // Psi = w (vrho Phi + sum_d 2 vgrad_d dPhi_d), vgrad = 2 vsigma grad rho  (hcgto.py:466, libxc.py:239)
+            const double c0 = wg * vr, c4 = 4.0 * wg * vs;
+            const double c1 = c4 * gx, c2 = c4 * gy, c3 = c4 * gz;
+#pragma unroll
+            for (int i = 0; i < NLP; i++) {
+                if ((pcol + i * TPR) * 2 < ld) {
+                    const vd2 ph = *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16);
+                    vd2 ps = {c0 * ph.x, c0 * ph.y};
+                    ps.x += c1 * as_d(raw[i][0][0], raw[i][0][1]); ps.y += c1 * as_d(raw[i][0][2], raw[i][0][3]);
+                    ps.x += c2 * as_d(raw[i][1][0], raw[i][1][1]); ps.y += c2 * as_d(raw[i][1][2], raw[i][1][3]);
+                    ps.x += c3 * as_d(raw[i][2][0], raw[i][2][1]); ps.y += c3 * as_d(raw[i][2][2], raw[i][2][3]);
+                    *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16 + VWS_XS * 8) = ps;
+                }
+            }
+        };
+        // ---- prologue: chunk 0 entirely (the consumers wait)
+        prefetch(0);
+        zero_abuf();
+        stage_phi();
+        __syncthreads();                 // (P0) pcnt = 0, abuf zeroed, Phi(0) staged -- for the producers themselves
+        density(0);
+        window(gs);
+        if (nchunk > 1) prefetch(1);
+        __syncthreads();                 // (P1) buffer 0 complete: the consumers start
+        for (int c = 0; c < nchunk; c++) {
+            const bool more = c + 1 < nchunk;
+            wlds += (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // slots of buffer (c + 1) & 1
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 0);
+            // phase A (consumers: first half of chunk c): Phi(c+1) -> LDS as soon as its loads have landed
+            if (more) { zero_abuf(); stage_phi(); }
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 1);
+            __syncthreads();             // (Ba)
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 2);
+            // phase B (consumers: second half of chunk c): density GEMMs of chunk c+1 on the matrix pipe
+            if (more) density((c + 1) & 1);
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 3);
+            __syncthreads();             // (Bb) the consumers have finished chunk c and wait
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 4);
+            if (more) {
+                window(gs + (c + 1) * KCH);
+                if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 5);
+                if (c + 2 < nchunk) prefetch(c + 2);
+            }
+            if (wave == VXC_WAVES) FG_STAMP(1, 8 * c + 6);
+            __syncthreads();             // (Bc)
+        }
+        if (exc_out) {
+            double v = exc_acc;
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) v += __shfl_xor(v, m);
+            if (lane == 0) atomicAdd(exc_out, v);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: upper-triangular tiles (vxc_wsu_kernel)
+    const int T = ld >> 4, ttot = T * (T + 1) / 2;
+    auto tile_ij = [&](int u, int &ti, int &tj) {
+        int i = 0, rem = u;
+        while (rem >= T - i) { rem -= T - i; i++; }
+        ti = i;
+        tj = i + rem;
+    };
+    const int tbase = ttot / VXC_WAVES, trem = ttot % VXC_WAVES;
+    const int nt = tbase + (wave < trem ? 1 : 0);
+    const int t0 = wave * tbase + min(wave, trem);
+    v4d acc[MAXT];
+    unsigned pi[MAXT], pj[MAXT];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        int ti, tj;
+        tile_ij(min(t0 + min(t, max(nt - 1, 0)), ttot - 1), ti, tj);
+        pi[t] = lds0 + 8u * (unsigned)(lk * LS + ti * 16 + lr);
+        pj[t] = lds0 + 8u * (unsigned)(lk * LS + tj * 16 + lr);
+    }
+    __syncthreads();  // (P0)
+    __syncthreads();  // (P1)
+    for (int c = 0; c < nchunk; c++) {
+        if (wave == 0) FG_STAMP(0, 8 * c + 0);
+        if (nt == MAXT) wsu_chunk<MAXT, MAXT, true, 2, 0, 2>(pi, pj, acc);
+        else wsu_chunk<MAXT, MAXT - 1, true, 2, 0, 2>(pi, pj, acc);
+        if (wave == 0) FG_STAMP(0, 8 * c + 1);
+        __syncthreads();  // (Ba)
+        if (wave == 0) FG_STAMP(0, 8 * c + 2);
+        if (nt == MAXT) wsu_chunk<MAXT, MAXT, true, 2, 2, 2>(pi, pj, acc);
+        else wsu_chunk<MAXT, MAXT - 1, true, 2, 2, 2>(pi, pj, acc);
+        if (wave == 0) FG_STAMP(0, 8 * c + 3);
+        __syncthreads();  // (Bb)
+        if (wave == 0) FG_STAMP(0, 8 * c + 4);
+        __syncthreads();  // (Bc)
+        if (wave == 0) FG_STAMP(0, 8 * c + 6);
+        const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);
+#pragma unroll
+        for (int t = 0; t < MAXT; t++) { pi[t] += delta; pj[t] += delta; }
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; t++) {
+        if (t < nt) {
+            int ti, tj;
+            tile_ij(t0 + t, ti, tj);
+            const int ia = ti * 16 + lk, ib = tj * 16 + lr;
+            const double sc = (ti != tj ? 1.0 : 0.5);  // acc = 2 V: see vxc_wsu_kernel
 #pragma unroll
             for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
         }
@@ -1601,6 +1896,66 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao, const double *d_w,
                       const double *d_v, void *stream) {
     return grid_vxc_impl(d_vmat, d_ao_a, d_ao_b, 1, ngrid, nao, d_w, d_v, nullptr, stream);
+}
+
+#ifdef FG_TRACE
+int dqc_debug_fused_trace(long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dqc::g_fg_trace), sizeof(long long) * 2 * dqc::FG_TRACE_N);
+}
+#endif
+
+/* fused density -> XC -> Vxc (see fused_grid_kernel).  Returns DQC_EUNSUPPORTED (no launch, no error text change) for shapes it
+ * does not cover: the caller then runs dqc_grid_density_lr + dqc_xc_eval + dqc_grid_vxc. */
+int dqc_grid_fused_supported(int nao, int norb_pad) {
+    const int ld = dqc_padded_nao(nao), T = ld / 16;
+    return (T == 11 || T == 13) && norb_pad >= 16 && norb_pad <= 64 && norb_pad % 16 == 0;
+}
+
+int dqc_grid_fused(double *d_vmat, double *d_rho, double *d_grho, double *d_exc, const double *d_ao, int ngrid, int nao,
+                   const double *d_w, const double *d_orb, const double *d_orbt, int norb_pad, const int *ids,
+                   const double *coefs, int nterm, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!dqc_grid_fused_supported(nao, norb_pad)) { set_error("dqc_grid_fused: shape not covered (10 <= ld/16 <= 13, norb_pad <= 64)"); return DQC_EINVAL; }
+    if (nterm < 0 || nterm > 8) { set_error("dqc_grid_fused: at most 8 functional terms"); return DQC_EINVAL; }
+    XcTerms t;
+    t.n = nterm;
+    for (int i = 0; i < nterm; i++) {
+        t.id[i] = ids[i];
+        t.c[i] = coefs[i];
+        switch (ids[i]) {
+        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: break;
+        default: set_error("dqc_grid_fused: LDA / GGA functional ids only"); return DQC_EINVAL;
+        }
+    }
+    const int ld = dqc_padded_nao(nao), T = ld / 16;
+    DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
+    if (d_exc) DQC_HIP(hipMemsetAsync(d_exc, 0, sizeof(double), st));
+    if (ngrid <= 0) return DQC_OK;
+    int nslab = 256;
+    int slab = (ngrid + nslab - 1) / nslab;
+    slab = (slab + 15) / 16 * 16;
+    nslab = (ngrid + slab - 1) / slab;
+    const size_t shmem = sizeof(double) * (2 * VWS_BUF + FG_ABUF) + 64;
+    int xcs = 0;
+    if (nterm == 2 && ids[0] == DQC_XC_GGA_X_PBE && ids[1] == DQC_XC_GGA_C_PBE) xcs = 1;
+    if (nterm == 2 && ids[0] == DQC_XC_LDA_X && ids[1] == DQC_XC_LDA_C_PW) xcs = 2;
+#define DQC_FG_CASE(M, R) DQC_FG_CASE2(M, R, 0) DQC_FG_CASE2(M, R, 1) DQC_FG_CASE2(M, R, 2)
+#define DQC_FG_CASE2(M, R, X)                                                                                          \
+    if ((T == 13 ? 12 : 9) == M && norb_pad / 16 == R && xcs == X) {                                                   \
+        auto kern = fused_grid_kernel<M, 7, R, X>;                                                                     \
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);         \
+        hipLaunchKernelGGL(kern, dim3(nslab), dim3(VWU_NT), shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_orb, d_orbt, slab, t, \
+                           d_rho, d_grho, d_exc);                                                                      \
+    }
+    DQC_FG_CASE(12, 1) DQC_FG_CASE(12, 2) DQC_FG_CASE(12, 3) DQC_FG_CASE(12, 4)
+    DQC_FG_CASE(9, 1) DQC_FG_CASE(9, 2) DQC_FG_CASE(9, 3) DQC_FG_CASE(9, 4)
+#undef DQC_FG_CASE
+#undef DQC_FG_CASE2
+    DQC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
 }
 
 }  // extern "C"

@@ -70,6 +70,8 @@ def load():
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_grid_fused_supported.argtypes = [c_int, c_int]
+    lib.dqc_grid_fused.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga_pol.argtypes = [c_dp] * 11 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
@@ -449,6 +451,27 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
         _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), st_),
                "dqc_grid_vxc")
     return vm
+
+
+def grid_fused_supported(nao, norb_pad):
+    return bool(load().dqc_grid_fused_supported(int(nao), int(norb_pad)))
+
+
+def grid_fused(ao, nao, w, factor, terms, want_dens=False, want_exc=False):
+    """density -> XC -> Vxc from one read of the AO matrix (4, ngrid, ld); factor = pad_factor(...) pair; terms: LDA / GGA list.
+    -> (vmat (ld, ld), rho or None, grho (3, ngrid) or None, exc (1,) or None)"""
+    orb, orbt = factor
+    ngrid, ld = ao.shape[-2], ao.shape[-1]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
+    rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device) if want_dens else None
+    grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if want_dens else None
+    exc = torch.empty(1, dtype=torch.float64, device=ao.device) if want_exc else None
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_fused(_ptr(vm), _ptr(rho), _ptr(grho), _ptr(exc), _ptr(ao), ngrid, nao, _ptr(w), _ptr(orb), _ptr(orbt),
+                                     orb.shape[1], ids, cfs, len(terms), st_), "dqc_grid_fused")
+    return vm, rho, grho, exc
 
 
 def probe_stream_read(buf):
