@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--molecules", type=int, default=32, help="size of the batch (whole job; sharded over the ranks)")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="a step is repeated `repeats` times so that the timed region of K steps lasts at least this long")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the batch's Fock builds are dealt to (molecule k -> stream k %% S): independent molecules, so "
+                         "the tail of one molecule's kernels overlaps the head of the next one's (SURVEY 8e: each rank, own streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--profile-mode", action="store_true",
@@ -119,6 +122,10 @@ def main():
     h0 = engines[0].hamilton
     nao, ngrid, ld = h0._nao_ao, h0.rgrid.shape[0], h0._ld
 
+    nstreams = max(1, min(args.streams, len(engines)))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(dev)]
+    torch.cuda.synchronize()
+
     def step(record=None, dense_dm=False, sel=None):
         for k, (eng, dm, orb) in enumerate(zip(engines, dms, orbs)):
             if sel is not None and k >= sel:
@@ -126,10 +133,12 @@ def main():
             # a fresh density-matrix tensor every step (defeats the J/K memoisation: everything is recomputed).
             # Default: D = ao_orb2dm(C_occ, n) exactly as scp2dm produces it in every SCF iteration (hf.py:105-113), so
             # the Hamiltonian knows its rank-n_occ factor; --dense-dm hands over an anonymous full matrix instead.
-            d = dm.clone() if dense_dm else eng.hamilton.ao_orb2dm(orb, eng.orb_weight)
             if record is None:
-                eng.dm2scp(d)
-            else:
+                with torch.cuda.stream(streams[k % nstreams]):  # independent molecules: dealt round-robin to the streams
+                    d = dm.clone() if dense_dm else eng.hamilton.ao_orb2dm(orb, eng.orb_weight)
+                    eng.dm2scp(d)
+            else:  # per-kernel events: one molecule at a time on the current stream
+                d = dm.clone() if dense_dm else eng.hamilton.ao_orb2dm(orb, eng.orb_weight)
                 record.append(eng.hamilton.timed_fock_kernels(d, eng.knvext.fullmatrix()))
 
     dense = args.dense_dm
@@ -343,7 +352,7 @@ def main():
                                    "sg3, %d per GPU; a step = %d pass(es) over the batch" % (nmol, len(mine), repeats),
                        "coulomb": ("density-fitted J, auxbasis %s (naux %d)" % (args.df, int(h0.df.j2c.shape[0]))) if args.df
                                   else "exact J from stored ERI tiles",
-                       "molecules_per_gpu": len(mine), "global_batch": nmol, "nao": nao, "ngrid": ngrid,
+                       "molecules_per_gpu": len(mine), "global_batch": nmol, "nao": nao, "ngrid": ngrid, "streams_per_gpu": nstreams,
                        "grid_pass": "fused density+XC+Vxc kernel" if fused else "density, XC, Vxc kernels",
                        "parallelism": "molecule-sharded x%d, no data-path collective" % world},
             "per_gpu_value": nmol * passes / elapsed / world,
