@@ -163,6 +163,7 @@ class HamiltonMI355(_Base):
         self.is_ao_set = True
         self.is_grad_ao_set = deriv >= 1
         self.is_lapl_ao_set = deriv == 2
+        self._ao_lapl_pm = None
 
     @property
     def basis(self):
@@ -406,7 +407,9 @@ class HamiltonMI355(_Base):
         # meta-GGA: the laplacian of the density is only formed for functionals that may use it (none of the kernel set does:
         # LibXC objects; a user-supplied BaseXC gets it, as in the reference, through the full-matrix path below)
         from .xc import LibXC
-        use_factor = fac is not None and (self.xcfamily != 4 or (isinstance(self.xc, LibXC) and self.is_lapl_ao_set))
+        # meta-GGA: LibXC objects of the kernel set never read the laplacian of the density (lapl=None); any other BaseXC gets it,
+        # as in the reference, from the factor too (cross term by the polarisation identity, see below)
+        use_factor = fac is not None and (self.xcfamily != 4 or self.is_lapl_ao_set)
         self.grid_path_counts["factor" if use_factor else "dense"] += 1
         if use_factor:
             # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
@@ -420,7 +423,16 @@ class HamiltonMI355(_Base):
             # tau = 1/2 sum_d sum_r (d_d Phi . L)_r^2 (hcgto.py:420-438 grad_grad term): the factor kernel on each gradient
             # component, phase 1 only
             gg = sum(lib.grid_density_lr(self._ao[d], self._nao_ao, f, False)[0] for d in (1, 2, 3) for f in fac)
-            return ValGrad(value=rho, grad=grho, lapl=None, kin=gg * 0.5)
+            if isinstance(self.xc, LibXC):
+                return ValGrad(value=rho, grad=grho, lapl=None, kin=gg * 0.5)
+            # lapl rho = 2 (sum_ij phi_i D_ij lapl phi_j + gg) (hcgto.py:427-436); with D = L L^T the cross term is
+            # sum_r (Phi L)_r (lapl Phi L)_r = 1/4 [ |(Phi + lapl Phi) L|^2 - |(Phi - lapl Phi) L|^2 ]: two more phase-1 passes of the
+            # factor kernel on the arrays Phi +- lapl Phi (formed on first use: 2 x ngrid x ld doubles)
+            if getattr(self, "_ao_lapl_pm", None) is None:
+                self._ao_lapl_pm = ((self._ao[0] + self._ao[4]).contiguous(), (self._ao[0] - self._ao[4]).contiguous())
+            pl = sum(lib.grid_density_lr(self._ao_lapl_pm[0], self._nao_ao, f, False)[0] for f in fac)
+            mi = sum(lib.grid_density_lr(self._ao_lapl_pm[1], self._nao_ao, f, False)[0] for f in fac)
+            return ValGrad(value=rho, grad=grho, lapl=2.0 * (0.25 * (pl - mi) + gg), kin=gg * 0.5)
         dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
         dao = lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld)
         rho, grho = lib.grid_density(self._ao, self._nao_ao, dao, gga)
