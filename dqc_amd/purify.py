@@ -9,20 +9,29 @@ dqc/qccalc/hf.py:105-113, 227-247; hcgto.py:272-281).  P is obtained without eig
     X  <- X^2            if tr X > n_occ            (lowers the trace)
           2 X - X^2      otherwise                  (raises it)
 
-converges quadratically to P (30-40 iterations for molecular spectra); once |X^2 - X|_max < tol the iterate is frozen
+converges quadratically to P (35-55 iterations for molecular spectra); once |X^2 - X|_max < tol the iterate is frozen
 (continuing would let the trace test pick the error-doubling branch at round-off level), and two McWeeny steps
 3 X^2 - 2 X^3 -- contracting at both 0 and 1 -- polish it.  Everything is device-side (`torch.where` on device
 scalars, no host decision), so the whole map F -> D replays inside the Fock-build hipGraph.  The result equals the
 eigh-based projector to round-off (tests compare both); non-convergence (a vanishing HOMO-LUMO gap) is reported through
 the returned idempotency error and the caller falls back to eigh.
 """
+import os
+
 import torch
 
+# launches per projector.  Early SCF iterations of the 20-atom molecules (HOMO-LUMO gaps of 0.02-0.03 Ha, Gershgorin bounds
+# 4 x wider than the spectrum) need 45-55 iterations, converged ones ~40; with 52 launches 1-3 steps per SCF run fell back to
+# eigh (4.5 ms each): 64 launches (frozen iterates cost 3 us each) make the run 8 % faster (tools/gpu_scf_time.py)
+_TC2_ITERS = int(os.environ.get("DQC_AMD_TC2_ITERS", "64"))
 
-def projector_from_fock(fock: torch.Tensor, nocc: int, iters: int = 52, tol: float = 1e-13, fused: bool = True):
+
+def projector_from_fock(fock: torch.Tensor, nocc: int, iters: int = None, tol: float = 1e-13, fused: bool = True):
     """fock (n, n) symmetric, orthonormal basis -> (P (n, n), idempotency error (0-dim device tensor)).
     fused=True runs the iterations in the HIP kernel of csrc/purify.hip (one launch each); fused=False is the same
     iteration written with torch ops (used by the CPU-side unit test and as the A/B reference)."""
+    if iters is None:
+        iters = _TC2_ITERS
     n = fock.shape[-1]
     eye = torch.eye(n, dtype=fock.dtype, device=fock.device)
     diag = torch.diagonal(fock)

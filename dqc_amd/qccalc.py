@@ -193,6 +193,7 @@ class SCF_QCCalc:
             host = yield torch.cat([head, row])
             emax, pe, grow = float(host[0]), float(host[1]), host[2:]
             if perr is not None and not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
+                self.eigh_fallbacks = getattr(self, "eigh_fallbacks", 0) + 1
                 dm = eng.scp2dm(fprev)
                 fock = eng.dm2scp(dm)
                 perr = None
