@@ -43,5 +43,5 @@ if "--scf" in sys.argv:
     qc.run()
     e = float(qc.energy())
     torch.cuda.synchronize()
-    out.update({"energy": e, "niter": qc.niter, "converged": qc.converged, "scf_s": time.perf_counter() - t4})
+    out.update({"energy": e, "niter": qc.niter, "converged": qc.converged, "accepted": qc.accepted, "scf_error": qc.scf_error, "scf_s": time.perf_counter() - t4})
 print(json.dumps(out), flush=True)
