@@ -13,6 +13,9 @@
 //     register footprint per lane stays ~20-40 accumulators for every class;
 //   * after the primitive loops the Cartesian block is transformed to real solid harmonics in LDS and
 //     scattered straight into the 8-fold-unique TILE storage the J/K kernels stream (no nao^4 tensor).
+//   (Tried in round 2: the class's Rys table staged in LDS behind the regions for NR <= 4 -- a root lookup is a gather over
+//   14-coefficient rows -- 42.7 instead of 27.8 ms per 20-atom cc-pVDZ fill: the copy per short-lived block and the LDS
+//   occupancy cost more than the L1 gathers.)
 //   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
 //   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
 #include "eri_core.hpp"
