@@ -157,6 +157,48 @@ DQC_DEV void rys_roots(double X, double *u, double *w) {
     }
 }
 
+// single root/weight r of the N-point rule from an LDS copy of the N table in the layout of rys_stage_lds: per (interval,
+// root) one row of (u-coefficient, w-coefficient) pairs at an odd row stride (29 doubles: rows of different intervals fall
+// into different banks).  Different lanes look up different intervals -- a gather; as ds_read_b128 pairs from LDS instead of
+// 28 uncoalesced global loads per call.
+constexpr int RYS_LDS_ROW = 2 * (RYS_DEG + 1) + 1;
+template <int N>
+constexpr int rys_lds_doubles() { return (14 + 2 * N) * N * RYS_LDS_ROW; }
+
+template <int N>
+DQC_DEV void rys_stage_lds(__attribute__((address_space(3))) double *lt, int tid, int nthreads) {
+    const double *src = RYS_TAB + RYS_OFF[N - 1];
+    constexpr int NI = 14 + 2 * N;
+    for (int e = tid; e < NI * N * (RYS_DEG + 1); e += nthreads) {
+        const int k = e % (RYS_DEG + 1), r = (e / (RYS_DEG + 1)) % N, it = e / ((RYS_DEG + 1) * N);
+        const double *row = src + (size_t)it * (2 * N) * (RYS_DEG + 1);
+        lt[(it * N + r) * RYS_LDS_ROW + 2 * k] = row[r * (RYS_DEG + 1) + k];
+        lt[(it * N + r) * RYS_LDS_ROW + 2 * k + 1] = row[(N + r) * (RYS_DEG + 1) + k];
+    }
+}
+
+template <int N>
+DQC_DEV void rys_root1_lds(const __attribute__((address_space(3))) double *lt, double X, int r, double &u, double &w) {
+    constexpr double XMAX = 35.0 + 5.0 * N;
+    if (X >= XMAX) {
+        double ix = 1.0 / X;
+        u = RYS_HERM_X2[N][r] * ix;
+        w = RYS_HERM_W[N][r] * sqrt(ix);
+        return;
+    }
+    int it = (int)(X * (1.0 / 2.5));
+    double x = (X - (it * 2.5 + 1.25)) * (1.0 / 1.25);
+    const __attribute__((address_space(3))) double *c = lt + (it * N + r) * RYS_LDS_ROW;
+    double x2 = 2.0 * x, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+    for (int k = RYS_DEG; k >= 1; k--) {
+        double t = x2 * a1 - a2 + c[2 * k]; a2 = a1; a1 = t;
+        double s = x2 * b1 - b2 + c[2 * k + 1]; b2 = b1; b1 = s;
+    }
+    u = x * a1 - a2 + c[0];
+    w = x * b1 - b2 + c[1];
+}
+
 // single root/weight r (runtime) -- used when different lanes need different roots
 template <int N>
 DQC_DEV void rys_root1(double X, int r, double &u, double &w) {

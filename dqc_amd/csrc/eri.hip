@@ -13,9 +13,12 @@
 //     register footprint per lane stays ~20-40 accumulators for every class;
 //   * after the primitive loops the Cartesian block is transformed to real solid harmonics in LDS and
 //     scattered straight into the 8-fold-unique TILE storage the J/K kernels stream (no nao^4 tensor).
-//   (Tried in round 2: the class's Rys table staged in LDS behind the regions for NR <= 4 -- a root lookup is a gather over
-//   14-coefficient rows -- 42.7 instead of 27.8 ms per 20-atom cc-pVDZ fill: the copy per short-lived block and the LDS
-//   occupancy cost more than the L1 gathers.)
+//   * classes with one or two Rys roots keep their root table in LDS (rys_stage_lds: (u, w) coefficient pairs per row, odd row
+//     stride): lanes of a wave work on different primitive quartets, so a root lookup is a gather -- 28 uncoalesced global
+//     loads per (direction, root) item, one VMEM read per 8.6 VALU instructions in (ps|ss).  20-atom cc-pVDZ fill 27.8 ->
+//     24.7 ms, naphthalene / cc-pVTZ 157 -> 153 ms; a generic (flat) pointer to the copy made it 42.7 ms, the 14 KB table of
+//     the three-root classes costs more occupancy than it saves.  PMC (profiles/r02u_*): the kernels are VALU-dependency
+//     bound (48 % of the wave cycles in issue stalls: Clenshaw recurrences, fp64 divisions), ~35 % VALU utilisation.
 //   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
 //   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
 #include "eri_core.hpp"

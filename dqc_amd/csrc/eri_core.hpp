@@ -40,10 +40,20 @@ struct EriCfg {
     static constexpr int BUF1 = SA * NCB * NCC * NCD;
     static constexpr int REG0 = GSZ > NOUT + BUF1 ? GSZ : NOUT + BUF1;
     static constexpr int REGION = REG0 | 1;  // odd stride: conflict-free when every lane owns a region
-    static constexpr size_t LDS_BYTES = sizeof(double) * (size_t)REGION * QPB;
+    // Rys table of this class's root count staged in LDS behind the regions when it is small (NR <= 2: 3.7 and 8.4 KB; with the 14 KB table of NR = 3 cc-pVTZ fills got 7 % slower).  Lanes of
+    // a wave work on different primitive quartets, so a root lookup is a gather: 28 uncoalesced global loads per (direction,
+    // root) item -- PMC: one VMEM read per 8.6 VALU instructions and 48 % of the wave cycles in issue stalls for (ps|ss)
+#ifdef ERI_NO_LDS_TAB  // A/B builds
+    static constexpr int TAB_DOUBLES = 0;
+#else
+    static constexpr int TAB_DOUBLES = NR <= 2 ? rys_lds_doubles<NR>() : 0;
+#endif
+    static constexpr size_t REG_DOUBLES = (size_t)REGION * QPB;
+    static constexpr size_t LDS_BYTES = sizeof(double) * (REG_DOUBLES + TAB_DOUBLES);
     // GRAD mode contracts straight from the accumulators: only the 2D-integral staging area is needed
     static constexpr int REGION_G = GSZ | 1;
-    static constexpr size_t LDS_BYTES_G = sizeof(double) * (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
+    static constexpr size_t REG_DOUBLES_G = (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
+    static constexpr size_t LDS_BYTES_G = sizeof(double) * (REG_DOUBLES_G + TAB_DOUBLES);
 };
 
 // output modes of the kernel
@@ -96,6 +106,13 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     const int q = tid / TPQ, s = tid % TPQ;  // quartet slot in the block, lane inside the quartet group
     constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : Cfg::REGION;
     double *reg = lds + (size_t)q * REGION;
+    constexpr bool TAB_LDS = Cfg::TAB_DOUBLES > 0;
+    typedef __attribute__((address_space(3))) double lds_double_t;
+    lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G : Cfg::REG_DOUBLES);
+    if constexpr (TAB_LDS) {
+        rys_stage_lds<NR>(ltab, tid, 256);
+        __syncthreads();
+    }
 
     long long task = (long long)blockIdx.x * QPB + q;
     const bool active = task < ntask;
@@ -171,7 +188,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             for (int item = s; item < 3 * NR; item += TPQ) {
                 const int d = item / NR, r = item - d * NR;
                 double u, w;
-                rys_root1<NR>(X, r, u, w);
+                if constexpr (TAB_LDS) rys_root1_lds<NR>(ltab, X, r, u, w);
+                else rys_root1<NR>(X, r, u, w);
                 const double b00 = 0.5 * u / pq;
                 const double b10 = 0.5 * (1.0 - u * qq / pq) / p;
                 const double b01 = 0.5 * (1.0 - u * p / pq) / qq;
