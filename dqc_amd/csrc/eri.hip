@@ -13,6 +13,9 @@
 //     register footprint per lane stays ~20-40 accumulators for every class;
 //   * after the primitive loops the Cartesian block is transformed to real solid harmonics in LDS and
 //     scattered straight into the 8-fold-unique TILE storage the J/K kernels stream (no nao^4 tensor).
+//   * the NR roots of a primitive quartet depend on X only: lane s of the quartet's lane group evaluates root s % NR once and the
+//     3 NR (direction, root) items fetch theirs by shuffle (round 1 evaluated the Clenshaw series per item: three times the
+//     work in groups of 1 or 4 lanes).  20-atom cc-pVDZ fill 24.7 -> 20.1 ms, benzene 12.4 -> 9.6, CH4 / cc-pVTZ 15.9 -> 12.2;
 //   * classes with one or two Rys roots keep their root table in LDS (rys_stage_lds: (u, w) coefficient pairs per row, odd row
 //     stride): lanes of a wave work on different primitive quartets, so a root lookup is a gather -- 28 uncoalesced global
 //     loads per (direction, root) item, one VMEM read per 8.6 VALU instructions in (ps|ss).  20-atom cc-pVDZ fill 27.8 ->

@@ -185,11 +185,43 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
             const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
             const double pref = pb[4] * pk[4] * 34.986836655249725 / (p * qq * sqrt(pq));  // 2 pi^(5/2)
-            for (int item = s; item < 3 * NR; item += TPQ) {
+            // the NR roots depend on X only, not on the direction: lane s of the quartet's group evaluates root s % NR ONCE and
+            // the (direction, root) items fetch theirs by shuffle (a one-lane group loops over all roots) -- per item this
+            // was a Clenshaw evaluation of its own, i.e. three times the work in groups of 1 or 4 lanes
+            double ru[TPQ == 1 ? NR : 1], rw[TPQ == 1 ? NR : 1];
+            if constexpr (TPQ == 1) {
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if constexpr (TAB_LDS) rys_root1_lds<NR>(ltab, X, r, ru[r], rw[r]);
+                    else rys_root1<NR>(X, r, ru[r], rw[r]);
+                }
+            } else {
+                static_assert(TPQ >= NR, "a quartet's lane group holds fewer lanes than the class has roots");
+                const int rmine = s < NR ? s : 0;
+                ru[0] = rw[0] = 0.0;
+                if (TPQ <= 64 || s < 64) {  // (a 256-lane group: its items all sit in the first wave)
+                    if constexpr (TAB_LDS) rys_root1_lds<NR>(ltab, X, rmine, ru[0], rw[0]);
+                    else rys_root1<NR>(X, rmine, ru[0], rw[0]);
+                }
+            }
+            constexpr int NROUND = (3 * NR + TPQ - 1) / TPQ;
+#pragma unroll
+            for (int round = 0; round < NROUND; round++) {
+                const int item_ = s + round * TPQ;
+                const int item = item_ < 3 * NR ? item_ : 3 * NR - 1;  // every lane of the wave takes part in the shuffles
                 const int d = item / NR, r = item - d * NR;
                 double u, w;
-                if constexpr (TAB_LDS) rys_root1_lds<NR>(ltab, X, r, u, w);
-                else rys_root1<NR>(X, r, u, w);
+                if constexpr (TPQ == 1) {
+                    u = ru[0]; w = rw[0];
+#pragma unroll
+                    for (int rr = 1; rr < NR; rr++)
+                        if (r == rr) { u = ru[rr]; w = rw[rr]; }
+                } else {  // lane r of this group holds root r (the items of a 256-lane group all sit in its first wave)
+                    const int src = ((tid & 63) - (s & 63)) + r;
+                    u = __shfl(ru[0], src, 64);
+                    w = __shfl(rw[0], src, 64);
+                }
+                if (item_ >= 3 * NR) continue;
                 const double b00 = 0.5 * u / pq;
                 const double b10 = 0.5 * (1.0 - u * qq / pq) / p;
                 const double b01 = 0.5 * (1.0 - u * p / pq) / qq;
