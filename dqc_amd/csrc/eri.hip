@@ -16,6 +16,10 @@
 //   * the NR roots of a primitive quartet depend on X only: lane s of the quartet's lane group evaluates root s % NR once and the
 //     3 NR (direction, root) items fetch theirs by shuffle (round 1 evaluated the Clenshaw series per item: three times the
 //     work in groups of 1 or 4 lanes).  20-atom cc-pVDZ fill 24.7 -> 20.1 ms, benzene 12.4 -> 9.6, CH4 / cc-pVTZ 15.9 -> 12.2;
+//   * the lanes of a quartet synchronise at wave level (eri_group_sync: a lane group of <= 64 lanes lies inside one wave) and a
+//     wave runs until ITS longest quartet is done -- no block barrier, no block-uniform primitive-quartet count; the
+//     recurrence coefficients use reciprocals formed once per primitive quartet instead of five fp64 divisions per item:
+//     20.2 -> 18.6 ms;
 //   * classes with one or two Rys roots keep their root table in LDS (rys_stage_lds: (u, w) coefficient pairs per row, odd row
 //     stride): lanes of a wave work on different primitive quartets, so a root lookup is a gather -- 28 uncoalesced global
 //     loads per (direction, root) item, one VMEM read per 8.6 VALU instructions in (ps|ss).  20-atom cc-pVDZ fill 27.8 ->

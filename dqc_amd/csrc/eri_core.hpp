@@ -93,6 +93,21 @@ DQC_DEV int cart_index(int l, int lx, int lz) {
     return row * (row + 1) / 2 + lz;
 }
 
+// synchronisation of the TPQ lanes that share a shell quartet: a lane group of at most 64 lanes lies inside one wave, whose LDS
+// instructions execute in program order -- a compiler-level wave barrier is enough and the block's other waves never wait
+// for this one (round 1 used __syncthreads and a block-uniform primitive-quartet count: every wave waited for the slowest
+// quartet of the block twice per primitive quartet); 256-lane groups are the block
+template <int TPQ>
+DQC_DEV void eri_group_sync() {
+    if constexpr (TPQ > 64) {
+        __syncthreads();
+    } else if constexpr (TPQ > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 template <int LA, int LB, int LC, int LD, int MODE>
 __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, DevShells sh, DevPairs prs, DevPairs prk,
                                                   int b0, int nb, int k0, int nk, int same, long long ntask, EriOut og) {
@@ -143,8 +158,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     const int pk0 = prk.pp_off[ik], nkp = prk.pp_off[ik + 1] - pk0;
     const int nq = active ? nbp * nkp : 0;
 
-    int maxq = nq;
-    if (TPQ > 1) {  // block-uniform trip count so that the barriers below are legal
+    int maxq = nq;  // groups inside a wave: the wave simply runs until its longest quartet is done (`on` masks the others)
+    if (TPQ > 64) {  // the group is the block: block-uniform trip count so that the barriers below are legal
         if (tid == 0) s_maxq = 0;
         __syncthreads();
         atomicMax(&s_maxq, nq);
@@ -184,7 +199,9 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const double pq = p + qq, rho = p * qq / pq;
             const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
             const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
-            const double pref = pb[4] * pk[4] * 34.986836655249725 / (p * qq * sqrt(pq));  // 2 pi^(5/2)
+            // reciprocals once per primitive quartet: the recurrence coefficients below were five fp64 divisions per item
+            const double ipq = 1.0 / pq, ip = 1.0 / p, iqq = 1.0 / qq;
+            const double pref = pb[4] * pk[4] * 34.986836655249725 * (ip * iqq) * sqrt(ipq);  // 2 pi^(5/2) / (p q sqrt(p + q))
             // the NR roots depend on X only, not on the direction: lane s of the quartet's group evaluates root s % NR ONCE and
             // the (direction, root) items fetch theirs by shuffle (a one-lane group loops over all roots) -- per item this
             // was a Clenshaw evaluation of its own, i.e. three times the work in groups of 1 or 4 lanes
@@ -222,11 +239,12 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                     w = __shfl(rw[0], src, 64);
                 }
                 if (item_ >= 3 * NR) continue;
-                const double b00 = 0.5 * u / pq;
-                const double b10 = 0.5 * (1.0 - u * qq / pq) / p;
-                const double b01 = 0.5 * (1.0 - u * p / pq) / qq;
-                const double c00 = (P[d] - A[d]) - u * qq / pq * PQ[d];
-                const double c0p = (Q[d] - Cc[d]) + u * p / pq * PQ[d];
+                const double uq = u * qq * ipq, up = u * p * ipq;
+                const double b00 = 0.5 * u * ipq;
+                const double b10 = 0.5 * (1.0 - uq) * ip;
+                const double b01 = 0.5 * (1.0 - up) * iqq;
+                const double c00 = (P[d] - A[d]) - uq * PQ[d];
+                const double c0p = (Q[d] - Cc[d]) + up * PQ[d];
                 // vertical recurrence g[n][m], n <= NMAX, m <= MMAX
                 double g[NMAX + 1][MMAX + 1];
                 g[0][0] = (d == 2) ? w * pref : 1.0;
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                     }
             }
         }
-        if (TPQ > 1) __syncthreads();
+        eri_group_sync<TPQ>();
         // ---------------- phase B: accumulate the Cartesian outputs ----------------
         if (on) {
 #pragma unroll
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 acc[m] += v;
             }
         }
-        if (TPQ > 1) __syncthreads();
+        eri_group_sync<TPQ>();
     }
 
     if constexpr (MODE == ERI_OUT_GRAD) {
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         const int n = s + TPQ * m;
         if (n < NOUT) buf0[n] = acc[m];
     }
-    if (TPQ > 1) __syncthreads();
+    eri_group_sync<TPQ>();
     {
         // index a: buf0[ca][rest] -> buf1[ma][rest]
         constexpr int R0 = Cfg::NCB * Cfg::NCC * Cfg::NCD;
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             buf1[e] = v;
         }
     }
-    if (TPQ > 1) __syncthreads();
+    eri_group_sync<TPQ>();
     {
         // index b: buf1[ma][cb][rest] -> buf0[ma][mb][rest]
         constexpr int R1 = Cfg::NCC * Cfg::NCD;
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             buf0[e] = v;
         }
     }
-    if (TPQ > 1) __syncthreads();
+    eri_group_sync<TPQ>();
     {
         // index c: buf0[mab][cc][cd] -> buf1[mab][mc][cd]
         const double *C = C2S + C2S_OFF[LC];
@@ -404,7 +422,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             buf1[e] = v;
         }
     }
-    if (TPQ > 1) __syncthreads();
+    eri_group_sync<TPQ>();
     if (active) {
         // index d and scatter: value (ma, mb, mc, md) -> all block-canonical images
         const double *C = C2S + C2S_OFF[LD];
