@@ -20,6 +20,8 @@
 //     wave runs until ITS longest quartet is done -- no block barrier, no block-uniform primitive-quartet count; the
 //     recurrence coefficients use reciprocals formed once per primitive quartet instead of five fp64 divisions per item:
 //     20.2 -> 18.6 ms;
+//     (tried: incremental (bra pair, ket pair) counters with the bra pair's data held in registers instead of the per-iteration
+//     integer division and re-read -- 17.85 -> 21.5 ms of kernel time: the extra live registers cost more than the division);
 //   * classes with one or two Rys roots keep their root table in LDS (rys_stage_lds: (u, w) coefficient pairs per row, odd row
 //     stride): lanes of a wave work on different primitive quartets, so a root lookup is a gather -- 28 uncoalesced global
 //     loads per (direction, root) item, one VMEM read per 8.6 VALU instructions in (ps|ss).  20-atom cc-pVDZ fill 27.8 ->
