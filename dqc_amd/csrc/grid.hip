@@ -1147,6 +1147,15 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int VWU_PROD = 256, VWU_NT = 512 + VWU_PROD;
 
+#ifdef VWU_TRACE  // per-chunk timeline of one block (100 MHz ticks): role 0 = consumer wave 0, role 1 = producer wave 8
+constexpr int VWU_TRACE_N = 4 * 128;
+__device__ long long g_vwu_trace[2 * VWU_TRACE_N];
+#define VWU_STAMP(role, slot) \
+    if (blockIdx.x == VWU_TRACE && (wave == 0 || wave == 8) && lane == 0 && (slot) < VWU_TRACE_N) g_vwu_trace[(role) * VWU_TRACE_N + (slot)] = wall_clock64()
+#else
+#define VWU_STAMP(role, slot)
+#endif
+
 template <int MAXT, int NTL, bool TWO, int D = 2, int KG0 = 0, int NKG = 4>
 __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsigned (&pj)[MAXT], v4d (&acc)[MAXT]) {
     // NTL <= MAXT: tiles actually looped over (waves that own one tile fewer skip the dummy MFMAs);
@@ -1171,6 +1180,108 @@ __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsi
     }
 }
 
+// the 4 producer waves of vxc_wsu_kernel / vxc_wsb_kernel (threads 512 .. 767): chunk c + 2 travels HBM -> registers while the
+// consumers run the MFMAs of chunk c; chunk c + 1 is combined into (Phi, Psi) and written to LDS in the window between chunks
+template <int NLP, bool GGA>
+DQC_DEV void vwu_producer(double *lds, const double *__restrict__ ao, int ngrid, int ld, const double *__restrict__ w,
+                          const double *__restrict__ vrho, const double *__restrict__ vgrad, int gs, int ge, int nchunk) {
+    constexpr int KCH = 16;
+    const int LS = ld;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    (void)wave; (void)lane;
+    const size_t cs = (size_t)ngrid * ld;
+    // ------------------------------------------------------------------ producers (see vxc_ws_kernel)
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int TPR = VWU_PROD / KCH;  // 16 threads per chunk row
+    const int pt = tid - 512;
+    const int prow = pt / TPR, pcol = pt % TPR;
+    const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+    unsigned wlds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds +
+                    8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);
+    typedef double vd2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    constexpr int BUF_FLAGS = 0x00020000;
+    v4u raw[NLP][GGA ? 4 : 1];
+    double cf[GGA ? 4 : 1], wg = 0.0;
+    auto as_d = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
+    auto prefetch = [&](int c) {
+        const int g0 = gs + c * KCH;
+        const int rows = ge - g0;
+        auto rsrc = [&](const double *base, size_t bytes) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, BUF_FLAGS);
+        };
+        const v2u xw = __builtin_amdgcn_raw_buffer_load_b64(rsrc(w + g0, (size_t)rows * 8), prow * 8, 0, 0);
+        wg = as_d(xw[0], xw[1]);
+        const v2u xr = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vrho + g0, (size_t)rows * 8), prow * 8, 0, 0);
+        cf[0] = as_d(xr[0], xr[1]);
+        if (GGA) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const v2u xg = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vgrad + (size_t)d * ngrid + g0, (size_t)rows * 8), prow * 8, 0, 0);
+                cf[d + 1] = as_d(xg[0], xg[1]);
+            }
+        }
+        const size_t nb = (size_t)rows * ld * 8;
+#pragma unroll
+        for (int d = 0; d < (GGA ? 4 : 1); d++) {
+            const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
+#pragma unroll
+            for (int i = 0; i < NLP; i++)
+                if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
+        }
+    };
+    auto stage = [&]() {
+        // GGA: acc = 2 V, so Psi = w (vrho Phi + sum_d 2 vgrad_d dPhi_d) as in vxc_ws_kernel and the epilogue halves
+        cf[0] *= wg;
+        if (GGA) {
+#pragma unroll
+            for (int d = 1; d < 4; d++) cf[d] *= 2.0 * wg;
+        }
+#pragma unroll
+        for (int i = 0; i < NLP; i++) {
+            if ((pcol + i * TPR) * 2 < ld) {
+                vd2 ps = {cf[0] * as_d(raw[i][0][0], raw[i][0][1]), cf[0] * as_d(raw[i][0][2], raw[i][0][3])};
+                if (GGA) {
+#pragma unroll
+                    for (int d = 1; d < 4; d++) {
+                        ps.x += cf[d] * as_d(raw[i][d][0], raw[i][d][1]);
+                        ps.y += cf[d] * as_d(raw[i][d][2], raw[i][d][3]);
+                    }
+                }
+                *(__attribute__((address_space(3))) v4u *)(wlds + i * TPR * 16) = raw[i][0];
+                *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16 + VWS_XS * 8) = ps;
+            }
+        }
+    };
+    prefetch(0);
+    stage();
+    if (nchunk > 1) prefetch(1);
+    __syncthreads();
+#ifdef VWU_TRACE
+    if (blockIdx.x == VWU_TRACE && tid == 512) { g_vwu_trace[VWU_TRACE_N - 4] = clock64(); g_vwu_trace[VWU_TRACE_N - 3] = wall_clock64(); }
+#endif
+    for (int c = 0; c < nchunk; c++) {
+        wlds += (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // buffer (c + 1) & 1
+        __syncthreads();  // the consumers have finished chunk c - 1 and wait: the vector ALUs are free for the combine
+#ifdef VWU_TRACE_CHUNKS
+        VWU_STAMP(1, 4 * c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VWU_STAMP(1, 4 * c + 1);
+#endif
+#ifndef VWU_EXP_NOSTAGE
+        if (c + 1 < nchunk) stage();
+#endif
+        __syncthreads();  // the consumers start the MFMAs of chunk c
+#ifndef VWU_EXP_NOLOAD
+        if (c + 2 < nchunk) prefetch(c + 2);
+#endif
+    }
+#ifdef VWU_TRACE
+    if (blockIdx.x == VWU_TRACE && tid == 512) { g_vwu_trace[VWU_TRACE_N - 2] = clock64(); g_vwu_trace[VWU_TRACE_N - 1] = wall_clock64(); }
+#endif
+}
+
 template <int MAXT, int NLP, bool GGA>
 __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
                                                            int ld, const double *__restrict__ w, const double *__restrict__ vrho,
@@ -1185,81 +1296,7 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
     const int nchunk = (ge - gs + KCH - 1) / KCH;
 
     if (wave >= VXC_WAVES) {
-        // ------------------------------------------------------------------ producers (see vxc_ws_kernel)
-        __builtin_amdgcn_s_setprio(3);
-        constexpr int TPR = VWU_PROD / KCH;  // 16 threads per chunk row
-        const int pt = tid - 512;
-        const int prow = pt / TPR, pcol = pt % TPR;
-        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
-        unsigned wlds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds +
-                        8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);
-        typedef double vd2 __attribute__((ext_vector_type(2)));
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-        constexpr int BUF_FLAGS = 0x00020000;
-        v4u raw[NLP][GGA ? 4 : 1];
-        double cf[GGA ? 4 : 1], wg = 0.0;
-        auto as_d = [](unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); };
-        auto prefetch = [&](int c) {
-            const int g0 = gs + c * KCH;
-            const int rows = ge - g0;
-            auto rsrc = [&](const double *base, size_t bytes) {
-                return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, BUF_FLAGS);
-            };
-            const v2u xw = __builtin_amdgcn_raw_buffer_load_b64(rsrc(w + g0, (size_t)rows * 8), prow * 8, 0, 0);
-            wg = as_d(xw[0], xw[1]);
-            const v2u xr = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vrho + g0, (size_t)rows * 8), prow * 8, 0, 0);
-            cf[0] = as_d(xr[0], xr[1]);
-            if (GGA) {
-#pragma unroll
-                for (int d = 0; d < 3; d++) {
-                    const v2u xg = __builtin_amdgcn_raw_buffer_load_b64(rsrc(vgrad + (size_t)d * ngrid + g0, (size_t)rows * 8), prow * 8, 0, 0);
-                    cf[d + 1] = as_d(xg[0], xg[1]);
-                }
-            }
-            const size_t nb = (size_t)rows * ld * 8;
-#pragma unroll
-            for (int d = 0; d < (GGA ? 4 : 1); d++) {
-                const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
-#pragma unroll
-                for (int i = 0; i < NLP; i++)
-                    if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
-            }
-        };
-        auto stage = [&]() {
-            // GGA: acc = 2 V, so Psi = w (vrho Phi + sum_d 2 vgrad_d dPhi_d) as in vxc_ws_kernel and the epilogue halves
-            cf[0] *= wg;
-            if (GGA) {
-#pragma unroll
-                for (int d = 1; d < 4; d++) cf[d] *= 2.0 * wg;
-            }
-#pragma unroll
-            for (int i = 0; i < NLP; i++) {
-                if ((pcol + i * TPR) * 2 < ld) {
-                    vd2 ps = {cf[0] * as_d(raw[i][0][0], raw[i][0][1]), cf[0] * as_d(raw[i][0][2], raw[i][0][3])};
-                    if (GGA) {
-#pragma unroll
-                        for (int d = 1; d < 4; d++) {
-                            ps.x += cf[d] * as_d(raw[i][d][0], raw[i][d][1]);
-                            ps.y += cf[d] * as_d(raw[i][d][2], raw[i][d][3]);
-                        }
-                    }
-                    *(__attribute__((address_space(3))) v4u *)(wlds + i * TPR * 16) = raw[i][0];
-                    *(__attribute__((address_space(3))) vd2 *)(wlds + i * TPR * 16 + VWS_XS * 8) = ps;
-                }
-            }
-        };
-        prefetch(0);
-        stage();
-        if (nchunk > 1) prefetch(1);
-        __syncthreads();
-        for (int c = 0; c < nchunk; c++) {
-            wlds += (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // buffer (c + 1) & 1
-            __syncthreads();  // the consumers have finished chunk c - 1 and wait: the vector ALUs are free for the combine
-            if (c + 1 < nchunk) stage();
-            __syncthreads();  // the consumers start the MFMAs of chunk c
-            if (c + 2 < nchunk) prefetch(c + 2);
-        }
+        vwu_producer<NLP, GGA>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk);
         return;
     }
 
@@ -1290,10 +1327,18 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
     }
     __syncthreads();
     for (int c = 0; c < nchunk; c++) {
+#ifdef VWU_TRACE_CONS
+        VWU_STAMP(0, 4 * c);
+#endif
         __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
         __syncthreads();  // ... and closes
+#ifdef VWU_TRACE_CONS
+        VWU_STAMP(0, 4 * c + 1);
+#endif
+#ifndef VWU_EXP_NOMFMA
         if (nt == MAXT) wsu_chunk<MAXT, MAXT, GGA>(pi, pj, acc);
         else wsu_chunk<MAXT, MAXT - 1, GGA>(pi, pj, acc);
+#endif
         const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);
 #pragma unroll
         for (int t = 0; t < MAXT; t++) { pi[t] += delta; pj[t] += delta; }
@@ -1308,10 +1353,144 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
             //   GGA: acc = 2 V -> off-diagonal tiles store acc (-> acc / 2 = V), diagonal tiles acc / 2 (already symmetric)
             //   one operand: acc = V -> off-diagonal tiles 2 acc, diagonal tiles acc
             const double sc = (GGA ? 1.0 : 2.0) * (ti != tj ? 1.0 : 0.5);
+#ifdef VWU_EXP_NOEPI
+            if (acc[t][0] != 1.2345e300) continue;
+#endif
 #pragma unroll
             for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vxc, one block per slab, GGA, T = 11 or 13 tile rows: vxc_wsu_kernel with ONE MFMA on the diagonal tiles.
+// vxc_wsu_kernel is 90 % MFMA-busy in cycles, but the chip sits at its power limit there (tools/gpu_vxc_trace.py: the shader
+// clock is 1.96 GHz with the MFMAs and the HBM stream both running, 2.35 GHz with the MFMAs alone, 2.41 GHz with the stream
+// alone), so what is left is the number of MFMAs.  A diagonal tile needs only M_ii = Phi_i^T Psi_i: symmetrize_kernel forms
+// (M_ii + M_ii^T) / 2 = V_ii anyway.  T^2 = 169 MFMAs per k-group instead of T (T + 1) = 182 (-7 %).  Every wave owns NO
+// off-diagonal tiles (two MFMAs each) followed by ND diagonal tiles (one each); the deal is fixed at compile time so that the
+// SIMDs (waves w and w + 4) carry 42, 42, 42, 43 MFMAs per k-group for T = 13 and no wave more than 12 accumulator tiles.
+// Measured (C5 shape, random data): 0.691 ms against 0.725 ms.  Not pursued: sharing fragment reads between the tiles of a
+// row -- a build that issues a quarter of the ds_read_b64 (wrong results, timing only) is just 3-5 % faster.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct WsdDeal {
+    int no[VXC_WAVES], nd[VXC_WAVES], o0[VXC_WAVES], d0[VXC_WAVES];
+    constexpr WsdDeal() : no{}, nd{}, o0{}, d0{} {
+        const int noff = T * (T - 1) / 2;
+        int cost[4] = {0, 0, 0, 0};
+        for (int w = 0; w < VXC_WAVES; w++) {
+            no[w] = noff / VXC_WAVES + (w < noff % VXC_WAVES ? 1 : 0);
+            cost[w & 3] += 2 * no[w];
+        }
+        for (int d = 0; d < T; d++) {  // greedy: the next diagonal tile goes to the lightest SIMD, there to the wave with fewer tiles
+            int q = 0;
+            for (int r = 1; r < 4; r++)
+                if (cost[r] < cost[q]) q = r;
+            const int w = no[q] + nd[q] <= no[q + 4] + nd[q + 4] ? q : q + 4;
+            nd[w]++;
+            cost[q]++;
+        }
+        for (int w = 1; w < VXC_WAVES; w++) {
+            o0[w] = o0[w - 1] + no[w - 1];
+            d0[w] = d0[w - 1] + nd[w - 1];
+        }
+    }
+    constexpr int max_tiles() const {
+        int m = 0;
+        for (int w = 0; w < VXC_WAVES; w++) m = no[w] + nd[w] > m ? no[w] + nd[w] : m;
+        return m;
+    }
+};
+
+template <int NO, int ND, int D = 2>
+DQC_DEV void wsd_chunk(const unsigned (&pi)[NO + ND], const unsigned (&pj)[NO + ND], v4d (&acc)[NO + ND]) {
+    // step s of a k-group: s < 2 NO: tile s / 2, h = s % 2 (h = 0: Phi_i^T Psi_j, h = 1: Psi_i^T Phi_j); then the diagonal tiles, h = 0
+    constexpr int PER = 2 * NO + ND, NS = 4 * PER;
+    double fa[D + 1], fb[D + 1];
+    auto rd = [&](int s) {
+        const int kk = s / PER, u = s % PER;
+        const int t = u < 2 * NO ? u / 2 : NO + (u - 2 * NO), h = u < 2 * NO ? u % 2 : 0;
+        fa[s % (D + 1)] = *(lds_cdouble_t *)(pi[t] + (kk * VWS_GS + (h ? VWS_XS : 0)) * 8);
+        fb[s % (D + 1)] = *(lds_cdouble_t *)(pj[t] + (kk * VWS_GS + (h ? 0 : VWS_XS)) * 8);
+    };
+#pragma unroll
+    for (int s = 0; s < D && s < NS; s++) rd(s);
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if (s + D < NS) rd(s + D);
+        __builtin_amdgcn_sched_barrier(0);
+        const int u = s % PER;
+        const int t = u < 2 * NO ? u / 2 : NO + (u - 2 * NO);
+        acc[t] = mfma_f64(fa[s % (D + 1)], fb[s % (D + 1)], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int T, int NO, int ND>
+DQC_DEV void wsd_consumer(double *lds, double *__restrict__ vmat, int nchunk, int o0, int d0) {
+    constexpr int NT = NO + ND, LS = 16 * T;
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    auto tile_ij = [&](int t, int &ti, int &tj) {
+        if (t >= NO) { ti = tj = d0 + (t - NO); return; }
+        int i = 0, rem = o0 + t;
+        while (rem >= T - 1 - i) { rem -= T - 1 - i; i++; }  // row i of the strict upper triangle holds T - 1 - i tiles
+        ti = i;
+        tj = i + 1 + rem;
+    };
+    v4d acc[NT];
+    unsigned pi[NT], pj[NT];  // LDS byte addresses of the row / column fragments in the Phi part (k-group 0, current buffer)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        int ti, tj;
+        tile_ij(t, ti, tj);
+        pi[t] = lds0 + 8u * (unsigned)(lk * LS + ti * 16 + lr);
+        pj[t] = lds0 + 8u * (unsigned)(lk * LS + tj * 16 + lr);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
+        __syncthreads();  // ... and closes
+        wsd_chunk<NO, ND>(pi, pj, acc);
+        const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);
+#pragma unroll
+        for (int t = 0; t < NT; t++) { pi[t] += delta; pj[t] += delta; }
+    }
+    // off-diagonal tiles hold 2 V_ij (symmetrize_kernel halves them against the zero lower tiles), diagonal tiles M_ii
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int ti, tj;
+        tile_ij(t, ti, tj);
+        const int ia = ti * 16 + lk, ib = tj * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * LS + ib], acc[t][r]);
+    }
+}
+
+template <int T, int NLP>
+__global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
+                                                           const double *__restrict__ w, const double *__restrict__ vrho,
+                                                           const double *__restrict__ vgrad, int slab) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int KCH = 16, ld = 16 * T;
+    constexpr WsdDeal<T> DL{};
+    static_assert(DL.max_tiles() <= 12, "more than 12 accumulator tiles per wave");
+    const int wave = threadIdx.x >> 6;
+    const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
+    if (gs >= ngrid) return;
+    const int nchunk = (ge - gs + KCH - 1) / KCH;
+    if (wave >= VXC_WAVES) {
+        vwu_producer<NLP, true>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk);
+        return;
+    }
+#define DQC_WSD_CASE(W) case W: wsd_consumer<T, DL.no[W], DL.nd[W]>(lds, vmat, nchunk, DL.o0[W], DL.d0[W]); break;
+    switch (wave) {  // wave-uniform; equal (NO, ND) pairs share one instantiation
+        DQC_WSD_CASE(0) DQC_WSD_CASE(1) DQC_WSD_CASE(2) DQC_WSD_CASE(3)
+        DQC_WSD_CASE(4) DQC_WSD_CASE(5) DQC_WSD_CASE(6) DQC_WSD_CASE(7)
+    }
+#undef DQC_WSD_CASE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1661,6 +1840,14 @@ static void launch_vxc_wsu_inst(dim3 grid, size_t shmem, hipStream_t st, double 
     hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
 }
 
+template <int T>
+static void launch_vxc_wsd(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, const double *w,
+                           const double *vrho, const double *vgrad, int slab) {
+    auto kern = vxc_wsd_kernel<T, 7>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, w, vrho, vgrad, slab);
+}
+
 template <bool GGA>
 static int launch_vxc_wsu(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                           const double *w, const double *vrho, const double *vgrad, int slab) {
@@ -1834,8 +2021,15 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             nslab = (ngrid + slab - 1) / slab;
             const int need = (T * (T + 1) / 2 + VXC_WAVES - 1) / VXC_WAVES;
             const size_t shmem_u = sizeof(double) * 2 * VWS_BUF;
-            int rc = gga ? launch_vxc_wsu<true>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
+            int rc = 0;
+            // GGA: one MFMA on the diagonal tiles (vxc_wsd_kernel); DQC_VXC_IMPL=upper keeps two on every tile (A/B runs)
+            if (gga && (T == 13 || T == 11) && !(impl_env && impl_env[0] == 'u')) {
+                if (T == 13) launch_vxc_wsd<13>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab);
+                else launch_vxc_wsd<11>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab);
+            } else {
+                rc = gga ? launch_vxc_wsu<true>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
                          : launch_vxc_wsu<false>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
+            }
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
             hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
@@ -1900,6 +2094,11 @@ int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b
     return grid_vxc_impl(d_vmat, d_ao_a, d_ao_b, 1, ngrid, nao, d_w, d_v, nullptr, stream);
 }
 
+#ifdef VWU_TRACE
+int dqc_debug_vwu_trace(long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dqc::g_vwu_trace), sizeof(long long) * 2 * dqc::VWU_TRACE_N);
+}
+#endif
 #ifdef FG_TRACE
 int dqc_debug_fused_trace(long long *host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(dqc::g_fg_trace), sizeof(long long) * 2 * dqc::FG_TRACE_N);

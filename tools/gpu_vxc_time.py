@@ -22,10 +22,11 @@ v = torch.randn(ngrid, dtype=torch.float64, device=dev)
 vg = torch.randn((3, ngrid), dtype=torch.float64, device=dev)
 for gga in (True, False):
     f = lambda: lib.grid_vxc(ao if gga else ao[0], nao, w, v, vg if gga else None)
-    f(); torch.cuda.synchronize()
+    vm = f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
         f()
     e1.record(); torch.cuda.synchronize()
-    print("vxc %s gga=%d: %.3f ms" % (kind, gga, e0.elapsed_time(e1) / 20))
+    print("vxc %s gga=%d lib %s: %.4f ms  checksum %.12e" % (kind, gga, os.path.basename(os.environ.get("DQC_AMD_LIB", "default")),
+                                                          e0.elapsed_time(e1) / 20, float(vm.sum())))
