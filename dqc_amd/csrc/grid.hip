@@ -70,6 +70,37 @@ DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1],
     }
 }
 
+// The same row dots with 16-byte loads (density_lr_kernel): phase 2 reads its B fragments with the panel's columns PERMUTED,
+// so that lane lr of the accumulator tiles (2 m, 2 m + 1) holds the ADJACENT AO columns 32 m + 2 lr and 32 m + 2 lr + 1 -- one
+// double2 load per tile pair instead of two 8-byte loads; an odd last tile keeps its plain layout.  C5 shape: 0.547 ms against
+// 0.564 ms (the permuted ds_read_b64 pattern has 2-way bank conflicts; with conflict-free reads it would be 0.535 ms.  Tried
+// instead: trading accumulators between neighbouring lanes with DPP swaps so that the LDS layout stays plain -- 0.572 ms).
+template <int NCT, int Q0>
+DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][4], const double *__restrict__ blkg, size_t cs,
+                                    const int (&roff)[4], int lr, int col0) {
+    // a batch = the NP double2 loads (+ the odd tile) of one (row, component); two batches in flight
+    constexpr int NQ = 4 - Q0, NB = 4 * NQ, NP = NCT / 2, ODD = NCT & 1, DP = 2;
+    double2 t2[DP][NP > 0 ? NP : 1];
+    double t1[DP];
+    auto issue = [&](int bt, double2 (&d2)[NP > 0 ? NP : 1], double &d1) {
+        const int r = bt / NQ, q = bt % NQ + Q0;
+        const double *base = blkg + q * cs + col0;  // uniform; tile pairs at immediate offsets
+#pragma unroll
+        for (int m = 0; m < NP; m++) d2[m] = *reinterpret_cast<const double2 *>(base + (roff[r] + lr) + m * 32);
+        if (ODD) d1 = base[roff[r] + (NCT - 1) * 16];
+    };
+    issue(0, t2[0], t1[0]);
+#pragma unroll
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt + 1 < NB) issue(bt + 1, t2[(bt + 1) % DP], t1[(bt + 1) % DP]);
+        const int r = bt / NQ, q = bt % NQ + Q0;
+#pragma unroll
+        for (int m = 0; m < NP; m++) p[r][q] += acc[2 * m][r] * t2[bt % DP][m].x + acc[2 * m + 1][r] * t2[bt % DP][m].y;
+        if (ODD) p[r][q] += acc[NCT - 1][r] * t1[bt % DP];
+        __builtin_amdgcn_sched_barrier(0);  // pin the pipeline: later batches must not be hoisted (spills)
+    }
+}
+
 template <int NCT, bool GGA>
 __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
@@ -269,6 +300,12 @@ DQC_DEV void den_trace(int k) {
 #define DEN_TRACE_POINT(k)
 #endif
 
+#ifdef DEN_EXP_UNPAIRED  // A/B builds: 8-byte epilogue loads
+constexpr bool DEN_PAIRED = false;
+#else
+constexpr bool DEN_PAIRED = true;
+#endif
+
 template <int NRT>
 struct LrGeom {
     static constexpr int RP = NRT * 16;
@@ -450,18 +487,26 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
 #pragma unroll
             for (int c = 1; c < NRT; c++)
                 if (kc == c) a4 = a1[c];
+            // B fragments with the panel's columns permuted (rowdot_epilogue_paired): tile 2 m + h, lane lr <- column
+            // 32 m + 2 lr + h (immediate offsets from one more base address)
             const double *b = sB + buf * B_SZ + lk * LSBP + lr;
+            const double *b2 = b + lr;
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const double av = a4[kk];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ct++) acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
+                for (int ct = 0; ct < NCT; ct++) {
+                    const double bv = (DEN_PAIRED && ct < 2 * (NCT / 2)) ? b2[kk * 4 * LSBP + 32 * (ct >> 1) + (ct & 1)]
+                                                                        : b[kk * 4 * LSBP + ct * 16];
+                    acc[ct] = mfma_f64(av, bv, acc[ct]);
+                }
             }
             if (kc + 1 < NRT) stage(buf ^ 1);
             __syncthreads();
         }
         DEN_TRACE_POINT(1);
-        rowdot_epilogue<NCT, GGA, 1>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
+        if constexpr (!DEN_PAIRED) rowdot_epilogue<NCT, GGA, 1>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
+        else if constexpr (GGA) rowdot_epilogue_paired<NCT, 1>(acc, p, aoblk, cs, roff, lr, jc * 16);
         DEN_TRACE_POINT(2);
     }
 #pragma unroll
@@ -498,7 +543,7 @@ static constexpr size_t density_lr_lds_bytes() {
 
 // widest phase-2 column panel per factor width (NRT tiles) that compiles without VGPR spills in GGA mode: 8 NRT phase-1 +
 // 8 NCT phase-2 accumulator registers + the epilogue's 4 NCT load-batch registers share 256; wider bases take more panels
-constexpr int lr_max_nct(int nrt) { return nrt <= 1 ? 16 : (nrt <= 3 ? 14 : (nrt <= 4 ? 13 : (nrt <= 6 ? 10 : 11))); }
+constexpr int lr_max_nct(int nrt) { return nrt <= 1 ? 16 : (nrt <= 3 ? 14 : (nrt <= 4 ? 12 : 10)); }
 
 template <int NRT, bool GGA>
 static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao, int ngrid,
