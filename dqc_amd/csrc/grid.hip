@@ -72,9 +72,10 @@ DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1],
 
 // The same row dots with 16-byte loads (density_lr_kernel): phase 2 reads its B fragments with the panel's columns PERMUTED,
 // so that lane lr of the accumulator tiles (2 m, 2 m + 1) holds the ADJACENT AO columns 32 m + 2 lr and 32 m + 2 lr + 1 -- one
-// double2 load per tile pair instead of two 8-byte loads; an odd last tile keeps its plain layout.  C5 shape: 0.547 ms against
-// 0.564 ms (the permuted ds_read_b64 pattern has 2-way bank conflicts; with conflict-free reads it would be 0.535 ms.  Tried
-// instead: trading accumulators between neighbouring lanes with DPP swaps so that the LDS layout stays plain -- 0.572 ms).
+// double2 load per tile pair instead of two 8-byte loads; an odd last tile keeps its plain layout.  C5 shape: 0.54 ms against
+// 0.564 ms (tools/gpu_den_time.py; the staged panel gets an odd row stride so that the permuted ds_read_b64 pattern stays
+// conflict-free).  Tried instead: trading accumulators between neighbouring lanes with DPP swaps so that the LDS layout stays
+// plain -- 0.572 ms.
 template <int NCT, int Q0>
 DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][4], const double *__restrict__ blkg, size_t cs,
                                     const int (&roff)[4], int lr, int col0) {
@@ -306,6 +307,13 @@ constexpr bool DEN_PAIRED = false;
 constexpr bool DEN_PAIRED = true;
 #endif
 
+// LDS row stride of the staged L^T panel.  The permuted fragment reads (lane lr at double 2 lr of row lk) are conflict-free
+// when the stride is ODD (rows lk and lk + 1 of a half-wave then take the even and the odd doubles); the plain reads want
+// stride == 16 (mod 32)
+constexpr int lr_panel_stride(int nct) {
+    return (DEN_PAIRED && nct >= 2) ? nct * 16 + 1 : (((nct * 16) & 31) == 16 ? nct * 16 : nct * 16 + 16);
+}
+
 template <int NRT>
 struct LrGeom {
     static constexpr int RP = NRT * 16;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = LrGeom<NRT>::RP, RPS = LrGeom<NRT>::RPS;
     constexpr int LSB = NCT * 16;
-    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    constexpr int LSBP = lr_panel_stride(NCT);
     constexpr int A_SZ = DEN_BM * DEN_SA;
     constexpr int B_SZ = DEN_KC * (LSBP > RPS ? LSBP : RPS);
     constexpr int NL2 = (DEN_KC * RP / 2 + DEN_NT - 1) / DEN_NT;   // double2 loads of the L chunk per thread
@@ -472,7 +480,11 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
             for (int i = 0; i < NB2; i++) {
                 const int e = (tid + i * DEN_NT) * 2;
                 const int row = e / LSB, col = e - row * LSB;
-                if (row < DEN_KC) *reinterpret_cast<double2 *>(sB + buf * B_SZ + row * LSBP + col) = pb[i];
+                if (row < DEN_KC) {  // two 8-byte stores: an odd row stride leaves every other row 8-byte aligned only
+                    double *d = sB + buf * B_SZ + row * LSBP + col;
+                    d[0] = pb[i].x;
+                    d[1] = pb[i].y;
+                }
             }
         };
         __syncthreads();
@@ -535,15 +547,14 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
 
 template <int NRT, int NCT>
 static constexpr size_t density_lr_lds_bytes() {
-    constexpr int LSB = NCT * 16;
-    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    constexpr int LSBP = lr_panel_stride(NCT);
     constexpr int RPS = LrGeom<NRT>::RPS;
     return sizeof(double) * 2 * (DEN_BM * DEN_SA + DEN_KC * (LSBP > RPS ? LSBP : RPS));
 }
 
 // widest phase-2 column panel per factor width (NRT tiles) that compiles without VGPR spills in GGA mode: 8 NRT phase-1 +
 // 8 NCT phase-2 accumulator registers + the epilogue's 4 NCT load-batch registers share 256; wider bases take more panels
-constexpr int lr_max_nct(int nrt) { return nrt <= 1 ? 16 : (nrt <= 3 ? 14 : (nrt <= 4 ? 12 : 10)); }
+constexpr int lr_max_nct(int nrt) { return nrt <= 3 ? 14 : (nrt <= 4 ? 12 : 10); }
 
 template <int NRT, bool GGA>
 static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao, int ngrid,
