@@ -12,7 +12,7 @@ from bench import source_sha16  # noqa: E402
 
 KEYS = [("grid_fused", ("fused_grid_kernel",)), ("jk_tiles", ("j_stream_kernel", "jk_tiles_kernel")),
         ("grid_density", ("density_lr_kernel",)), ("grid_density_dense", ("density_kernel",)),
-        ("grid_vxc", ("vxc_wsu_kernel", "vxc_ws_kernel")), ("grid_vxc_ws2", ("vxc_ws2_kernel",))]
+        ("grid_vxc", ("vxc_wsd_kernel", "vxc_wsu_kernel", "vxc_ws_kernel")), ("grid_vxc_ws2", ("vxc_ws2_kernel",))]
 
 
 def main():
