@@ -11,6 +11,11 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt /tmp/prof_f /tmp/prof_w /tmp/prof_m
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- python $repo/bench.py --profile-mode --molecules $nm --steps 10 --warmup 2 --min-seconds 0 > $out/${tag}_bench_under_rocprof.json 2> /tmp/kt.err
 python $repo/tools/rocpd_summary.py $(find /tmp/prof_kt -name '*.db' | head -1) > $out/${tag}_kernel_stats_bench_steps10.txt 2>&1
+# the same with ONE stream: kernels do not overlap, so the profiler's average duration is the per-launch duration that bench.py
+# measures with HIP events for `roofline` (with 3 streams the kernels of different molecules share the chip and stretch)
+rm -rf /tmp/prof_k1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_k1 -- python $repo/bench.py --profile-mode --molecules $nm --steps 10 --warmup 2 --min-seconds 0 --streams 1 > $out/${tag}_bench_under_rocprof_streams1.json 2> /tmp/k1.err
+python $repo/tools/rocpd_summary.py $(find /tmp/prof_k1 -name '*.db' | head -1) > $out/${tag}_kernel_stats_bench_steps10_streams1.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- python $repo/bench.py --profile-mode --molecules 4 --steps 3 --warmup 1 --min-seconds 0 > /dev/null 2> /tmp/f.err
 python $repo/tools/pmc_summary.py $(find /tmp/prof_f -name '*.db' | head -1) FETCH_SIZE > $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt 2>&1
 python $repo/tools/make_traffic_json.py $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt $out/${tag}_pmc_traffic.json > /dev/null
