@@ -97,7 +97,8 @@ def parse_moldesc(moldesc, dtype=torch.float64, device=torch.device("cpu")):
 
 
 def make_atombases(atomzs, atompos, basis) -> List[AtomCGTOBasis]:
-    """basis: str | list of str | list of list of CGTOBasis | dict (the forms of dqc/system/mol.py:357-400)"""
+    """basis: str | list of str | list of CGTOBasis | list of list of CGTOBasis | dict keyed by element symbol or atomic
+    number (the forms of dqc/system/mol.py:357-400)"""
     natm = len(atomzs)
     out = []
     for i in range(natm):
@@ -107,7 +108,10 @@ def make_atombases(atomzs, atompos, basis) -> List[AtomCGTOBasis]:
         elif isinstance(basis, dict):
             bi = basis[int(z)] if int(z) in basis else basis[[k for k, v in periodic_table_atomz.items() if v == int(z)][0]]
             b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
+        elif len(basis) > 0 and isinstance(basis[0], CGTOBasis):
+            b = basis  # one flat list of CGTOBasis: the same shells on every atom (mol.py:385-387)
         else:
+            assert len(basis) == natm, "a basis list needs one entry per atom"
             bi = basis[i]
             b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
         out.append(AtomCGTOBasis(atomz=z, bases=b, pos=atompos[i]))

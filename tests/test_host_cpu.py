@@ -83,6 +83,12 @@ def test_basis_loader_errors_and_forms():
     assert len(ab[0].bases) == 2 and len(ab[1].bases) == 3
     ab2 = make_atombases(zs, pos, ["3-21G", loadbasis("8:sto-3g")])
     assert len(ab2[1].bases) == 3
+    # one flat list of CGTOBasis = the same shells on every atom (mol.py:385-387; test_hf.py:124-126)
+    flat = loadbasis("1:3-21G")
+    ab3 = make_atombases(zs, pos, flat)
+    assert [len(a.bases) for a in ab3] == [2, 2] and ab3[1].bases is flat
+    with pytest.raises(AssertionError):
+        make_atombases(zs, pos, ["3-21G"])  # a list of names needs one entry per atom
     z3, p3 = parse_moldesc("O 0 0 0.2156; H 0 1.4749 -0.8625; H 0 -1.4749 -0.8625")
     assert z3.tolist() == [8, 1, 1] and p3.shape == (3, 3)
 
