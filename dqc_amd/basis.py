@@ -86,7 +86,9 @@ def parse_moldesc(moldesc, dtype=torch.float64, device=torch.device("cpu")):
         assert len(atomzs_raw) == len(atompos_raw), "Mismatch length of atomz and atompos"
         assert len(atomzs_raw) > 0, "Empty atom list"
         if not isinstance(atomzs_raw, torch.Tensor):
-            atomzs = torch.tensor([get_atomz(at) for at in atomzs_raw], device=device)
+            zl = [get_atomz(at) for at in atomzs_raw]
+            # fractional charges straight to the working precision (torch.tensor of Python floats would be float32)
+            atomzs = torch.tensor(zl, dtype=dtype if any(isinstance(z, float) for z in zl) else None, device=device)
         else:
             atomzs = atomzs_raw.to(device)
         atompos = torch.as_tensor(np.asarray(atompos_raw) if not isinstance(atompos_raw, torch.Tensor)

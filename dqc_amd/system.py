@@ -23,19 +23,29 @@ class Mol:
         self._atomzs, self._atompos = atomzs, atompos
         self._atombases = make_atombases(atomzs, atompos, basis)
         nelecs = float(torch.sum(atomzs.to(torch.float64))) - charge
-        if abs(nelecs - round(nelecs)) > 1e-9:
-            # the reference fills fractional occupations (mol.py:421-443 via occnumber); the MI355X driver occupies whole
-            # orbitals only -- fractional nuclear charges are fine as long as `charge` makes the electron count integral
-            raise NotImplementedError("non-integer electron count %g: choose `charge` so that sum(Z) - charge is an integer"
-                                      % nelecs)
+        assert nelecs >= 0, "Only %f electrons, but needs %f charge" % (nelecs + charge, charge)
+        # mol.py:402-419: a floating-point atomz / charge / spin switches to FRACTIONAL mode -- the electron count need not be
+        # an integer, the spin must then be given, and the last orbital of each spin channel is partially occupied
+        # (safeops.occnumber); integer input keeps the integer bookkeeping and the spin / electron-count parity check
+        def _isfloat(x):
+            return isinstance(x, float) or (isinstance(x, torch.Tensor) and x.is_floating_point())
+        self._frac_mode = bool(atomzs.is_floating_point() or _isfloat(charge) or (spin is not None and _isfloat(spin)))
         if spin is None:
+            assert not self._frac_mode, "Fraction case requires the spin argument to be specified"
             spin = int(round(nelecs)) % 2
-        if (int(round(nelecs)) - spin) % 2 != 0 or spin < 0:
-            raise AssertionError("inconsistent spin %d for %g electrons" % (spin, nelecs))
+        else:
+            assert spin >= 0, "inconsistent spin %g" % spin
+            if not self._frac_mode:
+                assert (int(round(nelecs)) - spin) % 2 == 0, "Spin %d is not suited for %d electrons" % (spin, round(nelecs))
         self._spin, self._charge = spin, charge
         self._nelecs = nelecs
-        self._nup = (int(round(nelecs)) + spin) // 2
-        self._ndn = (int(round(nelecs)) - spin) // 2
+        if self._frac_mode:
+            self._ndn = (nelecs - float(spin)) * 0.5
+            self._nup = self._ndn + float(spin)
+            assert self._ndn >= 0, "spin %g needs more than %g electrons" % (spin, nelecs)
+        else:
+            self._nup = (int(round(nelecs)) + spin) // 2
+            self._ndn = (int(round(nelecs)) - spin) // 2
         if vext is not None:
             vext = vext.to(device=self._device, dtype=dtype)
         # mol.py:445-474: a tensor -> 1-tuple; every element flattened ((3,), (3, 3) -> (9,), ...)
@@ -117,15 +127,23 @@ class Mol:
         q = (z.unsqueeze(0) * z.unsqueeze(1)) / r
         return (torch.sum(q) - torch.sum(torch.diagonal(q))) * 0.5
 
+    def _occnumber(self, a, n=None):
+        """occupations (at most 1 each) of the lowest orbitals summing to `a`: floor(a) ones, then the fractional rest
+        (dqc/utils/safeops.py:21-60); `n` pads with empty orbitals"""
+        import math
+        lo, hi = int(math.floor(a + 1e-12)), int(math.ceil(a - 1e-12))
+        w = torch.zeros(max(hi, n or 0), dtype=self._dtype, device=self._device)
+        w[:lo] = 1.0
+        if hi > lo:
+            w[hi - 1] = a - lo
+        return w
+
     def get_orbweight(self, polarized: bool = False):
         """occupation numbers of the lowest orbitals (mol.py:421-443, safeops.occnumber)"""
-        dev = self._device
+        wu = self._occnumber(self._nup)
         if polarized:
             from .utils.datastruct import SpinParam
-            wu = torch.ones(self._nup, dtype=self._dtype, device=dev)
-            wd = torch.ones(self._ndn, dtype=self._dtype, device=dev) if self._ndn > 0 \
-                else torch.zeros(1, dtype=self._dtype, device=dev)  # mol.py:437-441: one empty orbital
+            # mol.py:437-441: an empty spin-down channel keeps one (empty) orbital
+            wd = self._occnumber(self._ndn) if self._ndn > 0 else self._occnumber(0, n=1)
             return SpinParam(u=wu, d=wd)
-        w = torch.cat([torch.full((self._ndn,), 2.0, dtype=self._dtype, device=dev),
-                       torch.full((self._nup - self._ndn,), 1.0, dtype=self._dtype, device=dev)])
-        return w
+        return wu + self._occnumber(self._ndn, n=wu.numel())

@@ -73,7 +73,7 @@ class Hamilton:
         t = self.t
         olp = torch.as_tensor(natives.int1e("ovlp", t))
         kin = torch.as_tensor(natives.int1e("kin", t))
-        nuc = torch.as_tensor(natives.int1e("nuc", t))
+        nuc = torch.as_tensor(natives.int1e("nuc", t, np.asarray(t.atomzs, dtype=np.float64)))  # fractional Z: molintor.py:105-112
         self.olp_mat = self.convert2(olp)
         if self.efield is not None:
             fac = 1.0
@@ -272,13 +272,30 @@ class Engine:
         if not self.is_hf:
             rgrid, dvol = ogrid.get_predefined_grid(grid, tables.atomzs, tables.atompos)
             self.h.setup_grid(rgrid, dvol, self.xc)
-        nel = int(round(float(np.sum(tables.atomzs))))
-        assert (nel - spin) % 2 == 0, "spin inconsistent with the electron count"
-        # restricted occupations [2, ..., 2, 1, ..., 1] (mol.py:421-443): closed shell for spin 0, the reference's
-        # restricted open-shell treatment otherwise
-        nup, ndn = (nel + spin) // 2, (nel - spin) // 2
-        self.norb = nup
-        self.orb_weight = torch.cat([torch.full((ndn,), 2.0, dtype=torch.float64), torch.ones(nup - ndn, dtype=torch.float64)])
+        nel_f = float(np.sum(tables.atomzs))
+        if abs(nel_f - round(nel_f)) > 1e-12 or isinstance(spin, float):
+            # fractional mode (mol.py:402-443): n_dn = (n - spin) / 2 electrons per spin channel, the last orbital of each
+            # channel partially occupied (safeops.occnumber: floor(a) ones, then a - floor(a))
+            def occ(a, n=0):
+                lo, hi = int(np.floor(a + 1e-12)), int(np.ceil(a - 1e-12))
+                w = torch.zeros(max(hi, n), dtype=torch.float64)
+                w[:lo] = 1.0
+                if hi > lo:
+                    w[hi - 1] = a - lo
+                return w
+            ndn_f = (nel_f - spin) * 0.5
+            assert ndn_f >= 0
+            wu = occ(ndn_f + spin)
+            self.orb_weight = wu + occ(ndn_f, wu.numel())
+            self.norb = wu.numel()
+        else:
+            nel = int(round(nel_f))
+            assert (nel - spin) % 2 == 0, "spin inconsistent with the electron count"
+            # restricted occupations [2, ..., 2, 1, ..., 1] (mol.py:421-443): closed shell for spin 0, the reference's
+            # restricted open-shell treatment otherwise
+            nup, ndn = (nel + spin) // 2, (nel - spin) // 2
+            self.norb = nup
+            self.orb_weight = torch.cat([torch.full((ndn,), 2.0, dtype=torch.float64), torch.ones(nup - ndn, dtype=torch.float64)])
         self.enuc = nuclei_energy(tables.atomzs, tables.atompos)
 
     def dm2scp(self, dm):

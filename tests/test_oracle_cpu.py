@@ -483,3 +483,18 @@ def test_scan_correlation_oracle_constraints_and_derivatives():
     eu, vr, vsu, vtu = ox.mgga_c_scan(rho, sg, ta)
     ep, (a, b), c, d = ox.mgga_c_scan_pol(rho / 2, rho / 2, sg, ta)
     assert np.array_equal(eu, ep) and np.allclose(vr, a) and np.array_equal(vsu, c) and np.array_equal(vtu, d)
+
+
+FRAC = [("h2_z120_z125_321g_rhf", "3-21G", None, None), ("h2_z120_z125_6311ppgss_lda_sg3", "6-311++G**", "lda_x", "sg3"),
+        ("h2o_z83_z11_ccpvdz_pbe_sg2", "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2")]
+
+
+@pytest.mark.parametrize("name,basis,xc,grid", FRAC, ids=[f[0] for f in FRAC])
+def test_oracle_fractional_mode_vs_reference_generated_golden(name, basis, xc, grid, golden_dir):
+    """fractional nuclear charges and occupations (mol.py:402-443, molintor.py:105-112): the reference's own Mol / HF / KS run in
+    fractional mode (tools/make_golden.py: CASES_FRAC) against the restatement -- energy, occupations, converged density"""
+    g = np.load(os.path.join(golden_dir, "reffrac_%s.npz" % name))
+    kw = {} if xc is None else {"xc": xc, "grid": grid}
+    e, eng = oh.run_scf((g["atomzs"].tolist(), g["atompos"].tolist()), basis, spin=float(g["spin"]), tol=1e-10, **kw)
+    assert np.allclose(eng.orb_weight.numpy(), g["orb_weight"], atol=1e-12)
+    assert abs(e - float(g["e_tot"])) < 1e-9, (e, float(g["e_tot"]))

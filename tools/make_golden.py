@@ -258,8 +258,40 @@ def write_kats():
         json.dump(kat, f, indent=1)
 
 
+# fractional mode (mol.py:402-443): floating-point atomzs, spin given, last orbital partially occupied.
+# (moldesc, basis, xc, grid, spin) -- the H2-like systems of test_hf.py:245-256 / test_ks.py:521-534 and a heavier one
+CASES_FRAC = {
+    "h2_z120_z125_321g_rhf": (([1.2, 1.25], [[-0.5, 0, 0], [0.5, 0, 0]]), "3-21G", None, None, 0),
+    "h2_z120_z125_6311ppgss_lda_sg3": (([1.2, 1.25], [[-0.5, 0, 0], [0.5, 0, 0]]), "6-311++G**", "lda_x", "sg3", 0),
+    # water with Z = (8.3, 1.1, 1.1): 10.5 electrons, the (non-degenerate) 4a1 orbital holds the half electron
+    "h2o_z83_z11_ccpvdz_pbe_sg2": (([8.3, 1.1, 1.1], H2O[1]), "cc-pvdz", "gga_x_pbe+gga_c_pbe", "sg2", 0),
+}
+
+
+def run_case_frac(name):
+    moldesc, basis, xc, grid, spin = CASES_FRAC[name]
+    t0 = time.time()
+    kw = {"spin": spin}
+    if grid is not None:
+        kw["grid"] = grid
+    zs = torch.tensor(moldesc[0], dtype=torch.float64)
+    mol = rh.ref_mol((zs, torch.tensor(moldesc[1], dtype=torch.float64)), basis, **kw)
+    qc = dqc.HF(mol, restricted=True) if xc is None else dqc.KS(mol, xc=xc, restricted=True)
+    qc.run()
+    dm = qc.aodm()
+    hamilt = mol.get_hamiltonian()
+    X = hamilt._orthozer._orthozer.detach()
+    out = {"atomzs": np.array(moldesc[0], dtype=float), "atompos": np.array(moldesc[1], dtype=float), "spin": float(spin),
+           "e_tot": float(qc.energy()), "e_nuc": float(mol.get_nuclei_energy()),
+           "orb_weight": mol.get_orbweight().numpy(), "orb_weight_u": mol.get_orbweight(polarized=True).u.numpy(),
+           "orb_weight_d": mol.get_orbweight(polarized=True).d.numpy(), "dm_conv_ao": (X @ dm @ X.T).numpy()}
+    np.savez_compressed(os.path.join(GOLD, "reffrac_%s.npz" % name), **out)
+    print("%-36s E = %.10f  weights %s (%.1f s)" % (name, out["e_tot"], out["orb_weight"], time.time() - t0), flush=True)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     write_kats()
-    for c in (sys.argv[1:] or SMALL + list(CASES_POL) + list(CASES_DF)):
-        (run_case_pol if c in CASES_POL else (run_case_df if c in CASES_DF else run_case))(c)
+    for c in (sys.argv[1:] or SMALL + list(CASES_POL) + list(CASES_DF) + list(CASES_FRAC)):
+        (run_case_pol if c in CASES_POL else (run_case_df if c in CASES_DF else
+                                              (run_case_frac if c in CASES_FRAC else run_case)))(c)

@@ -262,6 +262,16 @@ def _calc(self):
         out = _nat.int1e("kin", t)
     elif name.startswith("int1e_nuc"):
         out = _nat.int1e("nuc", t)
+    elif name.startswith("int1e_rinv"):
+        # fractional-Z nuclear attraction (molintor.py:105-112): 1/|r - R| about env[4:7] (libcint PTR_RINV_ORIG, set by
+        # LibcintWrapper.centre_on_r).  The origin is always one of the atoms: = -(nuclear attraction of a unit charge there)
+        env = np.asarray(t.env)
+        orig = env[4:7]
+        hit = [i for i in range(t.natm) if np.allclose(env[int(t.atm[i][1]):int(t.atm[i][1]) + 3], orig, atol=1e-14)]
+        assert len(hit) == 1, "harness: rinv origin is not a (unique) atom position"
+        zs = np.zeros(t.natm)
+        zs[hit[0]] = 1.0
+        out = -_nat.int1e("nuc", t, zs)
     elif name.startswith("int2e"):
         out = _nat.int2e(t)
     else:
