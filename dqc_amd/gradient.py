@@ -47,7 +47,7 @@ def nuclear_gradient(qc) -> torch.Tensor:
     norbs = [eng.norb.u, eng.norb.d] if pol else [eng.norb]
     d_aos, w_ao = [], 0.0
     for dm, fock, w, n in zip(dms, focks, weights, norbs):
-        eps, C = torch.linalg.eigh((fock + fock.transpose(-2, -1)) * 0.5)
+        eps, C = eng._eigpairs(fock)  # generalised problem when the basis is not orthogonalised
         Cocc = C[:, :n]
         w_ao = w_ao + X @ ((Cocc * (w * eps[:n]).unsqueeze(0)) @ Cocc.T) @ X.T     # energy-weighted density
         d = X @ dm @ X.T

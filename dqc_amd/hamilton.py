@@ -72,6 +72,7 @@ class HamiltonMI355(_Base):
             self._orthozer = evec[:, acc] * ev[acc] ** (-0.5)
         else:
             self._orthozer = torch.eye(self._nao_ao, dtype=self.dtype, device=self.device)
+        self.orthogonalized = bool(orthozer)  # False: the API's matrices live in the raw AO basis (overlap != 1)
         if df is None:
             self._df = None
         else:  # hcgto.py:60-64
@@ -357,13 +358,18 @@ class HamiltonMI355(_Base):
         return None
 
     def aodm2dens(self, dm, xyz):
-        """density at arbitrary points (hcgto.py:283-299)"""
-        dao = self._unconvert_dm(dm)
+        """density at arbitrary points (hcgto.py:283-299): dm (*BD, nao, nao), xyz (*BR, ndim) -> (*BRD), the batch dimensions
+        of the two broadcast against each other as in the reference"""
+        dao = self._unconvert_dm(dm.to(self.device))
         pts = xyz.reshape(-1, xyz.shape[-1]).to(self.device).contiguous()
-        ao = lib.eval_gto(self._tab, pts, 0)
-        dp = lib.pad_matrix((dao + dao.transpose(-2, -1)) * 0.5, self._ld)
-        rho, _ = lib.grid_density(ao, self._nao_ao, dp, False)
-        return rho.reshape(xyz.shape[:-1])
+        ao = lib.eval_gto(self._tab, pts, 0)  # (npts, ld)
+        if dao.dim() == 2:
+            dp = lib.pad_matrix((dao + dao.transpose(-2, -1)) * 0.5, self._ld)
+            rho, _ = lib.grid_density(ao, self._nao_ao, dp, False)
+            return rho.reshape(xyz.shape[:-1])
+        basis = ao[:, :self._nao_ao].reshape(*xyz.shape[:-1], self._nao_ao)  # (*BR, nao)
+        dens = torch.matmul(dao, basis.unsqueeze(-1))  # (*BRD, nao, 1)
+        return torch.matmul(basis.unsqueeze(-2), dens).squeeze(-1).squeeze(-1)
 
     # ------------------------------------------------------------------ energies
     def get_e_hcore(self, dm):

@@ -42,6 +42,25 @@ class _Engine:
         self.knvext = self.hamilton.get_kinnucl()
         self.shape = self.knvext.shape
         self.dtype, self.device = self.knvext.dtype, self.knvext.device
+        # Mol(orthogonalize_basis=False): the Fock matrix lives in the raw AO basis and `diagonalize` is the generalised problem
+        # F C = S C e (hf.py:227-247: lsymeig(A=fock, M=ovlp)).  Solved through S^-1/2: C = S^-1/2 U, U from eigh(S^-1/2 F S^-1/2)
+        self.ovlp, self._sinvh = None, None
+        if not getattr(self.hamilton, "orthogonalized", True):
+            self.ovlp = self.hamilton.get_overlap().fullmatrix()
+            ev, evec = torch.linalg.eigh(self.ovlp)
+            self._sinvh = (evec * ev ** -0.5) @ evec.transpose(-2, -1)
+
+    def _eigpairs(self, fock):
+        """(eigenvalues ascending, eigenvectors) of the symmetrised Fock matrix; S-orthonormal vectors of F C = S C e when the
+        basis is not orthogonal"""
+        fock = (fock + fock.transpose(-2, -1)) * 0.5
+        if self._sinvh is None:
+            return torch.linalg.eigh(fock)
+        e, u = torch.linalg.eigh(self._sinvh @ fock @ self._sinvh)
+        return e, self._sinvh @ u
+
+    def _eigvecs(self, fock):
+        return self._eigpairs(fock)[1]
 
     def get_system(self):
         return self._system
@@ -74,17 +93,14 @@ class _Engine:
         if self.polarized:
             out = []
             for f, w, n in ((scp[0], self.orb_weight.u, self.norb.u), (scp[1], self.orb_weight.d, self.norb.d)):
-                _, evec = torch.linalg.eigh((f + f.transpose(-2, -1)) * 0.5)
-                out.append(self.hamilton.ao_orb2dm(evec[..., :n], w))
+                out.append(self.hamilton.ao_orb2dm(self._eigvecs(f)[..., :n], w))
             return SpinParam(u=out[0], d=out[1])
         return self.hamilton.ao_orb2dm(self.scp2orb(scp), self.orb_weight)
 
     def scp2orb(self, scp):
         """occupied orbitals of a (restricted) Fock matrix: the `diagonalize` step of hf.py:227-247"""
-        fock = (scp + scp.transpose(-2, -1)) * 0.5
-        # generalised problem F C = S C e with S = identity in the orthogonalised basis
-        _, evec = torch.linalg.eigh(fock)
-        return evec[..., :self.norb]
+        # generalised problem F C = S C e; S = identity in the orthogonalised basis
+        return self._eigvecs(scp)[..., :self.norb]
 
     def scp2scp(self, scp):
         return self.dm2scp(self.scp2dm(scp))
@@ -169,7 +185,7 @@ class SCF_QCCalc:
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
-            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform:
+            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and eng.ovlp is None:
                 purified = GraphedSCFStep(eng)
             elif not pol:
                 graphed = GraphedFock(eng)
@@ -179,11 +195,12 @@ class SCF_QCCalc:
         self.converged = self.stalled = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
+            S = eng.ovlp
             if pol:
                 dms = torch.stack([dm.u, dm.d])
-                err = fock @ dms - dms @ fock
+                err = fock @ dms - dms @ fock if S is None else fock @ dms @ S - S @ dms @ fock
             else:
-                err = fock @ dm - dm @ fock  # [F, D], S = 1
+                err = fock @ dm - dm @ fock if S is None else fock @ dm @ S - S @ dm @ fock  # [F, D] (S = 1) or F D S - S D F
             # ONE host read per iteration: max |[F, D]|, the projector error of the step just taken, and the new row of the
             # DIIS Gram matrix (this error vector against the stored ones) travel together
             ev = err.reshape(-1)
@@ -198,7 +215,7 @@ class SCF_QCCalc:
                 fock = eng.dm2scp(dm)
                 perr = None
                 dmm = torch.stack([dm.u, dm.d]) if pol else dm
-                err = fock @ dmm - dmm @ fock
+                err = fock @ dmm - dmm @ fock if S is None else fock @ dmm @ S - S @ dmm @ fock
                 ev = err.reshape(-1)
                 h2 = yield torch.cat([err.abs().max().reshape(1), (torch.stack(hist + [ev]) * ev).sum(-1)])
                 emax, grow = float(h2[0]), h2[1:]
