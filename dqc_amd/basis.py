@@ -105,17 +105,18 @@ def make_atombases(atomzs, atompos, basis) -> List[AtomCGTOBasis]:
     out = []
     for i in range(natm):
         z = atomzs[i].item() if isinstance(atomzs[i], torch.Tensor) else atomzs[i]
+        zi = int(round(z))  # a fractional charge takes the basis of the NEAREST element (mol.py:112-113: torch.round)
         if isinstance(basis, str):
-            b = loadbasis("%d:%s" % (int(z), basis))
+            b = loadbasis("%d:%s" % (zi, basis))
         elif isinstance(basis, dict):
-            bi = basis[int(z)] if int(z) in basis else basis[[k for k, v in periodic_table_atomz.items() if v == int(z)][0]]
-            b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
+            bi = basis[zi] if zi in basis else basis[[k for k, v in periodic_table_atomz.items() if v == zi][0]]
+            b = loadbasis("%d:%s" % (zi, bi)) if isinstance(bi, str) else bi
         elif len(basis) > 0 and isinstance(basis[0], CGTOBasis):
             b = basis  # one flat list of CGTOBasis: the same shells on every atom (mol.py:385-387)
         else:
             assert len(basis) == natm, "a basis list needs one entry per atom"
             bi = basis[i]
-            b = loadbasis("%d:%s" % (int(z), bi)) if isinstance(bi, str) else bi
+            b = loadbasis("%d:%s" % (zi, bi)) if isinstance(bi, str) else bi
         out.append(AtomCGTOBasis(atomz=z, bases=b, pos=atompos[i]))
     return out
 

@@ -10,7 +10,7 @@ from .hamilton import HamiltonMI355
 
 
 class Mol:
-    def __init__(self, moldesc, basis, *, grid="sg3", spin: Optional[int] = None, charge: int = 0,
+    def __init__(self, moldesc, basis, *, grid="sg3", spin: Optional[int] = None, charge: int = 0, orb_weights=None,
                  orthogonalize_basis: bool = True, ao_parameterizer: str = "qr", efield=None, vext=None,
                  dtype=torch.float64, device="cuda"):
         if dtype != torch.float64:
@@ -18,10 +18,29 @@ class Mol:
         self._dtype = dtype
         self._device = torch.device(device)
         self._grid_inp = grid
+        self._basis_inp = basis
         self._grid = None
         atomzs, atompos = parse_moldesc(moldesc, dtype=dtype)
         self._atomzs, self._atompos = atomzs, atompos
         self._atombases = make_atombases(atomzs, atompos, basis)
+        self._user_weights = None
+        if orb_weights is not None:
+            # mol.py:143-167: explicit occupations (SpinParam of equally long 1-D tensors); electron count, spin and charge
+            # follow from them
+            from .utils.datastruct import SpinParam
+            if not isinstance(orb_weights, SpinParam):
+                raise TypeError("Specifying orb_weights must be in SpinParam type")
+            assert orb_weights.u.ndim == 1 and orb_weights.d.ndim == 1 and len(orb_weights.u) == len(orb_weights.d)
+            wu, wd = orb_weights.u.to(dtype), orb_weights.d.to(dtype)
+            if not (bool(torch.all(wu[:-1] - wu[1:] > -1e-4)) and bool(torch.all(wd[:-1] - wd[1:] > -1e-4))):
+                import warnings
+                warnings.warn("The orbitals should be ordered in a non-increasing manner. "
+                              "Otherwise, some calculations might be wrong.")
+            self._user_weights = SpinParam(u=wu.to(self._device), d=wd.to(self._device))
+            spin = float(wu.sum() - wd.sum())
+            charge = float(torch.sum(atomzs.to(torch.float64))) - float(wu.sum() + wd.sum())
+            if abs(spin - round(spin)) < 1e-12 and abs(charge - round(charge)) < 1e-12 and not atomzs.is_floating_point():
+                spin, charge = int(round(spin)), int(round(charge))
         nelecs = float(torch.sum(atomzs.to(torch.float64))) - charge
         assert nelecs >= 0, "Only %f electrons, but needs %f charge" % (nelecs + charge, charge)
         # mol.py:402-419: a floating-point atomz / charge / spin switches to FRACTIONAL mode -- the electron count need not be
@@ -30,7 +49,9 @@ class Mol:
         def _isfloat(x):
             return isinstance(x, float) or (isinstance(x, torch.Tensor) and x.is_floating_point())
         self._frac_mode = bool(atomzs.is_floating_point() or _isfloat(charge) or (spin is not None and _isfloat(spin)))
-        if spin is None:
+        if self._user_weights is not None:
+            pass  # spin / charge were derived from the weights: nothing to validate
+        elif spin is None:
             assert not self._frac_mode, "Fraction case requires the spin argument to be specified"
             spin = int(round(nelecs)) % 2
         else:
@@ -39,10 +60,10 @@ class Mol:
                 assert (int(round(nelecs)) - spin) % 2 == 0, "Spin %d is not suited for %d electrons" % (spin, round(nelecs))
         self._spin, self._charge = spin, charge
         self._nelecs = nelecs
-        if self._frac_mode:
+        if self._frac_mode or self._user_weights is not None:
             self._ndn = (nelecs - float(spin)) * 0.5
             self._nup = self._ndn + float(spin)
-            assert self._ndn >= 0, "spin %g needs more than %g electrons" % (spin, nelecs)
+            assert self._ndn >= -1e-12, "spin %g needs more than %g electrons" % (spin, nelecs)
         else:
             self._nup = (int(round(nelecs)) + spin) // 2
             self._ndn = (int(round(nelecs)) - spin) // 2
@@ -107,13 +128,27 @@ class Mol:
     def get_hamiltonian(self):
         return self._hamilton
 
+    def make_copy(self, **kwargs):
+        """a new Mol identical to this one except for the constructor arguments given (mol.py:298-326)"""
+        parameters = {"moldesc": (self._atomzs, self._atompos), "basis": self._basis_inp,
+                      "orthogonalize_basis": self._orthogonalize_basis, "ao_parameterizer": self._aoparamzer,
+                      "grid": self._grid_inp, "spin": self._spin, "charge": self._charge,
+                      "orb_weights": self._user_weights, "efield": self._efield, "vext": self._vext,
+                      "dtype": self._dtype, "device": self._device}
+        parameters.update(kwargs)
+        if parameters["orb_weights"] is not None:  # spin / charge follow from the weights
+            parameters.pop("spin"), parameters.pop("charge")
+        return Mol(**parameters)
+
     def requires_grid(self):
         """mol.py:285-286: only an external potential needs the grid outside KS"""
         return self._vext is not None
 
     def setup_grid(self):
         if self._grid is None:
-            self._grid = get_predefined_grid(self._grid_inp, self._atomzs.tolist(), self._atompos.to(self._device),
+            # element-wise grid presets and Becke radii by the nearest element (mol.py:262-267: atomzs_int)
+            self._grid = get_predefined_grid(self._grid_inp, [int(round(float(z))) for z in self._atomzs],
+                                             self._atompos.to(self._device),
                                              dtype=self._dtype, device=self._device)
 
     def get_grid(self):
@@ -139,7 +174,10 @@ class Mol:
         return w
 
     def get_orbweight(self, polarized: bool = False):
-        """occupation numbers of the lowest orbitals (mol.py:421-443, safeops.occnumber)"""
+        """occupation numbers of the lowest orbitals (mol.py:421-443, safeops.occnumber), or the user's `orb_weights`"""
+        if self._user_weights is not None:
+            w = self._user_weights
+            return w if polarized else w.u + w.d
         wu = self._occnumber(self._nup)
         if polarized:
             from .utils.datastruct import SpinParam
