@@ -185,7 +185,7 @@ class SCF_QCCalc:
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
-            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and eng.ovlp is None:
+            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and getattr(eng, "ovlp", None) is None:
                 purified = GraphedSCFStep(eng)
             elif not pol:
                 graphed = GraphedFock(eng)
@@ -195,7 +195,7 @@ class SCF_QCCalc:
         self.converged = self.stalled = False
         for it in range(int(opts["maxiter"])):
             self.niter = it + 1
-            S = eng.ovlp
+            S = getattr(eng, "ovlp", None)  # overlap of a non-orthogonalised basis (None: identity)
             if pol:
                 dms = torch.stack([dm.u, dm.d])
                 err = fock @ dms - dms @ fock if S is None else fock @ dms @ S - S @ dms @ fock
