@@ -128,6 +128,17 @@ class Mol:
     def get_hamiltonian(self):
         return self._hamilton
 
+    def getparamnames(self, methodname: str, prefix: str = ""):
+        """mol.py:289-296"""
+        if methodname == "get_nuclei_energy":
+            return [prefix + "_atompos"] + ([prefix + "_atomzs"] if self._atomzs.is_floating_point() else [])
+        raise KeyError("Unknown methodname: %s" % methodname)
+
+    def set_cache(self, fname, paramnames=None):
+        """mol.py:217-250 writes the integral tensors to an h5 file; the MI355X path keeps them in HBM and refills them in
+        milliseconds -- the file cache (out of scope) is not provided"""
+        raise NotImplementedError("set_cache: the h5 parameter cache of the reference is not part of dqc_amd")
+
     def make_copy(self, **kwargs):
         """a new Mol identical to this one except for the constructor arguments given (mol.py:298-326)"""
         parameters = {"moldesc": (self._atomzs, self._atompos), "basis": self._basis_inp,
