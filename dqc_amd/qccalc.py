@@ -190,6 +190,7 @@ class SCF_QCCalc:
             elif not pol:
                 graphed = GraphedFock(eng)
         perr = None
+        fprev = None
         gram = np.zeros((0, 0))
         best_err, best_it = float("inf"), 0
         self.converged = self.stalled = False
@@ -206,9 +207,15 @@ class SCF_QCCalc:
             ev = err.reshape(-1)
             hist = es[-(int(opts["history"]) - 1):] if int(opts["history"]) > 1 else []
             row = (torch.stack(hist + [ev]) * ev).sum(-1)
-            head = torch.stack([err.abs().max(), perr if perr is not None else torch.zeros((), dtype=fock.dtype, device=fock.device)])
+            zero = torch.zeros((), dtype=fock.dtype, device=fock.device)
+            # the reference's own fixed-point residual max|F_out - F_in| (scp2scp(y) - y, scf_qccalc.py:109-113) rides along
+            fres_t = (fock - fprev).abs().max() if fprev is not None else zero + float("inf")
+            head = torch.stack([err.abs().max(), perr if perr is not None else zero, fres_t])
             host = yield torch.cat([head, row])
-            emax, pe, grow = float(host[0]), float(host[1]), host[2:]
+            emax, pe, fres, grow = float(host[0]), float(host[1]), float(host[2]), host[3:]
+            self.fock_residual = fres
+            if os.environ.get("DQC_AMD_SCF_TRACE"):
+                print("scf it %2d  max|[F,D]| %.2e  max|F_out-F_in| %.2e" % (it, emax, fres), flush=True)
             if perr is not None and not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
                 self.eigh_fallbacks = getattr(self, "eigh_fallbacks", 0) + 1
                 dm = eng.scp2dm(fprev)
@@ -225,6 +232,9 @@ class SCF_QCCalc:
             # loop as `stalled` -- `converged` keeps meaning f_tol, `scf_error` reports what was achieved
             if emax < best_err * 0.9:
                 best_err, best_it = emax, it
+            # (the reference's fixed-point residual max|F_out - F_in|, kept in self.fock_residual, runs ~3x the commutator;
+            # stopping on it as well -- 3e-9 or SURVEY.md 8d's 1e-8 -- saves 1-7 % of the iterations but costs a digit in the
+            # non-variational energy components that the goldens pin to 1e-7: not done)
             if emax < opts["f_tol"]:
                 self.converged = True
                 break
