@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
     constexpr int NKD = NK ? NK : 1;
     __shared__ double s_col[2][4][64];
     __shared__ __attribute__((aligned(16))) double s_g[NK ? 64 * LDT : 2];
-    __shared__ double s_d[NKD][4][72];
+    __shared__ __attribute__((aligned(16))) double s_d[4][72][NKD];  // density blocks, the NK exchange densities interleaved: one ds_read_b128 serves both
     const size_t n2 = (size_t)npad * npad;
     const double *Dj = work, *Dk = work + (size_t)nj * n2;
     double *Jacc = work + (size_t)(nj + NK) * n2, *Kacc = Jacc + (size_t)nj * n2;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
             const int blk = t >> 6, e = t & 63, x = e >> 3, y = e & 7;
             const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
 #pragma unroll
-            for (int q = 0; q < NK; q++) s_d[q][blk][x * 9 + y] = Dk[q * n2 + (size_t)(R * 8 + x) * npad + Cb * 8 + y];
+            for (int q = 0; q < NK; q++) s_d[blk][x * 9 + y][q] = Dk[q * n2 + (size_t)(R * 8 + x) * npad + Cb * 8 + y];
         }
         // ---- Coulomb: one density at a time
         for (int q = 0; q < nj; q++) {
@@ -289,12 +289,23 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
                 for (int a = 0; a < 8; a++) {
                     const double g1 = s_g[(x * 8 + a) * LDT + qq * 8 + y], g2 = s_g[(a * 8 + x) * LDT + qq * 8 + y];
                     const double g3 = s_g[(x * 8 + a) * LDT + y * 8 + q4], g4 = s_g[(a * 8 + x) * LDT + y * 8 + q4];
+                    if constexpr (NK == 2) {
+                        const vd2 d1 = *reinterpret_cast<const vd2 *>(&s_d[0][a * 9 + qq][0]);
+                        const vd2 d2 = *reinterpret_cast<const vd2 *>(&s_d[1][a * 9 + qq][0]);
+                        const vd2 d3 = *reinterpret_cast<const vd2 *>(&s_d[2][a * 9 + q4][0]);
+                        const vd2 d4 = *reinterpret_cast<const vd2 *>(&s_d[3][a * 9 + q4][0]);
+                        k1[0] += g1 * d1.x; k1[1] += g1 * d1.y;
+                        k2[0] += g2 * d2.x; k2[1] += g2 * d2.y;
+                        k3[0] += g3 * d3.x; k3[1] += g3 * d3.y;
+                        k4[0] += g4 * d4.x; k4[1] += g4 * d4.y;
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < NK; q++) {
-                        k1[q] += g1 * s_d[q][0][a * 9 + qq];
-                        k2[q] += g2 * s_d[q][1][a * 9 + qq];
-                        k3[q] += g3 * s_d[q][2][a * 9 + q4];
-                        k4[q] += g4 * s_d[q][3][a * 9 + q4];
+                        for (int q = 0; q < NK; q++) {
+                            k1[q] += g1 * s_d[0][a * 9 + qq][q];
+                            k2[q] += g2 * s_d[1][a * 9 + qq][q];
+                            k3[q] += g3 * s_d[2][a * 9 + q4][q];
+                            k4[q] += g4 * s_d[3][a * 9 + q4][q];
+                        }
                     }
                 }
             }
