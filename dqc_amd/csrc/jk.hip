@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
     constexpr int LDT = 68;  // row stride of the tile parked in LDS: 16-byte aligned rows, bank = 4 row + col (mod 32)
     __shared__ double s_col[4][64];
     __shared__ __attribute__((aligned(16))) double s_g[WITH_K ? 64 * LDT : 2];
-    __shared__ double s_d[WITH_K ? 4 : 1][72];  // D[J,K], D[I,K], D[J,L], D[I,L]; element (a, v) at a * 9 + v
+    // D[J,K], D[I,K] | D[J,L], D[I,L]; element (a, v) of a block at a * 9 + v, the two blocks of a pair interleaved so that
+    // one ds_read_b128 fetches both (the exchange part is LDS-read-bound)
+    __shared__ __attribute__((aligned(16))) double s_d[WITH_K ? 2 : 1][72][2];
     const size_t n2 = (size_t)npad * npad;
     const double *Dp = work;
     double *Jacc = work + n2, *Kacc = work + 2 * n2;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
             {
                 const int blk = t >> 6, e = t & 63, x = e >> 3, y = e & 7;
                 const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
-                s_d[blk][x * 9 + y] = Dp[(size_t)(R * 8 + x) * npad + Cb * 8 + y];
+                s_d[blk >> 1][x * 9 + y][blk & 1] = Dp[(size_t)(R * 8 + x) * npad + Cb * 8 + y];
             }
         }
         // ---- J: row sums over the 16 lanes of a row group, column sums over the 16 row groups ----
@@ -151,10 +153,13 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
                 const int q = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
 #pragma unroll
                 for (int a = 0; a < 8; a++) {
-                    k1 += s_g[(x * 8 + a) * LDT + q * 8 + y] * s_d[0][a * 9 + q];    // g[x][a][v=q][y]  D[J,K](a,v)
-                    k2 += s_g[(a * 8 + x) * LDT + q * 8 + y] * s_d[1][a * 9 + q];    // g[a][x][v=q][y]  D[I,K](a,v)
-                    k3 += s_g[(x * 8 + a) * LDT + y * 8 + q4] * s_d[2][a * 9 + q4];  // g[x][a][y][v=q4] D[J,L](a,v)
-                    k4 += s_g[(a * 8 + x) * LDT + y * 8 + q4] * s_d[3][a * 9 + q4];  // g[a][x][y][v=q4] D[I,L](a,v)
+                    typedef double vd2_ __attribute__((ext_vector_type(2)));
+                    const vd2_ d12 = *reinterpret_cast<const vd2_ *>(&s_d[0][a * 9 + q][0]);
+                    const vd2_ d34 = *reinterpret_cast<const vd2_ *>(&s_d[1][a * 9 + q4][0]);
+                    k1 += s_g[(x * 8 + a) * LDT + q * 8 + y] * d12.x;    // g[x][a][v=q][y]  D[J,K](a,v)
+                    k2 += s_g[(a * 8 + x) * LDT + q * 8 + y] * d12.y;    // g[a][x][v=q][y]  D[I,K](a,v)
+                    k3 += s_g[(x * 8 + a) * LDT + y * 8 + q4] * d34.x;   // g[x][a][y][v=q4] D[J,L](a,v)
+                    k4 += s_g[(a * 8 + x) * LDT + y * 8 + q4] * d34.y;   // g[a][x][y][v=q4] D[I,L](a,v)
                 }
             }
             k1 += __shfl_xor(k1, 1); k1 += __shfl_xor(k1, 2);
