@@ -36,6 +36,19 @@ constexpr int DEN_NT = DEN_BM * 4;  // threads per block
 constexpr int DEN_KC = 16;    // K chunk
 constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-free ds_read_b64 fragments)
 
+#ifdef DEN_EXP_UNPAIRED  // A/B builds: 8-byte epilogue loads
+constexpr bool DEN_PAIRED = false;
+#else
+constexpr bool DEN_PAIRED = true;
+#endif
+
+// LDS row stride of the staged B panel (D columns / L^T).  The permuted fragment reads (lane lr at double 2 lr of row lk) are conflict-free
+// when the stride is ODD (rows lk and lk + 1 of a half-wave then take the even and the odd doubles); the plain reads want
+// stride == 16 (mod 32)
+constexpr int lr_panel_stride(int nct) {
+    return (DEN_PAIRED && nct >= 2) ? nct * 16 + 1 : (((nct * 16) & 31) == 16 ? nct * 16 : nct * 16 + 16);
+}
+
 // row-dot epilogue shared by the density kernels: p[r][q] += sum_ct acc[ct][r] * Phi_q[row_r][col0 + 16 ct].
 // All loads of a batch (NCT tiles x 2 components) are issued before the first FMA and there is no per-tile guard
 // (the callers make every column panel a full one), so 2 NCT loads per lane are in flight instead of 4 -- the
@@ -76,16 +89,17 @@ DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1],
 // 0.564 ms (tools/gpu_den_time.py; the staged panel gets an odd row stride so that the permuted ds_read_b64 pattern stays
 // conflict-free).  Tried instead: trading accumulators between neighbouring lanes with DPP swaps so that the LDS layout stays
 // plain -- 0.572 ms.
-template <int NCT, int Q0>
-DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][4], const double *__restrict__ blkg, size_t cs,
-                                    const int (&roff)[4], int lr, int col0) {
+template <int NCT, bool GGA, int Q0 = 0>
+DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1], const double *__restrict__ blk0,
+                                    const double *__restrict__ blkg, size_t cs, const int (&roff)[4], int lr, int col0) {
     // a batch = the NP double2 loads (+ the odd tile) of one (row, component); two batches in flight
-    constexpr int NQ = 4 - Q0, NB = 4 * NQ, NP = NCT / 2, ODD = NCT & 1, DP = 2;
+    constexpr int NQ = (GGA ? 4 : 1) - Q0, NB = 4 * NQ, NP = NCT / 2, ODD = NCT & 1, DP = 2;
+    if (NB == 0) return;
     double2 t2[DP][NP > 0 ? NP : 1];
     double t1[DP];
     auto issue = [&](int bt, double2 (&d2)[NP > 0 ? NP : 1], double &d1) {
         const int r = bt / NQ, q = bt % NQ + Q0;
-        const double *base = blkg + q * cs + col0;  // uniform; tile pairs at immediate offsets
+        const double *base = (q == 0 ? blk0 : blkg + q * cs) + col0;  // uniform; tile pairs at immediate offsets
 #pragma unroll
         for (int m = 0; m < NP; m++) d2[m] = *reinterpret_cast<const double2 *>(base + (roff[r] + lr) + m * 32);
         if (ODD) d1 = base[roff[r] + (NCT - 1) * 16];
@@ -109,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
                                                          const double *__restrict__ aoe) {
     // aoe: array the row dots are taken with (== ao except for the "pair" form rowdot(ao . D, aoe), LDA mode only)
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int LSB = NCT * 16;                 // width of the staged D column panel (== 16 mod 32 when NCT odd)
-    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    constexpr int LSB = NCT * 16;                 // width of the staged D column panel
+    constexpr int LSBP = lr_panel_stride(NCT);    // odd: the B fragments are read with permuted columns (rowdot_epilogue_paired)
     constexpr int A_SZ = DEN_BM * DEN_SA, B_SZ = DEN_KC * LSBP;
     constexpr int NB2 = (DEN_KC * LSB / 2 + DEN_NT - 1) / DEN_NT;  // double2 loads of the B chunk per thread
     constexpr int NKK = DEN_KC / 4;
@@ -178,7 +192,11 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             for (int i = 0; i < NB2; i++) {
                 const int e = (tid + i * DEN_NT) * 2;
                 const int row = e / LSB, col = e - row * LSB;
-                if (row < DEN_KC) *reinterpret_cast<double2 *>(sB + buf * B_SZ + row * LSBP + col) = pb[i];
+                if (row < DEN_KC) {  // two 8-byte stores: odd row stride
+                    double *d = sB + buf * B_SZ + row * LSBP + col;
+                    d[0] = pb[i].x;
+                    d[1] = pb[i].y;
+                }
             }
         };
         __syncthreads();  // buffers free (previous column panel fully consumed)
@@ -191,17 +209,21 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             const bool more = kc + 1 < nk;
             const double *a = sA + buf * A_SZ + (wave * 16 + lr) * DEN_SA + lk;
             const double *b = sB + buf * B_SZ + lk * LSBP + lr;
+            const double *b2 = b + lr;  // permuted columns: tile 2 m + h, lane lr <- column 32 m + 2 lr + h
 #pragma unroll
             for (int kk = 0; kk < NKK; kk++) {
                 if (more) prefetch_part(kc + 1, kk);  // global loads in flight during the MFMAs
                 const double av = a[kk * 4];
 #pragma unroll
-                for (int ct = 0; ct < NCT; ct++)
+                for (int ct = 0; ct < NCT; ct++) {
+                    const double bv = (DEN_PAIRED && ct < 2 * (NCT / 2)) ? b2[kk * 4 * LSBP + 32 * (ct >> 1) + (ct & 1)]
+                                                                        : b[kk * 4 * LSBP + ct * 16];
 #ifndef ABL_DEN_NO_MFMA
-                    acc[ct] = mfma_f64(av, b[kk * 4 * LSBP + ct * 16], acc[ct]);
+                    acc[ct] = mfma_f64(av, bv, acc[ct]);
 #else
-                    acc[ct][0] += av * b[kk * 4 * LSBP + ct * 16];
+                    acc[ct][0] += av * bv;
 #endif
+                }
             }
             if (more) stage(buf ^ 1);
             __syncthreads();
@@ -210,7 +232,10 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
 #ifdef ABL_DEN_NO_EPI
         if (ngrid < 0)
 #endif
-        rowdot_epilogue<NCT, GGA>(acc, p, GGA ? aoblk : aoeblk, aoblk, cs, roff, jc * 16);
+        {
+            if constexpr (DEN_PAIRED) rowdot_epilogue_paired<NCT, GGA>(acc, p, GGA ? aoblk : aoeblk, aoblk, cs, roff, lr, jc * 16);
+            else rowdot_epilogue<NCT, GGA>(acc, p, GGA ? aoblk : aoeblk, aoblk, cs, roff, jc * 16);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -241,8 +266,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
 
 template <int NCT>
 static constexpr size_t density_lds_bytes() {
-    constexpr int LSB = NCT * 16;
-    constexpr int LSBP = (LSB & 31) == 16 ? LSB : LSB + 16;
+    constexpr int LSBP = lr_panel_stride(NCT);
     return sizeof(double) * 2 * (DEN_BM * DEN_SA + DEN_KC * LSBP);
 }
 
@@ -300,19 +324,6 @@ DQC_DEV void den_trace(int k) {
 #else
 #define DEN_TRACE_POINT(k)
 #endif
-
-#ifdef DEN_EXP_UNPAIRED  // A/B builds: 8-byte epilogue loads
-constexpr bool DEN_PAIRED = false;
-#else
-constexpr bool DEN_PAIRED = true;
-#endif
-
-// LDS row stride of the staged L^T panel.  The permuted fragment reads (lane lr at double 2 lr of row lk) are conflict-free
-// when the stride is ODD (rows lk and lk + 1 of a half-wave then take the even and the odd doubles); the plain reads want
-// stride == 16 (mod 32)
-constexpr int lr_panel_stride(int nct) {
-    return (DEN_PAIRED && nct >= 2) ? nct * 16 + 1 : (((nct * 16) & 31) == 16 ? nct * 16 : nct * 16 + 16);
-}
 
 template <int NRT>
 struct LrGeom {
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
         }
         DEN_TRACE_POINT(1);
         if constexpr (!DEN_PAIRED) rowdot_epilogue<NCT, GGA, 1>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
-        else if constexpr (GGA) rowdot_epilogue_paired<NCT, 1>(acc, p, aoblk, cs, roff, lr, jc * 16);
+        else if constexpr (GGA) rowdot_epilogue_paired<NCT, true, 1>(acc, p, aoblk, aoblk, cs, roff, lr, jc * 16);
         DEN_TRACE_POINT(2);
     }
 #pragma unroll
