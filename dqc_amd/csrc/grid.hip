@@ -92,7 +92,7 @@ DQC_DEV void rowdot_epilogue(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1],
 template <int NCT, bool GGA, int Q0 = 0>
 DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][GGA ? 4 : 1], const double *__restrict__ blk0,
                                     const double *__restrict__ blkg, size_t cs, const int (&roff)[4], int lr, int col0) {
-    // a batch = the NP double2 loads (+ the odd tile) of one (row, component); two batches in flight
+    // roff[r] = row * ld + 2 lr (the lane's first column of a tile pair).  A batch = the NP double2 loads (+ the odd tile) of one (row, component); two batches in flight
     constexpr int NQ = (GGA ? 4 : 1) - Q0, NB = 4 * NQ, NP = NCT / 2, ODD = NCT & 1, DP = 2;
     if (NB == 0) return;
     double2 t2[DP][NP > 0 ? NP : 1];
@@ -101,8 +101,8 @@ DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][GGA ? 
         const int r = bt / NQ, q = bt % NQ + Q0;
         const double *base = (q == 0 ? blk0 : blkg + q * cs) + col0;  // uniform; tile pairs at immediate offsets
 #pragma unroll
-        for (int m = 0; m < NP; m++) d2[m] = *reinterpret_cast<const double2 *>(base + (roff[r] + lr) + m * 32);
-        if (ODD) d1 = base[roff[r] + (NCT - 1) * 16];
+        for (int m = 0; m < NP; m++) d2[m] = *reinterpret_cast<const double2 *>(base + roff[r] + m * 32);
+        if (ODD) d1 = base[(roff[r] - lr) + (NCT - 1) * 16];
     };
     issue(0, t2[0], t1[0]);
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
         for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
     int roff[4];  // block-local element offsets of this lane's four accumulator rows
 #pragma unroll
-    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + lr;
+    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + (DEN_PAIRED ? 2 : 1) * lr;
 
     const int nk = ld / DEN_KC;
     // every panel is a full one: the last panel is shifted back to end at ntile and the tiles it shares with its
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
         for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
     int roff[4];  // block-local element offsets of this lane's four accumulator rows
 #pragma unroll
-    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + lr;
+    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + (DEN_PAIRED ? 2 : 1) * lr;
 
     // ---- phase 2 + epilogue, one column panel of NCT tiles at a time.  Every panel is a full one: the last panel
     // is shifted back to end at ntile and the tiles it shares with its predecessor (tile index < jnew) get zero L^T
