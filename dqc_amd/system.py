@@ -107,6 +107,17 @@ class Mol:
     def efield(self):
         return self._efield
 
+    # isotope-averaged atomic masses in a.m.u. (IUPAC abridged standard atomic weights, Z = 1 .. 18) -> atomic units of mass
+    _AMU = {1: 1.00797, 2: 4.00260, 3: 6.941, 4: 9.01218, 5: 10.81, 6: 12.011, 7: 14.0067, 8: 15.9994, 9: 18.998403,
+            10: 20.179, 11: 22.98977, 12: 24.305, 13: 26.98154, 14: 28.0855, 15: 30.97376, 16: 32.06, 17: 35.453, 18: 39.948}
+
+    @property
+    def atommasses(self):
+        """atomic masses in atomic units (mol.py:336-342; electron masses per a.m.u.: 1822.888486209)"""
+        if self._atomzs.is_floating_point():
+            raise RuntimeError("Atom masses are not available for floating point Z")
+        return torch.tensor([self._AMU[int(z)] * 1822.888486209 for z in self._atomzs], dtype=self._dtype, device=self._device)
+
     def densityfit(self, method=None, auxbasis=None):
         """dqc/system/mol.py:170-204: switch the Hamiltonian to the density-fitted Coulomb operator.
         auxbasis: list (per atom) of lists of CGTOBasis, a basis name shipped under dqc_amd/data/basis, or "etb[:beta]"
