@@ -52,3 +52,32 @@ def equadrupole(qc, unit="Debye*Angst"):
     pos = mol.atompos.to(h.device)
     ion = torch.einsum("ad,ae,a->de", pos, pos, mol.atomzs.to(pos.dtype).to(h.device))
     return (elec + ion) * _unit(_QUADRUPOLE_UNITS, unit, "quadrupole")
+
+
+def optimal_geometry(qc, length_unit=None, gtol=1e-5, maxiter=200):
+    """atom positions (natoms, 3) that minimise the SCF energy (properties.py:321-341, 486-510).  The reference minimises by
+    autograd gradients of the energy with respect to the positions; here every step is a fresh `Mol.make_copy(moldesc=...)` +
+    SCF run and the ANALYTIC nuclear gradient of the converged density (`SCF_QCCalc.nuclear_gradient`), driven by BFGS."""
+    import numpy as np
+    from scipy.optimize import minimize
+    system = qc.get_system()
+    zs = system.atomzs
+    x0 = system.atompos.detach().cpu().numpy().astype(np.float64)
+    natm = x0.shape[0]
+    cls = qc.__class__
+    kwargs = dict(getattr(qc, "_ctor_kwargs", {}))
+
+    def fun(x):
+        pos = torch.as_tensor(x.reshape(natm, 3), dtype=torch.float64)
+        q = cls(system.make_copy(moldesc=(zs, pos)), **kwargs).run()
+        return float(q.energy()), q.nuclear_gradient().detach().cpu().numpy().reshape(-1)
+
+    res = minimize(fun, x0.reshape(-1), jac=True, method="BFGS", options={"gtol": gtol, "maxiter": maxiter})
+    pos = torch.as_tensor(res.x.reshape(natm, 3), dtype=torch.float64)
+    if length_unit is not None:
+        key = length_unit.lower()
+        table = {"bohr": 1.0, "angst": _ANGSTROM, "angstrom": _ANGSTROM, "a": _ANGSTROM}
+        if key not in table:
+            raise ValueError("Unknown length unit: %s" % length_unit)
+        pos = pos * table[key]
+    return pos

@@ -319,6 +319,7 @@ class HF(SCF_QCCalc):
         if variational:
             raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
         super().__init__(_Engine(system, None, is_ks=False, restricted=restricted))
+        self._ctor_kwargs = {"restricted": restricted}  # to rebuild the same calculation on another geometry
 
 
 class KS(SCF_QCCalc):
@@ -326,3 +327,4 @@ class KS(SCF_QCCalc):
         if variational:
             raise NotImplementedError("the variational solver is out of scope (SURVEY.md 2, row 3)")
         super().__init__(_Engine(system, xc, is_ks=True, restricted=restricted))
+        self._ctor_kwargs = {"xc": xc, "restricted": restricted}
