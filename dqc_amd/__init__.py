@@ -8,6 +8,6 @@ from .hamilton import HamiltonMI355  # noqa: F401
 from .system import Mol  # noqa: F401
 from .qccalc import HF, KS  # noqa: F401
 from .grid import get_grid, get_predefined_grid  # noqa: F401
-from .properties import edipole, equadrupole, optimal_geometry  # noqa: F401
+from .properties import edipole, equadrupole, optimal_geometry, hessian_pos, vibration, ir_spectrum, raman_spectrum  # noqa: F401
 
 __version__ = "0.1.0"

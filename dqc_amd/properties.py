@@ -81,3 +81,127 @@ def optimal_geometry(qc, length_unit=None, gtol=1e-5, maxiter=200):
             raise ValueError("Unknown length unit: %s" % length_unit)
         pos = pos * table[key]
     return pos
+
+
+# ---- second-order properties by central differences of FIRST-order analytic quantities -------------------------------------
+# The reference differentiates twice through the SCF (properties.py:344-437).  Here the Hessian is the central difference of the
+# analytic nuclear gradient and d(dipole)/dR the central difference of the dipole expectation value, over the same 6 natoms
+# displaced SCF runs (milliseconds each on the GPU for the molecules these properties are asked for).
+_TIME = 2.4188843265857e-17   # s per a.u. of time
+_LIGHT_SPEED = 2.99792458e8   # m / s
+_AMU = 5.485799090649e-4      # a.m.u. per a.u. of mass
+_FREQ_UNITS = {None: 1.0, "cm-1": 1e-2 / _TIME / _LIGHT_SPEED, "cm^-1": 1e-2 / _TIME / _LIGHT_SPEED, "hz": 1.0 / _TIME,
+               "thz": 1.0 / _TIME / 1e12}
+_IR_UNITS = {None: 1.0, "(debye/angst)^2/amu": (_DEBYE / _ANGSTROM) ** 2 / _AMU,
+             "km/mol": (_DEBYE / _ANGSTROM) ** 2 / _AMU * 42.256}
+
+
+def _displaced(qc, step):
+    """gradient (3N,) and dipole (3,) [a.u.] of the 6 N geometries displaced by +-step along every Cartesian coordinate"""
+    system = qc.get_system()
+    pos0 = system.atompos.detach().cpu().to(torch.float64)
+    cls, kwargs = qc.__class__, dict(getattr(qc, "_ctor_kwargs", {}))
+    out = {}
+    for i in range(pos0.numel()):
+        for sgn in (1.0, -1.0):
+            pos = pos0.clone().reshape(-1)
+            pos[i] += sgn * step
+            q = cls(system.make_copy(moldesc=(system.atomzs, pos.reshape(pos0.shape))), **kwargs).run()
+            out[(i, sgn)] = (q.nuclear_gradient().detach().cpu().reshape(-1), edipole(q, unit=None).cpu())
+    return out
+
+
+_FD_CACHE = {}  # (id(qc), step) -> (Hessian, d dipole / dR): one set of displaced runs serves Hessian, vibrations and IR
+
+
+def _second_order(qc, step):
+    key = (id(qc), step)
+    if key not in _FD_CACHE:
+        d = _displaced(qc, step)
+        n = len(d) // 2
+        hess = torch.stack([(d[(i, 1.0)][0] - d[(i, -1.0)][0]) / (2 * step) for i in range(n)])
+        dmu = torch.stack([(d[(i, 1.0)][1] - d[(i, -1.0)][1]) / (2 * step) for i in range(n)], dim=-1)  # (3, 3N)
+        _FD_CACHE.clear()
+        _FD_CACHE[key] = ((hess + hess.T) * 0.5, dmu)
+    return _FD_CACHE[key]
+
+
+def hessian_pos(qc, unit=None, step=5e-3):
+    """d2E / dR dR (3 natoms, 3 natoms) in Hartree / Bohr^2 (properties.py:21-41)"""
+    if unit is not None:
+        raise ValueError("hessian_pos: only atomic units are provided")
+    return _second_order(qc, step)[0]
+
+
+def _vibration_au(qc, step):
+    hess, dmu = _second_order(qc, step)
+    mass = qc.get_system().atommasses.cpu().repeat_interleave(3)
+    isq = mass ** -0.5
+    ev, u = torch.linalg.eigh(hess * isq.unsqueeze(0) * isq.unsqueeze(1))
+    modes = u * isq.unsqueeze(1)  # M-orthonormal: modes^T M modes = 1, as xitorch.symeig(A, M) returns them
+    freq = ev.abs().sqrt() * torch.sign(ev) / (2 * torch.pi)
+    return torch.flip(freq, dims=(-1,)), torch.flip(modes, dims=(-1,)), dmu
+
+
+def vibration(qc, freq_unit="cm^-1", length_unit=None, step=5e-3):
+    """vibrational frequencies (largest first; imaginary ones negative) and normal modes (properties.py:43-71, 359-381)"""
+    freq, modes, _ = _vibration_au(qc, step)
+    if length_unit is not None:
+        raise ValueError("vibration: normal modes are returned in atomic units only")
+    return freq * _unit(_FREQ_UNITS, freq_unit, "frequency"), modes
+
+
+def ir_spectrum(qc, freq_unit="cm^-1", ints_unit="(debye/angst)^2/amu", step=5e-3):
+    """positive vibrational frequencies (largest first) and their IR intensities |d mu / d Q|^2 (properties.py:73-109, 383-404)"""
+    freq, modes, dmu = _vibration_au(qc, step)
+    keep = freq > 0
+    freq, modes = freq[keep], modes[:, keep]
+    dmu_dq = dmu @ modes
+    ints = (dmu_dq * dmu_dq).sum(0)
+    return freq * _unit(_FREQ_UNITS, freq_unit, "frequency"), ints * _unit(_IR_UNITS, ints_unit, "IR intensity")
+
+
+_RAMAN_UNITS = {None: 1.0, "angst^4/amu": _ANGSTROM ** 4 / _AMU}
+
+
+def _polarizability(qc_at, field_step):
+    """static polarisability alpha = d mu / dF (3, 3) by central differences of the dipole expectation value in a small field"""
+    system = qc_at.get_system()
+    cls, kwargs = qc_at.__class__, dict(getattr(qc_at, "_ctor_kwargs", {}))
+    cols = []
+    for d in range(3):
+        mus = []
+        for sgn in (1.0, -1.0):
+            f = torch.zeros(3, dtype=torch.float64)
+            f[d] = sgn * field_step
+            q = cls(system.make_copy(efield=f), **kwargs).run()
+            mus.append(edipole(q, unit=None).cpu())
+        cols.append((mus[0] - mus[1]) / (2 * field_step))
+    return torch.stack(cols, dim=-1)  # alpha[i, d] = d mu_i / d F_d
+
+
+def raman_spectrum(qc, freq_unit="cm^-1", ints_unit="angst^4/amu", step=5e-3, field_step=2e-3):
+    """positive frequencies (largest first) and Raman activities 45 a'^2 + 7 g'^2 (properties.py:111-160, 406-437; eq. 2-4 of
+    doi:10.1080/00268970701516412) from the derivative of the polarisability along the normal modes"""
+    freq, modes, _ = _vibration_au(qc, step)
+    keep = freq > 0
+    freq, modes = freq[keep], modes[:, keep]
+    system = qc.get_system()
+    pos0 = system.atompos.detach().cpu().to(torch.float64)
+    cls, kwargs = qc.__class__, dict(getattr(qc, "_ctor_kwargs", {}))
+    dalpha = []
+    for i in range(pos0.numel()):
+        a = []
+        for sgn in (1.0, -1.0):
+            pos = pos0.clone().reshape(-1)
+            pos[i] += sgn * step
+            q = cls(system.make_copy(moldesc=(system.atomzs, pos.reshape(pos0.shape))), **kwargs).run()
+            a.append(_polarizability(q, field_step))
+        dalpha.append((a[0] - a[1]) / (2 * step))
+    dalpha_dr = torch.stack(dalpha, dim=-1)        # (3, 3, 3N)
+    dq = torch.matmul(dalpha_dr, modes)            # (3, 3, nmodes)
+    alpha_p2 = (torch.einsum("iim->m", dq) / 3.0) ** 2
+    gamma_p2 = 0.5 * ((dq[0, 0] - dq[1, 1]) ** 2 + (dq[0, 0] - dq[2, 2]) ** 2 + (dq[1, 1] - dq[2, 2]) ** 2
+                      + 3 * (dq[0, 1] ** 2 + dq[0, 2] ** 2 + dq[1, 0] ** 2 + dq[1, 2] ** 2 + dq[2, 0] ** 2 + dq[2, 1] ** 2))
+    ints = 45 * alpha_p2 + 7 * gamma_p2
+    return freq * _unit(_FREQ_UNITS, freq_unit, "frequency"), ints * _unit(_RAMAN_UNITS, ints_unit, "Raman activity")
