@@ -111,19 +111,18 @@ def _displaced(qc, step):
     return out
 
 
-_FD_CACHE = {}  # (id(qc), step) -> (Hessian, d dipole / dR): one set of displaced runs serves Hessian, vibrations and IR
+_FD_CACHE = []  # [weakref(qc), step, (Hessian, d dipole / dR)]: one set of displaced runs serves Hessian, vibrations and IR
 
 
 def _second_order(qc, step):
-    key = (id(qc), step)
-    if key not in _FD_CACHE:
+    import weakref
+    if not (_FD_CACHE and _FD_CACHE[0]() is qc and _FD_CACHE[1] == step):
         d = _displaced(qc, step)
         n = len(d) // 2
         hess = torch.stack([(d[(i, 1.0)][0] - d[(i, -1.0)][0]) / (2 * step) for i in range(n)])
         dmu = torch.stack([(d[(i, 1.0)][1] - d[(i, -1.0)][1]) / (2 * step) for i in range(n)], dim=-1)  # (3, 3N)
-        _FD_CACHE.clear()
-        _FD_CACHE[key] = ((hess + hess.T) * 0.5, dmu)
-    return _FD_CACHE[key]
+        _FD_CACHE[:] = [weakref.ref(qc), step, ((hess + hess.T) * 0.5, dmu)]
+    return _FD_CACHE[2]
 
 
 def hessian_pos(qc, unit=None, step=5e-3):
