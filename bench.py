@@ -12,7 +12,8 @@ GPU; at N GPUs the SAME batch is sharded 32/N per rank (strong scaling over a fi
 only the closing barrier / max-reduce of the timing).  value = molecules x steps / max-over-ranks time.
 
 Usage: python bench.py [--gpus N --steps K --warmup W --molecules M --no-cpu-baseline --profile-mode]
-For N>1 launch with torch.distributed.run (one rank per GPU, RCCL); prints ONE JSON line on rank 0.
+With --gpus N > 1 from a bare shell the script launches its own N ranks (torch.distributed.run, one per GPU, RCCL);
+started under a launcher (WORLD_SIZE set) it is one of the ranks.  ONE JSON line on rank 0 either way.
 """
 import argparse
 import glob
@@ -68,26 +69,47 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for self-tests")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true",
                     help="self-test only: map every rank to cuda:0 (exercise the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="self-test of the N-rank launch path only (rendezvous + one all_reduce, no GPU work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started from a bare shell (`python bench.py --gpus N`): become the launcher -- one rank per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1; rank 0 of the children prints the ONE JSON line
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU)" % (args.gpus, world))
     import torch.distributed as dist
     if args.all_ranks_on_gpu0:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = None
+    if not args.launch_check:
+        if not args.all_ranks_on_gpu0 and torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: --gpus %d but only %d device(s) visible" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    n_ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        # every rank contributes a one: the sum is the number of ranks that really joined the collective (RCCL over xGMI
+        # with the nccl backend); reported in the JSON line
+        ones = torch.ones(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
+    if args.launch_check:  # launcher self-test (runs without a GPU): rendezvous + collective only
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "n_ranks_seen": n_ranks_seen, "backend": args.backend}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import dqc_amd
     from dqc_amd import lib
@@ -170,10 +192,14 @@ def main():
             step(dense_dm=dense)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = {"setup_s": [setup_s], "timed_s": [elapsed]}
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+        # one row per rank (owned by it, zero elsewhere): a sum is a gather
+        tab_r = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+        tab_r[rank, 0], tab_r[rank, 1] = setup_s, elapsed
+        dist.all_reduce(tab_r)
+        per_rank = {"setup_s": tab_r[:, 0].tolist(), "timed_s": tab_r[:, 1].tolist()}
+        elapsed = float(tab_r[:, 1].max())
     passes = args.steps * repeats
 
     # ---------------- per-kernel HIP-event timing (same stream as the launches), first 4 local molecules ----------------
@@ -343,7 +369,7 @@ def main():
             "metric": "SCF iterations/sec (Fock build + XC grid) per GPU, cc-pVDZ 20-atom",
             "value": nmol * passes / elapsed,
             "unit": "SCF Fock-build iterations/s (whole job)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "per_rank": per_rank, "steps": args.steps, "warmup": args.warmup, "repeats": repeats,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "timed_region_s": elapsed,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -374,6 +400,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this very command line as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) and hand its exit code back"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def eri_fill_stats(h, dev):

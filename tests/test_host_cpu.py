@@ -185,6 +185,20 @@ def test_run_sharded_world_size_2_gloo():
     assert all("OK" in o for o in outs), outs
 
 
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no launcher in the environment spawns its two ranks itself (torch.distributed.run,
+    127.0.0.1) and rank 0 prints ONE JSON line; --launch-check stops after the rendezvous + all_reduce (no GPU needed)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2
+
+
 def test_cart2sph_matrix_host_function():
     """dqc_cart2sph_matrix (host-side, no GPU): block-diagonal solid-harmonic matrix == the oracle's per-shell tables"""
     import ctypes
