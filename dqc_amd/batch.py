@@ -102,3 +102,32 @@ def run_concurrent(qcs, max_inflight: int = 16, **run_kwargs):
     for s in streams:
         main.wait_stream(s)
     return qcs
+
+
+def run_lockstep(qcs, group_size: int = 16, inflight: int = 2, nstreams: int = 3, **run_kwargs):
+    """Run the SCF of a batch on one GPU with everything but the Fock builds batched across molecules
+    (dqc_amd/lockstep.py): calculations are bucketed by (nao, n_occ), every bucket is cut into groups of at most
+    `group_size` that advance in lockstep, and `inflight` groups are driven at once on their own streams so that one
+    group's latency-bound phase (DIIS, purification: ~1 ms of small launches) overlaps another's Fock builds.
+    Calculations that do not qualify (unrestricted, non-uniform occupations, raw AO basis) run through
+    `run_concurrent`.  Returns `qcs`; every element is in the state `qc.run()` leaves it in."""
+    from .lockstep import LockstepSCF, signature
+    buckets, rest = {}, []
+    for q in qcs:
+        s = signature(q)
+        (buckets.setdefault(s, []) if s is not None else rest).append(q)
+    groups = []
+    for s, members in buckets.items():
+        if len(members) == 1:
+            rest.extend(members)
+            continue
+        # equal-sized groups, at least `inflight` of them when there are enough molecules
+        ng = max((len(members) + group_size - 1) // group_size, min(inflight, len(members) // 2))
+        size = (len(members) + ng - 1) // ng
+        for i in range(0, len(members), size):
+            groups.append(LockstepSCF(members[i:i + size], nstreams=nstreams))
+    if groups:
+        run_concurrent(groups, max_inflight=inflight, **run_kwargs)
+    if rest:
+        run_concurrent(rest, **run_kwargs)
+    return qcs

@@ -21,10 +21,16 @@ typedef double pv4d __attribute__((ext_vector_type(4)));
 // One block of four waves per 16 x 16 tile: the K range is split over the waves (one batch of loads each for ld <= 208:
 // a single L2 round trip per iteration instead of four), partial tiles are summed through LDS.  A frozen iterate only
 // copies its tile (the launch is then a few microseconds).
+// blockIdx.y = molecule of a batch (lockstep SCF of many molecules: dqc_amd/lockstep.py): matrices `xstride` doubles apart,
+// state slots `sstride` doubles apart; every molecule freezes on its own.
 __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xout, const double *__restrict__ xin, int ld,
                                                          double nocc, double tol, int k, double *__restrict__ trace,
-                                                         double *__restrict__ idem) {
+                                                         double *__restrict__ idem, size_t xstride, int sstride) {
     __shared__ double red[3][4][64];
+    xout += blockIdx.y * xstride;
+    xin += blockIdx.y * xstride;
+    trace += (size_t)blockIdx.y * sstride;
+    idem += (size_t)blockIdx.y * sstride;
     const int T = ld >> 4;
     const int ti = blockIdx.x / T, tj = blockIdx.x % T;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -89,7 +95,10 @@ __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xo
     }
 }
 
-__global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double *__restrict__ trace0) {
+__global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double *__restrict__ trace0, size_t xstride,
+                                    int sstride) {
+    x += blockIdx.x * xstride;
+    trace0 += (size_t)blockIdx.x * sstride;
     double s = 0.0;
     for (int i = threadIdx.x; i < ld; i += blockDim.x) s += x[(size_t)i * ld + i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -109,6 +118,9 @@ __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double
 __global__ __launch_bounds__(64) void orth_factor_kernel(double *__restrict__ q, const double *__restrict__ y,
                                                          const double *__restrict__ g, int n, int r, int rb) {
     extern __shared__ double sm[];
+    q += (size_t)blockIdx.y * n * r;  // blockIdx.y = molecule of a batch
+    y += (size_t)blockIdx.y * n * r;
+    g += (size_t)blockIdx.y * r * r;
     const int ldc = r | 1, t = threadIdx.x;  // odd row stride: the rows of different lanes start in different banks
     double *c = sm, *rw = sm + (size_t)r * ldc;
     const int row0 = blockIdx.x * rb;
@@ -153,43 +165,161 @@ __global__ __launch_bounds__(64) void orth_factor_kernel(double *__restrict__ q,
     }
 }
 
+// Pulay coefficients of a batch of DIIS problems, one 64-lane block per molecule.  gram (nmol, H, H): error-vector scalar
+// products, the first m slots valid.  Solves  [[G/g, -1], [-1^T, 0]] (c, lambda) = (0, -1)  (g = largest diagonal of G: the
+// coefficients do not depend on the scale, the conditioning does) in the least-squares / minimum-norm sense of
+// numpy.linalg.lstsq(rcond=None), which is what the one-molecule driver does on the host (dqc_amd/qccalc.py): symmetric
+// eigendecomposition by cyclic Jacobi rotations in LDS, eigenvalues below eps N |lambda|_max dropped.  Reference:
+// the fixed-point solver of dqc/qccalc/scf_qccalc.py:109-113 (any convergent mixer has the same fixed point).
+#define DQC_DIIS_NMAX 17
+__global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cout, const double *__restrict__ gram, int H, int m) {
+    __shared__ double A[DQC_DIIS_NMAX][DQC_DIIS_NMAX + 1], V[DQC_DIIS_NMAX][DQC_DIIS_NMAX + 1];
+    __shared__ double rot[2];
+    const int t = threadIdx.x, N = m + 1;
+    gram += (size_t)blockIdx.x * H * H;
+    cout += (size_t)blockIdx.x * H;
+    double g = 0.0;
+    for (int i = 0; i < m; i++) g = fmax(g, gram[i * H + i]);
+    g = fmax(g, 1e-300);
+    for (int e = t; e < N * N; e += 64) {
+        const int i = e / N, j = e % N;
+        double a;
+        if (i < m && j < m) a = gram[i * H + j] / g;
+        else if (i == m && j == m) a = 0.0;
+        else a = -1.0;
+        A[i][j] = a;
+        V[i][j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0.0;  // every lane sums the whole off-diagonal part: uniform decision without a reduction
+        for (int i = 0; i < N; i++)
+            for (int j = i + 1; j < N; j++) off += A[i][j] * A[i][j];
+        if (off < 1e-60) break;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                if (t == 0) {
+                    const double apq = A[p][q];
+                    double c = 1.0, sn = 0.0;
+                    if (fabs(apq) > 1e-300) {
+                        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(tt * tt + 1.0);
+                        sn = tt * c;
+                    }
+                    rot[0] = c;
+                    rot[1] = sn;
+                }
+                __syncthreads();
+                const double c = rot[0], sn = rot[1];
+                // columns p, q of A and V (lane t = row), then rows p, q of A (lane t = column)
+                double akp = 0, akq = 0;
+                if (t < N) {
+                    akp = A[t][p]; akq = A[t][q];
+                    const double vkp = V[t][p], vkq = V[t][q];
+                    V[t][p] = c * vkp - sn * vkq;
+                    V[t][q] = sn * vkp + c * vkq;
+                }
+                __syncthreads();
+                if (t < N) {
+                    A[t][p] = c * akp - sn * akq;
+                    A[t][q] = sn * akp + c * akq;
+                }
+                __syncthreads();
+                if (t < N) {
+                    akp = A[p][t]; akq = A[q][t];
+                }
+                __syncthreads();
+                if (t < N) {
+                    A[p][t] = c * akp - sn * akq;
+                    A[q][t] = sn * akp + c * akq;
+                }
+                __syncthreads();
+            }
+    }
+    double lmax = 0.0;
+    for (int i = 0; i < N; i++) lmax = fmax(lmax, fabs(A[i][i]));
+    const double cut = 2.220446049250313e-16 * N * lmax;
+    if (t < H) {
+        double x = 0.0;
+        if (t < m)
+            for (int i = 0; i < N; i++) {
+                const double lam = A[i][i];
+                if (fabs(lam) > cut) x += V[t][i] * (-V[m][i]) / lam;  // rhs = (0, ..., 0, -1)
+            }
+        cout[t] = x;
+    }
+}
+
 }  // namespace dqc
+
+extern "C" int dqc_diis_solve(double *d_c, const double *d_gram, int nmol, int nhist, int m, void *stream) {
+    // d_gram (nmol, nhist, nhist) Gram matrices of the stored error vectors, the first m slots valid; d_c (nmol, nhist) Pulay
+    // coefficients (zero for the unused slots).  Enqueues only.
+    using namespace dqc;
+    if (nmol <= 0) return DQC_OK;
+    if (m < 1 || m > nhist || nhist + 1 > DQC_DIIS_NMAX) { set_error("dqc_diis_solve: need 1 <= m <= nhist <= 16"); return DQC_EINVAL; }
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(nmol), dim3(64), 0, (hipStream_t)stream, d_c, d_gram, nhist, m);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nmol, double nocc, int iters, double tol,
+                                      double *d_state, void *stream);
 
 extern "C" int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                               void *stream) {
     // d_x (ld, ld): X0 on entry (spectrum in [0, 1], zero padded to ld = multiple of 16), the purified projector on
     // return; d_tmp (ld, ld) scratch; d_state: 2 * (iters + 2) doubles -- trace[0..iters], idem[0..iters]
     // (idem[k] = max |X_k^2 - X_k|, so the caller can tell convergence: min over k).  Enqueues only.
+    return dqc_purify_tc2_batched(d_x, d_tmp, ld, 1, nocc, iters, tol, d_state, stream);
+}
+
+extern "C" int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nmol, double nocc, int iters, double tol,
+                                      double *d_state, void *stream) {
+    // the same for nmol matrices at once (one launch per iteration for the whole batch, blockIdx.y = molecule):
+    // d_x, d_tmp (nmol, ld, ld); d_state (nmol, 2 * (iters + 2)).  Every matrix freezes on its own.  Enqueues only.
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     if (ld <= 0 || (ld & 15)) { set_error("dqc_purify_tc2: ld must be a positive multiple of 16"); return DQC_EINVAL; }
     if (iters < 1) { set_error("dqc_purify_tc2: iters must be >= 1"); return DQC_EINVAL; }
+    if (nmol < 1 || nmol > 65535) { set_error("dqc_purify_tc2_batched: 1 <= nmol <= 65535"); return DQC_EINVAL; }
+    const int sstride = 2 * (iters + 2);
+    const size_t xstride = (size_t)ld * ld;
     double *trace = d_state, *idem = d_state + (iters + 2);
-    DQC_HIP(hipMemsetAsync(d_state, 0, sizeof(double) * 2 * (iters + 2), st));
-    hipLaunchKernelGGL(purify_trace_kernel, dim3(1), dim3(256), 0, st, d_x, ld, trace);
+    DQC_HIP(hipMemsetAsync(d_state, 0, sizeof(double) * (size_t)sstride * nmol, st));
+    hipLaunchKernelGGL(purify_trace_kernel, dim3(nmol), dim3(256), 0, st, d_x, ld, trace, xstride, sstride);
     DQC_CHECK_LAUNCH();
     const int T = ld >> 4;
     double *cur = d_x, *nxt = d_tmp;
     for (int k = 0; k < iters; k++) {
-        hipLaunchKernelGGL(purify_tc2_kernel, dim3(T * T), dim3(256), 0, st, nxt, cur, ld, nocc, tol, k, trace, idem);
+        hipLaunchKernelGGL(purify_tc2_kernel, dim3(T * T, nmol), dim3(256), 0, st, nxt, cur, ld, nocc, tol, k, trace, idem, xstride,
+                           sstride);
         DQC_CHECK_LAUNCH();
         std::swap(cur, nxt);
     }
-    if (cur != d_x) DQC_HIP(hipMemcpyAsync(d_x, cur, sizeof(double) * (size_t)ld * ld, hipMemcpyDeviceToDevice, st));
+    if (cur != d_x) DQC_HIP(hipMemcpyAsync(d_x, cur, sizeof(double) * xstride * nmol, hipMemcpyDeviceToDevice, st));
     return DQC_OK;
 }
 
-extern "C" int dqc_orth_factor(double *d_q, const double *d_y, const double *d_g, int n, int r, void *stream) {
-    // d_y (n, r) row-major with full column rank, d_g (r, r) = Y^T Y  ->  d_q (n, r) = Y C^-T, G = C C^T.  Enqueues only.
+extern "C" int dqc_orth_factor_batched(double *d_q, const double *d_y, const double *d_g, int n, int r, int nmol, void *stream) {
+    // d_y (nmol, n, r) row-major with full column rank, d_g (nmol, r, r) = Y^T Y  ->  d_q (nmol, n, r) = Y C^-T, G = C C^T.
+    // Enqueues only.
     using namespace dqc;
-    if (n <= 0 || r <= 0) return DQC_OK;
+    if (n <= 0 || r <= 0 || nmol <= 0) return DQC_OK;
+    if (nmol > 65535) { set_error("dqc_orth_factor_batched: nmol <= 65535"); return DQC_EINVAL; }
     int rb = 64;  // rows of Y per block: as many as fit next to the r x r factor
     const int ldc = r | 1;
     while (rb > 8 && sizeof(double) * (size_t)(r + rb) * ldc > 150 * 1024) rb >>= 1;
     const size_t lds = sizeof(double) * (size_t)(r + rb) * ldc;
     if (lds > 150 * 1024) { set_error("dqc_orth_factor: r above 132 is not supported"); return DQC_EINVAL; }
     (void)hipFuncSetAttribute((const void *)orth_factor_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(orth_factor_kernel, dim3((n + rb - 1) / rb), dim3(64), lds, (hipStream_t)stream, d_q, d_y, d_g, n, r, rb);
+    hipLaunchKernelGGL(orth_factor_kernel, dim3((n + rb - 1) / rb, nmol), dim3(64), lds, (hipStream_t)stream, d_q, d_y, d_g, n, r, rb);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
+}
+
+extern "C" int dqc_orth_factor(double *d_q, const double *d_y, const double *d_g, int n, int r, void *stream) {
+    // one matrix: d_y (n, r), d_g (r, r) -> d_q (n, r)
+    return dqc_orth_factor_batched(d_q, d_y, d_g, n, r, 1, stream);
 }

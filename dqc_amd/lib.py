@@ -59,6 +59,9 @@ def load():
     lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_orth_factor.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_vp]
+    lib.dqc_purify_tc2_batched.argtypes = [c_dp, c_dp, c_int, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
+    lib.dqc_orth_factor_batched.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_vp]
+    lib.dqc_diis_solve.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
@@ -234,6 +237,34 @@ def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
         _check(load().dqc_purify_tc2(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
                                      st_), "dqc_purify_tc2")
     return x_pad
+
+
+def purify_tc2_batched(x_pad, tmp, nocc, iters, tol, state):
+    """in-place TC2 purification of the (nmol, ld, ld) batch x_pad; state (nmol, 2 (iters + 2))"""
+    nmol, ld = x_pad.shape[0], x_pad.shape[-1]
+    with _on(x_pad.device) as st_:
+        _check(load().dqc_purify_tc2_batched(_ptr(x_pad), _ptr(tmp), ld, nmol, float(nocc), int(iters), float(tol), _ptr(state),
+                                             st_), "dqc_purify_tc2_batched")
+    return x_pad
+
+
+def orth_factor_batched(y, g, out=None):
+    """y (nmol, n, r), g (nmol, r, r) = y^T y -> (nmol, n, r) orthonormal bases (one launch)"""
+    nmol, n, r = y.shape
+    q = torch.empty_like(y) if out is None else out
+    with _on(y.device) as st_:
+        _check(load().dqc_orth_factor_batched(_ptr(q), _ptr(y.contiguous()), _ptr(g.contiguous()), n, r, nmol, st_),
+               "dqc_orth_factor_batched")
+    return q
+
+
+def diis_solve(gram, m, out=None):
+    """gram (nmol, H, H) Gram matrices of the stored error vectors (first m slots valid) -> Pulay coefficients (nmol, H)"""
+    nmol, H, _ = gram.shape
+    c = torch.empty((nmol, H), dtype=torch.float64, device=gram.device) if out is None else out
+    with _on(gram.device) as st_:
+        _check(load().dqc_diis_solve(_ptr(c), _ptr(gram), nmol, H, int(m), st_), "dqc_diis_solve")
+    return c
 
 
 def orth_factor(y, g):

@@ -1,0 +1,245 @@
+"""Lockstep SCF of a batch of same-size molecules: everything around the Fock build is ONE set of launches for the batch.
+
+The reference runs one self-consistency loop per molecule (dqc/qccalc/scf_qccalc.py:84-116: `dm0 = "1e"` core guess, then
+the fixed point F = dm2scp(scp2dm(F)), engine steps dqc/qccalc/hf.py:105-113 / ks.py:176-187).  A batch is M independent
+problems; on the GPU the part of an iteration that is NOT the Fock build -- commutator, DIIS,
+`diagonalize` + `ao_orb2dm` -- is small-matrix work that leaves 95 % of the chip idle and costs ~100 launches per molecule.
+Here M molecules with the same (nao, n_occ) advance together:
+
+    E = F D - D F, max|E|                    batched GEMM on the stacked (M, n, n) matrices
+    Gram row, Pulay coefficients, F_mix      stacked history on the device, dqc_diis_solve (one block per molecule)
+    P = projector(F_mix)                     dqc_purify_tc2_batched: one launch per TC2 step for ALL molecules
+    Q = orth(P Omega)                        dqc_orth_factor_batched
+    F[m], D[m] = Fock build of Q[m]          per molecule: the hipGraph of ao_orb2dm + dm2scp (dqc_amd/graph.py), dealt to
+                                             a few HIP streams so that one molecule's kernel tails overlap the next one's heads
+
+with ONE device -> host read per iteration for the whole batch (max|[F, D]| and the projector error of every molecule).
+A molecule that has converged is frozen (its Fock builds stop; its slot in the stacked arrays idles) until the batch is
+done.  Same numbers as the one-molecule driver (dqc_amd/qccalc.py) up to round-off: same error vector, same history
+length, same least-squares Pulay solve, same purification.
+
+Restricted closed-shell (uniform occupations) engines in an orthogonalised basis only; `signature(qc)` says whether a
+calculation qualifies -- everything else keeps the one-molecule driver (`batch.run_lockstep` sorts that out)."""
+import os
+import warnings
+
+import torch
+
+from . import lib
+from .purify import _TC2_ITERS
+
+
+def signature(qc):
+    """key under which calculations can share a lockstep batch, or None when the calculation needs the one-molecule driver"""
+    eng = qc._engine
+    if eng.polarized or getattr(eng, "ovlp", None) is not None:
+        return None
+    w = eng.orb_weight
+    if not w.numel() or not bool((w == w[0]).all()):
+        return None
+    n, r = int(eng.shape[-1]), int(eng.norb)
+    if not (0 < r <= 128 and r < n):
+        return None
+    return (str(eng.device), n, r, float(w[0]))
+
+
+def projectors_from_focks(focks, nocc, iters=None, tol=1e-13):
+    """focks (M, n, n) symmetric, orthonormal bases -> (P (M, n, n), err (M,)): the batched form of
+    purify.projector_from_fock (Gershgorin bounds, TC2 with one launch per step for the whole batch, two McWeeny steps)"""
+    if iters is None:
+        iters = _TC2_ITERS
+    M, n, _ = focks.shape
+    dev, dt = focks.device, focks.dtype
+    diag = torch.diagonal(focks, dim1=-2, dim2=-1)
+    rad = focks.abs().sum(-1) - diag.abs()
+    emin, emax = (diag - rad).amin(-1), (diag + rad).amax(-1)
+    eye = torch.eye(n, dtype=dt, device=dev)
+    x = (emax.reshape(M, 1, 1) * eye - focks) / (emax - emin).reshape(M, 1, 1)
+    ld = (n + 15) // 16 * 16
+    if ld != n:
+        xp = torch.zeros((M, ld, ld), dtype=dt, device=dev)
+        xp[:, :n, :n] = x
+    else:
+        xp = x.contiguous()
+    tmp = torch.empty_like(xp)
+    state = torch.empty((M, 2 * (iters + 2)), dtype=dt, device=dev)
+    lib.purify_tc2_batched(xp, tmp, nocc, iters, tol, state)
+    x = xp[:, :n, :n]
+    for _ in range(2):
+        x2 = torch.bmm(x, x)
+        x = 3.0 * x2 - 2.0 * torch.bmm(x2, x)
+    x = (x + x.transpose(-2, -1)) * 0.5
+    tr = torch.diagonal(x, dim1=-2, dim2=-1).sum(-1)
+    err = (torch.bmm(x, x) - x).abs().amax((-2, -1)) + (tr - nocc).abs()
+    return x, err
+
+
+class LockstepSCF:
+    """M restricted closed-shell calculations (HF / KS objects, built, same `signature`) iterated together.
+        LockstepSCF(qcs).run()      -> every qc has .energy(), .aodm(), .converged, .niter, .scf_error as after qc.run()"""
+
+    def __init__(self, qcs, nstreams: int = 3, graph="auto"):
+        sigs = {signature(q) for q in qcs}
+        if len(sigs) != 1 or None in sigs:
+            raise ValueError("LockstepSCF needs restricted closed-shell calculations of one (device, nao, n_occ) signature")
+        self.qcs = list(qcs)
+        self.engines = [q._engine for q in qcs]
+        e0 = self.engines[0]
+        self.device, self.dtype = e0.device, e0.dtype
+        self._engine = e0  # (batch.run_concurrent reads the device from here)
+        self.n, self.r = int(e0.shape[-1]), int(e0.norb)
+        self.occ = float(e0.orb_weight[0])
+        self.nstreams = max(1, min(nstreams, len(qcs)))
+        self._graphs = None
+        # the per-molecule Fock build replays as a hipGraph where it is launch-bound (small molecules: ~30 launches for
+        # 0.1-0.4 ms of kernels); a 20-atom build (1.4 ms of kernels) is issued eagerly -- capturing 32 graphs would cost
+        # more than the launches they save
+        self.use_graph = (self.n <= 160) if graph == "auto" else bool(graph)
+        gen = torch.Generator().manual_seed(20240229)
+        self.omega = torch.randn((self.n, self.r), dtype=self.dtype, generator=gen).to(self.device)
+        self.eigh_fallbacks = 0
+
+    # ------------------------------------------------------------------ pieces
+    def _fock_builders(self):
+        if self._graphs is None:
+            from .graph import GraphedFock
+            self._graphs = [GraphedFock(e, warmup=1) for e in self.engines]
+        return self._graphs
+
+    def _occupied(self, fmix):
+        """(Q (M, n, r) orthonormal occupied-space bases of the Fock matrices, err (M,)) without an eigensolver"""
+        p, err = projectors_from_focks(fmix, self.r)
+        y = torch.matmul(p, self.omega)
+        g = torch.bmm(y.transpose(-2, -1), y)
+        q = lib.orth_factor_batched(y, g)
+        # a failed factorisation (NaN / wrong range) must show in the error so that the molecule falls back to eigh
+        ferr = (torch.bmm(q, q.transpose(-2, -1)) - p).abs().amax((-2, -1))
+        return q, err + ferr
+
+    def _build(self, q, active, fock, dm, streams):
+        """fock[m], dm[m] <- Fock build of the orbitals q[m] for the active molecules, dealt to the side streams"""
+        main = torch.cuda.current_stream(self.device)
+        graphs = self._fock_builders() if self.use_graph else None
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for k, m in enumerate(active):
+            s = streams[k % len(streams)]
+            s.wait_event(ready)
+            with torch.cuda.stream(s):
+                if graphs is not None:
+                    g = graphs[m]
+                    g.orb.copy_(q[m])
+                    g.graph.replay()
+                    fock[m].copy_(g.fock)
+                    dm[m].copy_(g.dm)
+                else:  # hf.py:105-113 (ao_orb2dm) + the Fock build, as the one-molecule driver issues them
+                    e = self.engines[m]
+                    d = e.hamilton.ao_orb2dm(q[m], e.orb_weight)
+                    fock[m].copy_(e.dm2scp(d))
+                    dm[m].copy_(d)
+        for s in streams[:min(len(streams), len(active))]:
+            main.wait_stream(s)
+
+    # ------------------------------------------------------------------ the loop
+    def run(self, **kw):
+        gen = self._run_gen(**kw)
+        try:
+            req = next(gen)
+            while True:
+                req = gen.send(req.cpu().numpy())
+        except StopIteration:
+            pass
+        return self
+
+    def _run_gen(self, dm0="1e", fwd_options=None):
+        """generator with the protocol of SCF_QCCalc._run_gen: yields the small device tensor it needs on the host (one per
+        iteration for the whole batch), is resumed with its numpy copy"""
+        if dm0 != "1e":
+            raise RuntimeError("LockstepSCF starts from the core guess dm0='1e' (scf_qccalc.py:88-91)")
+        opts = {"maxiter": 50, "f_tol": 1e-9, "history": 12}
+        opts.update(fwd_options or {})
+        H = int(opts["history"])
+        M, n, dev, dt = len(self.qcs), self.n, self.device, self.dtype
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(self.nstreams)]
+        fock = torch.empty((M, n, n), dtype=dt, device=dev)
+        dm = torch.empty((M, n, n), dtype=dt, device=dev)
+        fh = torch.zeros((M, H, n * n), dtype=dt, device=dev)
+        eh = torch.zeros((M, H, n * n), dtype=dt, device=dev)
+        gram = torch.zeros((M, H, H), dtype=dt, device=dev)
+        coef = torch.zeros((M, H), dtype=dt, device=dev)
+        trace = bool(os.environ.get("DQC_AMD_SCF_TRACE"))
+        for q in self.qcs:
+            q.converged = q.stalled = False
+            q.niter, q.scf_error = 0, float("inf")
+            q.eigh_fallbacks = 0
+
+        def fix_failed(qmat, fmix, perr_host, which):
+            # purification did not converge (vanishing gap): that molecule's orbitals come from eigh (hf.py:227-247)
+            for m in which:
+                if not perr_host[m] < 1e-9:
+                    qmat[m].copy_(self.engines[m].scp2orb(fmix[m]))
+                    self.qcs[m].eigh_fallbacks += 1
+                    self.eigh_fallbacks += 1
+
+        # core guess (scf_qccalc.py:88-91): F0 = dm2scp(0), occupy its lowest orbitals
+        z = torch.zeros((n, n), dtype=dt, device=dev)
+        f0 = torch.stack([e.dm2scp(z) for e in self.engines])
+        qmat, perr = self._occupied(f0)
+        host = yield perr
+        active = list(range(M))
+        fix_failed(qmat, f0, host, active)
+        self._build(qmat, active, fock, dm, streams)
+
+        best = [[float("inf"), 0] for _ in range(M)]
+        fmix = f0
+        for it in range(int(opts["maxiter"])):
+            a = torch.bmm(fock, dm)
+            err = a - a.transpose(-2, -1)  # [F, D] (both symmetric)
+            emax_t = err.abs().amax((-2, -1))
+            slot = it % H
+            ev = err.reshape(M, -1)
+            eh[:, slot] = ev
+            fh[:, slot] = fock.reshape(M, -1)
+            row = (eh * ev.unsqueeze(1)).sum(-1)  # scalar products with every stored error vector (unused slots hold zeros)
+            gram[:, slot, :] = row
+            gram[:, :, slot] = row
+            m_valid = min(it + 1, H)
+            if m_valid > 1:
+                lib.diis_solve(gram, m_valid, out=coef)
+                fmix = (coef.unsqueeze(-1) * fh).sum(1).reshape(M, n, n)
+            else:
+                fmix = fock.clone()
+            # the next projector is formed before the host has seen max|[F, D]| (speculatively: it is ~1 ms for the whole batch)
+            qmat, perr = self._occupied(fmix)
+            host = yield torch.cat([emax_t, perr])
+            emax, pe = host[:M], host[M:]
+            if trace:
+                print("lockstep it %2d  max|[F,D]|: %s" % (it, " ".join("%.1e" % emax[m] for m in range(M))), flush=True)
+            for m in list(active):
+                qc = self.qcs[m]
+                qc.niter, qc.scf_error = it + 1, float(emax[m])
+                if emax[m] < best[m][0] * 0.9:
+                    best[m] = [float(emax[m]), it]
+                done = emax[m] < opts["f_tol"]
+                stalled = (not done) and emax[m] < 100 * opts["f_tol"] and it - best[m][1] >= 8
+                if done or stalled:
+                    qc.converged, qc.stalled = bool(done), bool(stalled)
+                    self._finish(qc, m, fock, dm)
+                    active.remove(m)
+            if not active:
+                break
+            fix_failed(qmat, fmix, pe, active)
+            if it + 1 < int(opts["maxiter"]):
+                self._build(qmat, active, fock, dm, streams)
+        for m in active:  # maxiter exhausted
+            qc = self.qcs[m]
+            self._finish(qc, m, fock, dm)
+            warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e)"
+                          % (qc.niter, qc.scf_error, opts["f_tol"]))
+
+    @staticmethod
+    def _finish(qc, m, fock, dm):
+        qc._dm = dm[m].clone()
+        qc._fock = fock[m].clone()
+        qc._has_run = True

@@ -21,6 +21,9 @@ from .utils.datastruct import SpinParam
 from .xc import get_xc
 
 
+_DIIS_SCALE = os.environ.get("DQC_AMD_DIIS_SCALE", "1") != "0"
+
+
 class _Engine:
     def __init__(self, system, xc=None, is_ks=False, restricted=None):
         self._system = system
@@ -260,7 +263,10 @@ class SCF_QCCalc:
             gram = gnew
             if m > 1:
                 B = np.zeros((m + 1, m + 1))
-                B[:m, :m] = gram
+                # the Pulay coefficients do not change when the Gram block is scaled (only the multiplier does): normalised to
+                # a unit largest diagonal, otherwise lstsq's rank cut (eps x largest singular value, set by the +-1 border)
+                # discards the whole Gram block once the errors fall below ~1e-8 and the mix degrades to a plain average
+                B[:m, :m] = gram / max(float(np.max(np.diag(gram))), 1e-300) if _DIIS_SCALE else gram
                 B[m, :m] = -1
                 B[:m, m] = -1
                 rhs = np.zeros(m + 1)

@@ -200,6 +200,20 @@ int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, d
  * Q Q^T = P.  One launch (Cholesky in LDS + row-wise forward substitution); r <= 132.  Enqueues only. */
 int dqc_orth_factor(double *d_q, const double *d_y, const double *d_g, int n, int r, void *stream);
 
+/* ---- the same two steps for a BATCH of molecules iterated in lockstep (the reference runs one SCF loop per
+ * molecule, scf_qccalc.py:109-113; here nmol same-size problems share every launch, blockIdx.y = molecule) ----
+ * d_x, d_tmp (nmol, ld, ld); d_state (nmol, 2 * (iters + 2)); every matrix freezes on its own. */
+int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nmol, double nocc, int iters, double tol,
+                           double *d_state, void *stream);
+/* d_y (nmol, n, r), d_g (nmol, r, r) -> d_q (nmol, n, r) */
+int dqc_orth_factor_batched(double *d_q, const double *d_y, const double *d_g, int n, int r, int nmol, void *stream);
+/* Pulay (DIIS) coefficients of nmol independent problems on the device: d_gram (nmol, nhist, nhist) scalar products of the stored
+ * error vectors [F, D] (first m slots valid), d_c (nmol, nhist) <- c with sum c = 1 minimising |sum c_i e_i| -- the
+ * minimum-norm least-squares solution of the bordered system (Gram block normalised to a unit largest diagonal), as
+ * numpy.linalg.lstsq gives it in the one-molecule driver.  nhist <= 16.  Replaces the fixed-point mixer of
+ * scf_qccalc.py:109-113 (xitorch Broyden) -- any convergent mixer has the same fixed point. */
+int dqc_diis_solve(double *d_c, const double *d_gram, int nmol, int nhist, int m, void *stream);
+
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
  * AO basis.  d_vgrad may be NULL (LDA; then ncomp may be 1).  The matrix is overwritten. */
