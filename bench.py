@@ -245,7 +245,7 @@ def main():
             for st, f in zip(steps_g, focks):
                 st(f)
         barrier()
-        out_extra["full_scf_iterations_per_s_per_gpu"] = nsel * K / (time.perf_counter() - t0)
+        one_mol_graph_rate = nsel * K / (time.perf_counter() - t0)
         del steps_g
         # the Hartree-Fock flavour of the J/K pass (get_elrep + get_exchange, hf.py:198-199): one fused J + K launch
         if h0.df is None:
@@ -275,41 +275,54 @@ def main():
             torch.cuda.synchronize()
             out_extra["jk_multi_j_only_ms"] = e0.elapsed_time(e1) / K
             out_extra["eri_fill"] = eri_fill_stats(h0, dev)
-        # SURVEY.md 8(d) metric (iv): time to the converged energies of the batch -- KS(...).run().energy() from the core guess
-        # for every molecule of this rank, one after the other (setup above excluded, reported beside it)
-        # (a) one molecule after the other; (b) dqc_amd.batch.run_concurrent: one stream per molecule in flight, so the host
-        # part of one SCF iteration (DIIS algebra, the per-iteration device -> host read) overlaps the others' GPU work
-        from dqc_amd.batch import run_concurrent
+        # SURVEY.md 8(d) metric (iv): time to the converged energies of the batch -- KS(...).energy() of every molecule of this
+        # rank from the core guess (setup above excluded, reported beside it).  (a) the batch driver: lockstep SCF
+        # (dqc_amd/lockstep.py: DIIS, purification and the Cholesky-QR batched over the molecules, one host read per iteration
+        # for the batch); (b) the one-molecule drivers of round 2, 8 in flight on their own streams, as the cross-check
+        from dqc_amd.batch import run_concurrent, run_lockstep
         barrier()
         t0 = time.perf_counter()
-        for qc in qcs:
-            qc.run()
-        es_serial = [float(qc.energy()) for qc in qcs]
+        run_lockstep(qcs)
+        es = [float(qc.energy()) for qc in qcs]
         barrier()
-        scf_serial_s = time.perf_counter() - t0
+        scf_s = time.perf_counter() - t0
+        nits = [int(qc.niter) for qc in qcs]
+        nit, nconv = sum(nits), sum(int(qc.converged) for qc in qcs)
+        nstall, nfb = sum(int(qc.stalled) for qc in qcs), sum(int(getattr(qc, "eigh_fallbacks", 0)) for qc in qcs)
+        errmax = max(float(qc.scf_error) for qc in qcs)
+        hist = {}
+        for k in nits:
+            hist[k] = hist.get(k, 0) + 1
         barrier()
         t0 = time.perf_counter()
         run_concurrent(qcs, max_inflight=8)
-        es = [float(qc.energy()) for qc in qcs]
-        nit = sum(qc.niter for qc in qcs)
-        nacc = sum(int(qc.accepted) for qc in qcs)
+        es_conc = [float(qc.energy()) for qc in qcs]
+        nit_conc = sum(qc.niter for qc in qcs)
         barrier()
-        scf_s = time.perf_counter() - t0
-        de_max = max(abs(a - b) for a, b in zip(es, es_serial))
-        tab = torch.tensor([scf_s, float(nit), float(nacc), float(len(qcs)), setup_s], dtype=torch.float64, device=dev)
+        scf_conc_s = time.perf_counter() - t0
+        de_max = max(abs(a - b) for a, b in zip(es, es_conc))
+        tab = torch.tensor([scf_s, float(nit), float(nconv), float(len(qcs)), setup_s, float(nstall), float(nfb), scf_conc_s,
+                            float(nit_conc)], dtype=torch.float64, device=dev)
         if world > 1:
             tmx = tab.clone()
             dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
             dist.all_reduce(tab, op=dist.ReduceOp.SUM)
-            tab[0], tab[4] = tmx[0], tmx[4]
-        out_extra["batch_scf"] = {"time_to_converged_energy_s": float(tab[0]), "time_serial_loop_s": scf_serial_s,
-                                  "max_abs_energy_diff_concurrent_vs_serial_ha": de_max, "setup_s_max_rank": float(tab[4]),
-                                  "molecules": int(tab[3]), "accepted": int(tab[2]), "scf_iterations_total": int(tab[1]),
+            tab[0], tab[4], tab[7] = tmx[0], tmx[4], tmx[7]
+        out_extra["batch_scf"] = {"time_to_converged_energy_s": float(tab[0]), "scf_iterations_total": int(tab[1]),
+                                  "molecules": int(tab[3]), "converged": int(tab[2]), "stalled": int(tab[5]),
+                                  "eigh_fallbacks": int(tab[6]), "max_scf_error_rank0": errmax,
+                                  "iterations_histogram_rank0": {str(k): v for k, v in sorted(hist.items())},
+                                  "time_one_molecule_drivers_8_in_flight_s": float(tab[7]),
+                                  "scf_iterations_one_molecule_drivers": int(tab[8]),
+                                  "max_abs_energy_diff_lockstep_vs_one_molecule_ha": de_max, "setup_s_max_rank": float(tab[4]),
                                   "energy_molecule0_ha": es[0] if rank == 0 else None,
-                                  "note": "KS(mol, xc).run().energy() of every molecule from the core guess, DIIS + purification "
-                                          "hipGraph step, 8 molecules in flight on their own streams (batch.run_concurrent); "
-                                          "time_serial_loop_s = the same one molecule after the other (rank 0's clock); one-off "
-                                          "setup (ERI fill, AO on grid) listed separately"}
+                                  "note": "KS(mol, xc) energies of every molecule from the core guess, f_tol 1e-9 on max|[F,D]|: "
+                                          "lockstep batch driver (batch.run_lockstep); the one-molecule DIIS + purification-graph "
+                                          "drivers (batch.run_concurrent, 8 in flight) beside it; one-off setup (ERI fill, AO on "
+                                          "grid) listed separately"}
+        # SURVEY.md 8(d) metric (ii) for the batch: whole SCF iterations (DIIS + projector + Fock build) per second
+        out_extra["full_scf_iterations_per_s_per_gpu"] = nit / scf_s
+        out_extra["full_scf_iterations_per_s_one_molecule_graph_per_gpu"] = one_mol_graph_rate
 
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components

@@ -192,10 +192,12 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cou
     }
     __syncthreads();
     for (int sweep = 0; sweep < 30; sweep++) {
-        double off = 0.0;  // every lane sums the whole off-diagonal part: uniform decision without a reduction
-        for (int i = 0; i < N; i++)
+        double off = 0.0, dia = 0.0;  // every lane sums the whole matrix: uniform decision without a reduction
+        for (int i = 0; i < N; i++) {
+            dia += A[i][i] * A[i][i];
             for (int j = i + 1; j < N; j++) off += A[i][j] * A[i][j];
-        if (off < 1e-60) break;
+        }
+        if (off <= 1e-34 * dia) break;  // quadratic convergence: the next sweep would not change a digit
         for (int p = 0; p < N - 1; p++)
             for (int q = p + 1; q < N; q++) {
                 if (t == 0) {

@@ -15,7 +15,8 @@ namespace dqc {
 
 __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                           const double *__restrict__ rho, const double *__restrict__ grho, int n, XcTerms terms,
-                          int gga) {
+                          int gga, const double *__restrict__ w, double *__restrict__ exc) {
+    double equad = 0.0;  // this lane's share of the quadrature E_xc = sum_i w_i e_i (hcgto.py:320-328), when asked for
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double r = rho[i];
         double gx = 0, gy = 0, gz = 0;
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, dou
         double e, vr, vs;
         xc_point(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
         if (edens) edens[i] = e;
+        if (exc) equad += w[i] * e;
         if (vrho) vrho[i] = vr;
         if (vgrad && gga) {
             vgrad[i] = 2.0 * vs * gx;
@@ -30,6 +32,21 @@ __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, dou
             vgrad[2 * (size_t)n + i] = 2.0 * vs * gz;
         }
     }
+    if (exc) {  // wavefront reduction of the grid quadrature; one partial per block, summed in order by xc_quad_sum_kernel
+        __shared__ double part[4];
+        for (int o = 32; o > 0; o >>= 1) equad += __shfl_xor(equad, o);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = equad;
+        __syncthreads();
+        if (threadIdx.x == 0) exc[1 + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+}
+
+// exc[0] = sum of the per-block partials exc[1 .. nb] in a fixed order (no atomics: the quadrature is reproducible bit for bit)
+__global__ __launch_bounds__(64) void xc_quad_sum_kernel(double *__restrict__ exc, int nb) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += exc[1 + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) exc[0] = s;
 }
 
 
@@ -152,11 +169,15 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
 
 }  // namespace dqc
 
-extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
-                           const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
-                           void *stream) {
+extern "C" int dqc_xc_eval_quad(double *d_exc, double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
+                                const double *d_grho, const double *d_w, int n, const int *ids, const double *coefs, int nterm,
+                                void *stream) {
+    // dqc_xc_eval plus the quadrature of the energy density in the same pass: d_exc[0] = sum_i w_i e_i (wavefront reductions,
+    // one partial per block in d_exc[1 ..], summed in a fixed order: no atomics).  d_exc: DQC_XC_QUAD_DOUBLES doubles.
+    // d_exc / d_w NULL: no quadrature.
     using namespace dqc;
     if (nterm < 0 || nterm > 8) { set_error("dqc_xc_eval: at most 8 functional terms"); return DQC_EINVAL; }
+    if (d_exc && !d_w) { set_error("dqc_xc_eval_quad: the quadrature needs the grid weights"); return DQC_EINVAL; }
     XcTerms t;
     t.n = nterm;
     bool need_grad = false;
@@ -170,13 +191,27 @@ extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, con
         }
     }
     if (need_grad && !d_grho) { set_error("dqc_xc_eval: GGA functional needs the density gradient"); return DQC_EINVAL; }
-    if (n <= 0) return DQC_OK;
+    if (n <= 0) {
+        if (d_exc) DQC_HIP(hipMemsetAsync(d_exc, 0, sizeof(double), (hipStream_t)stream));
+        return DQC_OK;
+    }
     int blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    const int cap = d_exc ? DQC_XC_QUAD_DOUBLES - 1 : 4096;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(xc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
-                       d_grho, n, t, d_grho ? 1 : 0);
+                       d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
     DQC_CHECK_LAUNCH();
+    if (d_exc) {
+        hipLaunchKernelGGL(xc_quad_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exc, blocks);
+        DQC_CHECK_LAUNCH();
+    }
     return DQC_OK;
+}
+
+extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
+                           const double *d_grho, int n, const int *ids, const double *coefs, int nterm,
+                           void *stream) {
+    return dqc_xc_eval_quad(nullptr, d_edens, d_vrho, d_vgrad, d_rho, d_grho, nullptr, n, ids, coefs, nterm, stream);
 }
 
 namespace dqc {

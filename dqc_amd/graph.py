@@ -17,7 +17,8 @@ from .utils.datastruct import SpinParam
 
 
 class GraphedFock:
-    def __init__(self, engine, warmup: int = 2):
+    def __init__(self, engine, warmup: int = 2, with_energy: bool = False):
+        self.with_energy = with_energy
         if engine.polarized:
             raise NotImplementedError("GraphedFock covers the restricted engines; UHF/UKS run eagerly")
         self.engine = engine
@@ -36,14 +37,18 @@ class GraphedFock:
         torch.cuda.synchronize(engine.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.dm, self.fock = self._body()
+            self.dm, self.fock, self.energy = self._body()
         h._jk_cache = None     # the memoised tensors belong to the graph's private pool
         h._jkpol_cache = None
         h._dm_factor = None
+        h._energy_memo = None
 
     def _body(self):
         dm = self.engine.hamilton.ao_orb2dm(self.orb, self.weight)
-        return dm, self.engine.dm2scp(dm)
+        fock = self.engine.dm2scp(dm)
+        # the total energy of this density rides along: its two-electron parts are by-products of the build just made
+        # (the Hamiltonian's memo), the rest is tr(D h)
+        return dm, fock, (self.engine.dm2energy(dm) if self.with_energy else None)
 
     def __call__(self, orb):
         """orb (nao, norb) occupied orbitals in the orthogonalised basis -> Fock matrix (static buffer)"""
@@ -98,6 +103,7 @@ class GraphedSCFStep:
         h._jk_cache = None
         h._jkpol_cache = None
         h._dm_factor = None
+        h._energy_memo = None
 
     def _dm_of_projector(self, p, s_):
         """occ * P as ao_orb2dm(Q, occ) with Q an orthonormal basis of range(P) (Cholesky QR of P . Omega, one small launch:

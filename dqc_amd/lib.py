@@ -71,6 +71,7 @@ def load():
     lib.dqc_eval_gto.argtypes = [c_int, c_dp, c_dp, c_int] + tab + [c_vp]
     lib.dqc_grid_density.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_vp]
     lib.dqc_xc_eval.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
+    lib.dqc_xc_eval_quad.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_grid_fused_supported.argtypes = [c_int, c_int]
@@ -401,6 +402,20 @@ def xc_eval(terms, rho, grho, want_e=True, want_v=True):
         _check(load().dqc_xc_eval(_ptr(e), _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), n, ids, cfs, len(terms), st_),
                "dqc_xc_eval")
     return e, v, vg
+
+
+def xc_eval_quad(terms, rho, grho, w, want_v=True):
+    """potentials AND the quadrature E_xc = sum_i w_i e_i from one pass over the grid -> exc (result in exc[0]), vrho, vgrad (3, n) or None"""
+    n = rho.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    exc = torch.empty(1025, dtype=torch.float64, device=rho.device)  # DQC_XC_QUAD_DOUBLES: result + per-block partials
+    v = torch.empty_like(rho) if want_v else None
+    vg = torch.empty((3, n), dtype=torch.float64, device=rho.device) if (want_v and grho is not None) else None
+    with _on(rho.device) as st_:
+        _check(load().dqc_xc_eval_quad(_ptr(exc), None, _ptr(v), _ptr(vg), _ptr(rho), _ptr(grho), _ptr(w), n, ids, cfs, len(terms),
+                                       st_), "dqc_xc_eval_quad")
+    return exc, v, vg
 
 
 def xc_eval_pol(terms, rho_u, rho_d, grho_u, grho_d, want_e=True, want_v=True):

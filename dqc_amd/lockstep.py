@@ -103,7 +103,7 @@ class LockstepSCF:
     def _fock_builders(self):
         if self._graphs is None:
             from .graph import GraphedFock
-            self._graphs = [GraphedFock(e, warmup=1) for e in self.engines]
+            self._graphs = [GraphedFock(e, warmup=1, with_energy=True) for e in self.engines]
         return self._graphs
 
     def _occupied(self, fmix):
@@ -116,8 +116,9 @@ class LockstepSCF:
         ferr = (torch.bmm(q, q.transpose(-2, -1)) - p).abs().amax((-2, -1))
         return q, err + ferr
 
-    def _build(self, q, active, fock, dm, streams):
-        """fock[m], dm[m] <- Fock build of the orbitals q[m] for the active molecules, dealt to the side streams"""
+    def _build(self, q, active, fock, dm, etot, streams):
+        """fock[m], dm[m], etot[m] <- Fock build (and total energy) of the orbitals q[m] for the active molecules, dealt to the
+        side streams"""
         main = torch.cuda.current_stream(self.device)
         graphs = self._fock_builders() if self.use_graph else None
         ready = torch.cuda.Event()
@@ -132,11 +133,13 @@ class LockstepSCF:
                     g.graph.replay()
                     fock[m].copy_(g.fock)
                     dm[m].copy_(g.dm)
+                    etot[m].copy_(g.energy)
                 else:  # hf.py:105-113 (ao_orb2dm) + the Fock build, as the one-molecule driver issues them
                     e = self.engines[m]
                     d = e.hamilton.ao_orb2dm(q[m], e.orb_weight)
                     fock[m].copy_(e.dm2scp(d))
                     dm[m].copy_(d)
+                    etot[m].copy_(e.dm2energy(d))  # by-products of the build just made + tr(D h): no second pass
         for s in streams[:min(len(streams), len(active))]:
             main.wait_stream(s)
 
@@ -168,6 +171,7 @@ class LockstepSCF:
         eh = torch.zeros((M, H, n * n), dtype=dt, device=dev)
         gram = torch.zeros((M, H, H), dtype=dt, device=dev)
         coef = torch.zeros((M, H), dtype=dt, device=dev)
+        etot = torch.zeros(M, dtype=dt, device=dev)
         trace = bool(os.environ.get("DQC_AMD_SCF_TRACE"))
         for q in self.qcs:
             q.converged = q.stalled = False
@@ -189,7 +193,7 @@ class LockstepSCF:
         host = yield perr
         active = list(range(M))
         fix_failed(qmat, f0, host, active)
-        self._build(qmat, active, fock, dm, streams)
+        self._build(qmat, active, fock, dm, etot, streams)
 
         best = [[float("inf"), 0] for _ in range(M)]
         fmix = f0
@@ -225,21 +229,22 @@ class LockstepSCF:
                 stalled = (not done) and emax[m] < 100 * opts["f_tol"] and it - best[m][1] >= 8
                 if done or stalled:
                     qc.converged, qc.stalled = bool(done), bool(stalled)
-                    self._finish(qc, m, fock, dm)
+                    self._finish(qc, m, fock, dm, etot)
                     active.remove(m)
             if not active:
                 break
             fix_failed(qmat, fmix, pe, active)
             if it + 1 < int(opts["maxiter"]):
-                self._build(qmat, active, fock, dm, streams)
+                self._build(qmat, active, fock, dm, etot, streams)
         for m in active:  # maxiter exhausted
             qc = self.qcs[m]
-            self._finish(qc, m, fock, dm)
+            self._finish(qc, m, fock, dm, etot)
             warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e)"
                           % (qc.niter, qc.scf_error, opts["f_tol"]))
 
     @staticmethod
-    def _finish(qc, m, fock, dm):
+    def _finish(qc, m, fock, dm, etot):
         qc._dm = dm[m].clone()
         qc._fock = fock[m].clone()
+        qc._energy = etot[m].clone()  # engine.dm2energy(dm) as evaluated with the Fock build of this very dm
         qc._has_run = True

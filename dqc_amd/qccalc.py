@@ -45,6 +45,7 @@ class _Engine:
         self.knvext = self.hamilton.get_kinnucl()
         self.shape = self.knvext.shape
         self.dtype, self.device = self.knvext.dtype, self.knvext.device
+        self._enuc = torch.as_tensor(system.get_nuclei_energy()).to(device=self.device, dtype=self.dtype)  # on the device once
         # Mol(orthogonalize_basis=False): the Fock matrix lives in the raw AO basis and `diagonalize` is the generalised problem
         # F C = S C e (hf.py:227-247: lsymeig(A=fock, M=ovlp)).  Solved through S^-1/2: C = S^-1/2 U, U from eigh(S^-1/2 F S^-1/2)
         self.ovlp, self._sinvh = None, None
@@ -113,10 +114,10 @@ class _Engine:
         if self.polarized:  # hf.py:166-172 / ks.py:157-166 with dmtot = dm.u + dm.d
             tot = dm.u + dm.d
             e = h.get_e_hcore(tot) + h.get_e_elrep(tot) + (h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
-            return e + self._system.get_nuclei_energy().to(e.device)
+            return e + self._enuc
         e = h.get_e_hcore(dm) + h.get_e_elrep(dm)
         e = e + (h.get_e_xc(dm) if self.is_ks else h.get_e_exchange(dm))
-        return e + self._system.get_nuclei_energy().to(e.device)
+        return e + self._enuc
 
     def energy_parts(self, dm):
         h = self.hamilton
@@ -292,6 +293,7 @@ class SCF_QCCalc:
                 fock = eng.dm2scp(dm)
         self._dm = dm
         self._fock = fock
+        self._energy = None
         self._has_run = True
         if not self.accepted:  # the reference's xitorch solver emits a ConvergenceWarning here
             warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e); energy() and "
@@ -300,6 +302,9 @@ class SCF_QCCalc:
 
     def energy(self):
         assert self._has_run
+        e = getattr(self, "_energy", None)  # the lockstep driver keeps dm2energy(dm) of the final Fock build (same call, same dm)
+        if e is not None:
+            return e
         return self._engine.dm2energy(self._dm)
 
     def aodm(self):

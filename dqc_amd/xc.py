@@ -149,6 +149,16 @@ class LibXC(BaseXC):
         return ValGrad(value=v, grad=vg)
 
 
+    def get_vxc_and_exc(self, densinfo, w):
+        """(potentials, E_xc = sum_g w_g e_g as a (1,) device tensor) from ONE pass over the grid, for the unpolarised LDA / GGA
+        kernel set; (potentials, None) otherwise.  What get_vxc + get_edensityxc (libxc.py:40-85) give in two passes."""
+        if isinstance(densinfo, SpinParam) or self.family == 4 or not self.terms:
+            return self.get_vxc(densinfo), None
+        rho, grad = self._flat(densinfo)
+        exc, v, vg = lib.xc_eval_quad(self.terms, rho, grad, w)
+        return ValGrad(value=v, grad=vg), exc
+
+
 class _SumXC(BaseXC):
     def __init__(self, a, b):
         self.a, self.b = a, b

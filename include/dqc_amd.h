@@ -124,6 +124,13 @@ int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *
 /* spin-polarised variant (polarised branches of dqc/xc/libxc.py:124-242): inputs rho_u, rho_d (n) and their
  * gradients (3,n) or NULL; outputs edens (n) = zk*(rho_u+rho_d), vrho_{u,d} (n), and
  * vgrad_u = 2 vsigma_uu grad_u + vsigma_ud grad_d, vgrad_d = 2 vsigma_dd grad_d + vsigma_ud grad_u  (libxc.py:205-215) */
+/* the same pass with the grid quadrature of the energy density fused in (E_xc = sum_g w_g e_g, hcgto.py:320-328):
+ * wavefront reductions, one partial per block, summed in a fixed order (no atomics: bit-reproducible).  d_exc:
+ * DQC_XC_QUAD_DOUBLES doubles, the result in d_exc[0], the rest scratch; d_edens may be NULL. */
+#define DQC_XC_QUAD_DOUBLES 1025
+int dqc_xc_eval_quad(double *d_exc, double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
+                     const double *d_grho, const double *d_w, int n, const int *ids, const double *coefs, int nterm,
+                     void *stream);
 int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
                     const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
                     int n, const int *ids, const double *coefs, int nterm, void *stream);
