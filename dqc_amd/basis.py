@@ -31,8 +31,20 @@ def _normalize_basisname(name):
     return b
 
 
+_BASIS_CACHE = {}
+
+
 def loadbasis(cmd: str, dtype=torch.float64, device=torch.device("cpu"), requires_grad=False) -> List[CGTOBasis]:
-    """cmd = "<atomz>:<basis name>", e.g. "8:cc-pVDZ" -> list of normalised CGTOBasis (loadbasis.py:11-83)"""
+    """cmd = "<atomz>:<basis name>", e.g. "8:cc-pVDZ" -> list of normalised CGTOBasis (loadbasis.py:11-83).  Parsed and normalised
+    once per (element, basis): later calls get fresh CGTOBasis objects over the same (read-only) tensors."""
+    import dataclasses
+    key = (cmd.strip().lower(), dtype, str(device))
+    if key not in _BASIS_CACHE:
+        _BASIS_CACHE[key] = _loadbasis(cmd, dtype, device)
+    return [dataclasses.replace(b) for b in _BASIS_CACHE[key]]
+
+
+def _loadbasis(cmd: str, dtype, device) -> List[CGTOBasis]:
     atomz_str, raw = cmd.split(":")
     atomz = int(atomz_str)
     fpath = os.path.join(_DATA, _normalize_basisname(raw.strip()), "%02d.gaussian94" % atomz)

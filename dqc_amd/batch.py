@@ -16,6 +16,36 @@ def molecule_cost(nao: int, ngrid: int) -> float:
     return float(nao) ** 4 + 12.0 * float(ngrid) * float(nao) ** 2
 
 
+def molecule_bytes(nao: int, ngrid: int, ncomp: int = 4) -> int:
+    """device memory one resident molecule needs: 8-fold-unique ERI tiles (~nao^4 bytes), the AO matrix on the grid
+    (ncomp = 1 LDA, 4 GGA, 5 meta-GGA components) and the per-point work arrays of a Fock build"""
+    nb = (nao + 7) // 8
+    npair = nb * (nb + 1) // 2
+    ld = (nao + 15) // 16 * 16 + 16
+    return npair * (npair + 1) // 2 * 4096 * 8 + 8 * ncomp * ngrid * ld + 8 * 16 * ngrid + 64 * ld * ld
+
+
+def reserve_device_memory(nbytes: int, device) -> float:
+    """Take `nbytes` of device memory from the driver in ONE request and hand it to PyTorch's caching allocator (the block
+    is freed into the cache, later tensors are carved out of it).  Fresh VRAM is not free on this platform: the kernel
+    driver clears it at ~35 GB/s (measured, tools/gpu_alloc_cost*.py: the first ~84 GiB of a freshly booted MI355X are
+    instant, beyond that -- or while memory released by a previous process is still being wiped -- a 2 GB hipMalloc blocks
+    for 60 ms), which used to be spread over the ERI-tile and AO allocations of every molecule of a batch.  Returns the
+    seconds the request took.  A long-lived process pays this once, not once per batch."""
+    import time
+    dev = torch.device(device)
+    free, _ = torch.cuda.mem_get_info(dev)
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    nbytes = int(min(nbytes, free - (2 << 30)))
+    if nbytes <= cached:
+        return 0.0
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    block = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    del block
+    return time.perf_counter() - t0
+
+
 def shard_lpt(costs: Sequence[float], world_size: int) -> List[List[int]]:
     """longest-processing-time-first assignment of molecule indices to ranks (deterministic)"""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))

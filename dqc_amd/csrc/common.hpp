@@ -56,31 +56,69 @@ struct DevShells {
     int nsh = 0;
 };
 
-// simple RAII-less device allocation list freed at the end of a (synchronous) setup call
+// pinned host staging blocks, recycled once the copy that read them has completed (host.hip)
+struct Staging {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    int dev = 0;
+    bool held = false;  // handed to an open DevPool: its copy has not even been enqueued yet
+    bool busy = false;  // an event was recorded behind its copy: free again once that event has completed
+};
+Staging *staging_acquire(size_t bytes);
+void staging_release(Staging *s, hipStream_t st);
+
+// Device scratch of a setup call (shell / pair tables).  Two modes:
+//   DevPool pool;       synchronous: hipMalloc / pageable copies / hipFree -- the caller synchronises the stream before return;
+//   DevPool pool(st);   stream-ordered: hipMallocAsync, copies staged through recycled pinned blocks, hipFreeAsync -- the call
+//                       only ENQUEUES (no device-wide synchronisation by hipFree, no host wait), so the setup of the next
+//                       molecule overlaps this one's kernels.
 struct DevPool {
     std::vector<void *> ptrs;
+    std::vector<Staging *> stg;
+    hipStream_t ast = nullptr;
+    bool async = false;
+    DevPool() {}
+    explicit DevPool(hipStream_t st) : ast(st), async(true) {}
+    DevPool(const DevPool &) = delete;
+    DevPool &operator=(const DevPool &) = delete;
+    int dmalloc(void **p, size_t bytes) {
+        hipError_t e = async ? hipMallocAsync(p, bytes ? bytes : 8, ast) : hipMalloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) return DQC_ENOMEM;
+        ptrs.push_back(*p);
+        return 0;
+    }
     template <typename T>
     int upload(T **dst, const std::vector<T> &src, hipStream_t st) {
         size_t bytes = src.size() * sizeof(T);
         void *p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return DQC_ENOMEM;
-        ptrs.push_back(p);
-        if (bytes && hipMemcpyAsync(p, src.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess)
-            return DQC_EHIP;
+        if (dmalloc(&p, bytes)) return DQC_ENOMEM;
+        if (bytes) {
+            const void *from = src.data();
+            if (async) {
+                Staging *s = staging_acquire(bytes);
+                if (!s) return DQC_ENOMEM;
+                stg.push_back(s);
+                std::memcpy(s->host, src.data(), bytes);
+                from = s->host;
+            }
+            if (hipMemcpyAsync(p, from, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return DQC_EHIP;
+        }
         *dst = (T *)p;
         return 0;
     }
     template <typename T>
     int alloc(T **dst, size_t n) {
         void *p = nullptr;
-        if (hipMalloc(&p, n * sizeof(T) + 8) != hipSuccess) return DQC_ENOMEM;
-        ptrs.push_back(p);
+        if (dmalloc(&p, n * sizeof(T) + 8)) return DQC_ENOMEM;
         *dst = (T *)p;
         return 0;
     }
     void release() {
-        for (void *p : ptrs) (void)hipFree(p);
+        for (void *p : ptrs) (void)(async ? hipFreeAsync(p, ast) : hipFree(p));
         ptrs.clear();
+        for (Staging *s : stg) staging_release(s, ast);
+        stg.clear();
     }
     ~DevPool() { release(); }
 };

@@ -102,7 +102,7 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     if (nbas == 0) return DQC_OK;
     HostPairs hp;
     build_pairs(b, hp);
-    DevPool pool;
+    DevPool pool(st);  // stream-ordered scratch: this call only enqueues
     DevShells ds;
     if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
     int *d_sh = nullptr, *d_off = nullptr;
@@ -116,7 +116,6 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st);
     if (rc) return rc;
-    DQC_HIP(hipStreamSynchronize(st));
     return DQC_OK;
 }
 

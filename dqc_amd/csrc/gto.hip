@@ -144,7 +144,7 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
-    DevPool pool;
+    DevPool pool(st);  // stream-ordered scratch: this call only enqueues
     DevShells ds;
     if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_eval_gto: device upload failed"); return rc; }
     if (ngrid > 0) {
@@ -160,6 +160,5 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
             hipLaunchKernelGGL(eval_gto_kernel<3>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
         DQC_CHECK_LAUNCH();
     }
-    DQC_HIP(hipStreamSynchronize(st));  // the shell tables are freed on return
     return DQC_OK;
 }

@@ -1,10 +1,45 @@
 // host.hip -- error handling, table parsing and small utilities of libdqc_amd.so
 #include "common.hpp"
+#include <mutex>
 
 namespace dqc {
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
+
+// ---- pinned staging blocks of the stream-ordered DevPool ----
+static std::mutex g_stg_mu;
+static std::vector<Staging *> g_stg;
+
+Staging *staging_acquire(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_stg_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (Staging *s : g_stg) {
+        if (s->dev != dev || s->cap < bytes || s->held) continue;
+        if (s->busy && hipEventQuery(s->ev) != hipSuccess) continue;  // its copy is still in flight
+        s->busy = false;
+        s->held = true;
+        return s;
+    }
+    Staging *s = new Staging;
+    size_t cap = 1 << 16;
+    while (cap < bytes) cap <<= 1;
+    if (hipHostMalloc(&s->host, cap, hipHostMallocDefault) != hipSuccess) { delete s; return nullptr; }
+    if (hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(s->host); delete s; return nullptr; }
+    s->cap = cap;
+    s->dev = dev;
+    s->held = true;
+    g_stg.push_back(s);
+    return s;
+}
+
+void staging_release(Staging *s, hipStream_t st) {
+    // stays `busy` until the event recorded behind the copy has completed (checked at the next acquire)
+    std::lock_guard<std::mutex> lk(g_stg_mu);
+    s->busy = hipEventRecord(s->ev, st) == hipSuccess;
+    s->held = false;
+}
 
 int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, const double *env,
                 int nenv, const double *zs) {

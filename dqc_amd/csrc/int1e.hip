@@ -165,7 +165,7 @@ extern "C" int dqc_int1e(int which, double *d_out, const int *atm, int natm, con
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, zs);
     if (rc) return rc;
-    DevPool pool;
+    DevPool pool(st);  // stream-ordered scratch: this call only enqueues
     DevShells ds;
     if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_int1e: device upload failed"); return rc; }
     double *d_xyz = nullptr, *d_z = nullptr;
@@ -179,6 +179,5 @@ extern "C" int dqc_int1e(int which, double *d_out, const int *atm, int natm, con
                            d_xyz, d_z);
         DQC_CHECK_LAUNCH();
     }
-    DQC_HIP(hipStreamSynchronize(st));
     return DQC_OK;
 }

@@ -35,6 +35,7 @@ class GraphedFock:
                 self._body()
         torch.cuda.current_stream(engine.device).wait_stream(s)
         torch.cuda.synchronize(engine.device)
+        getattr(engine.hamilton, "_tiles", None) if engine.hamilton.df is None else None  # (retires the tile-fill event before the capture)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.dm, self.fock, self.energy = self._body()
@@ -96,6 +97,7 @@ class GraphedSCFStep:
                 self._body()
         torch.cuda.current_stream(engine.device).wait_stream(s)
         torch.cuda.synchronize(engine.device)
+        getattr(engine.hamilton, "_tiles", None) if engine.hamilton.df is None else None  # (retires the tile-fill event before the capture)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.fock, self.dm, self.err = self._body()

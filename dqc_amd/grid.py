@@ -201,6 +201,16 @@ def _becke_weights(rgrids, atompos, atomradii, ratom_adjust):
     rad = atomradii if ratom_adjust == "becke" else atomradii ** 0.5
     uij = (rad - rad.unsqueeze(1)) / (rad + rad.unsqueeze(1))
     aij = torch.clamp(uij / (uij * uij - 1), min=-0.45, max=0.45).unsqueeze(-1)
+    if device.type == "cuda" and not atompos.requires_grad and dtype == torch.float64:
+        # one lane per grid point in the HIP kernel (csrc/becke.hip) instead of ~25 elementwise launches per atom on
+        # (natoms, natoms, ngrid_atom) temporaries; autograd callers (nuclear gradients) keep the torch expression below
+        from . import lib
+        off = [0]
+        for g in rgrids:
+            off.append(off[-1] + g.shape[0])
+        atom_off = torch.tensor(off, dtype=torch.int32).to(device)
+        return lib.becke_weights(torch.cat(rgrids, 0).contiguous(), atom_off, atompos.contiguous(), (1.0 / ratoms).contiguous(),
+                                 aij.squeeze(-1).contiguous(), _BECKE_CUT)
     eye = torch.eye(natoms, dtype=dtype, device=device).unsqueeze(-1)
     out = []
     for ia in range(natoms):
@@ -242,9 +252,12 @@ class BeckeGrid:
         raise KeyError("Invalid methodname: %s" % methodname)
 
 
+_ATOM_GRID_CACHE = {}
+
+
 def get_grid(atomzs, atompos, *, nr=99, nang=590, radgrid_generator="uniform",
              radgrid_transform="sg2-dasgupta", atom_radii="expected", multiatoms_scheme="becke",
-             truncate="dasgupta", dtype=torch.float64, device=None):
+             truncate="dasgupta", dtype=torch.float64, device=None, _cache_tag=None):
     assert atompos.ndim == 2 and atompos.shape[0] == len(atomzs)
     device = atompos.device if device is None else torch.device(device)
     zlist = [int(a) for a in atomzs]
@@ -259,7 +272,12 @@ def get_grid(atomzs, atompos, *, nr=99, nang=590, radgrid_generator="uniform",
         raise ValueError("Unknown radial grid transformation: %s" % radgrid_transform)
     if truncate not in ("dasgupta", "nwchem", "no", None):
         raise ValueError("Unknown truncation rule: %s" % truncate)
-    cache = {}
+    # the one-atom grids depend on the element and the grid options only: built once per process and device
+    if (isinstance(nr, int) and isinstance(nang, int)) or _cache_tag is not None:
+        cache = _ATOM_GRID_CACHE.setdefault((_cache_tag, nr if isinstance(nr, int) else None, nang if isinstance(nang, int) else None,
+                                             radgrid_generator, radgrid_transform, atom_radii, truncate, dtype, str(device)), {})
+    else:  # per-element callables without a name: nothing to key a process-wide cache on
+        cache = {}
     pos = atompos.to(dtype=dtype, device=device)
     rgrids, dvols = [], []
     for z, p in zip(zlist, pos):
@@ -303,5 +321,6 @@ def get_predefined_grid(grid_inp, atomzs, atompos, *, dtype=torch.float64, devic
         nrl, nal = _NR[grid_inp], _NANG[grid_inp]
         return get_grid(atomzs, atompos, nr=lambda z: nrl[get_period(z) - 1], nang=lambda z: nal[get_period(z) - 1],
                         radgrid_generator="chebyshev2", radgrid_transform="treutlerm4", atom_radii="bragg",
-                        multiatoms_scheme="treutler", truncate="nwchem", dtype=dtype, device=device)
+                        multiatoms_scheme="treutler", truncate="nwchem", dtype=dtype, device=device,
+                        _cache_tag=("level", grid_inp))
     raise TypeError("Unknown type of grid_inp: %s" % type(grid_inp))

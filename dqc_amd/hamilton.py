@@ -33,6 +33,17 @@ except Exception:  # dqc (or one of its dependencies: xitorch, dqclibs) is absen
     _Base = object
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """one side stream per device for setup work that overlaps the main stream (ERI tile fill)"""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class HamiltonMI355(_Base):
     def __init__(self, atombases: List[AtomCGTOBasis], spherical: bool = True, df=None, efield=None,
                  vext: Optional[torch.Tensor] = None, cache=None, orthozer: bool = True,
@@ -64,14 +75,11 @@ class HamiltonMI355(_Base):
         self._nao_ao = self._tab.nao
         self._ld = lib.padded_nao(self._nao_ao)
 
-        ovlp = lib.int1e("ovlp", self._tab, self.device)
-        self._ovlp_ao = ovlp
-        if orthozer:
-            ev, evec = torch.linalg.eigh(ovlp)
-            acc = ev > 1e-6  # dqc/hamilton/orbconverter.py:73
-            self._orthozer = evec[:, acc] * ev[acc] ** (-0.5)
-        else:
-            self._orthozer = torch.eye(self._nao_ao, dtype=self.dtype, device=self.device)
+        self._ovlp_ao = lib.int1e("ovlp", self._tab, self.device)
+        # the orthogonaliser (eigh of S: 5 ms of small rocSOLVER kernels with the host waiting) is formed at first use, so that
+        # build() can put the ERI tile fill on a side stream BEFORE it and the two overlap
+        self._X = None
+        self._fill_done = None
         self.orthogonalized = bool(orthozer)  # False: the API's matrices live in the raw AO basis (overlap != 1)
         if df is None:
             self._df = None
@@ -98,6 +106,29 @@ class HamiltonMI355(_Base):
 
     # ------------------------------------------------------------------ properties
     @property
+    def _orthozer(self):
+        """X with X^T S X = 1 (dqc/hamilton/orbconverter.py:67-116: eigh(S), eigenvalues below 1e-6 dropped)"""
+        if self._X is None:
+            if self.orthogonalized:
+                ev, evec = torch.linalg.eigh(self._ovlp_ao)
+                acc = ev > 1e-6  # dqc/hamilton/orbconverter.py:73
+                self._X = evec[:, acc] * ev[acc] ** (-0.5)
+            else:
+                self._X = torch.eye(self._nao_ao, dtype=self.dtype, device=self.device)
+        return self._X
+
+    @property
+    def _tiles(self):
+        """the ERI tile store; a stream that reaches for it while the side-stream fill is still running waits for the fill"""
+        ev = self._fill_done
+        if ev is not None and not torch.cuda.is_current_stream_capturing():  # (a capture's warm-up pass has waited already)
+            if ev.query():
+                self._fill_done = None
+            else:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+        return self._tiles_store
+
+    @property
     def nao(self) -> int:
         return self._orthozer.shape[-1]
 
@@ -118,7 +149,33 @@ class HamiltonMI355(_Base):
 
     # ------------------------------------------------------------------ setups
     def build(self):
+        if self.is_built:  # idempotent: the integrals of a Hamiltonian do not change (a second caller finds them resident)
+            return self
         tab, dev = self._tab, self.device
+        fill_done = None
+        if self._df is None:
+            # exact J/K keeps the 8-fold-unique 8^4 tiles resident: ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, > 288 GB
+            # near nao 740).  Fail with a message instead of an allocator OOM deep inside the fill.
+            need = int(lib.load().dqc_eri_tile_count(tab.nao)) * 4096 * 8
+            free, _total = torch.cuda.mem_get_info(dev)
+            free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)  # blocks cached by the allocator are reusable
+            if need > free:
+                raise lib.DqcAmdError(
+                    "the exact-J/K ERI tile store of this basis needs %.1f GB (nao = %d) but only %.1f GB of device memory "
+                    "are free: use the density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...)) "
+                    "for Kohn-Sham runs of this size" % (need / 1e9, tab.nao, free / 1e9))
+            # the fill (VALU-bound, 18 ms for a 20-atom molecule) runs on a side stream while this stream does the small
+            # latency-bound setup work -- eigh of S, T, V, their conversions; the streams join at the end of build()
+            main = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._tiles_store = lib.eri_tiles(tab, dev)
+                fill_done = torch.cuda.Event()
+                fill_done.record(side)
+            self._tiles_store.record_stream(main)
+            self._fill_done = fill_done  # whoever touches the tiles first waits for it (the `_tiles` property)
+            self._jkwork = lib.jk_workspace(self._nao_ao, dev)
         kin = lib.int1e("kin", tab, dev)
         nuc = lib.int1e("nuc", tab, dev, self._zs)
         self.olp_mat = self._convert2(self._ovlp_ao)
@@ -130,19 +187,7 @@ class HamiltonMI355(_Base):
                 kin = kin + torch.einsum("dab,d->ab", mats, ef.reshape(-1).to(device=dev, dtype=self.dtype)) / fac
         self.kinnucl_mat = self._convert2(kin + nuc)
         self.nucl_mat = self._convert2(nuc)
-        if self._df is None:
-            # exact J/K keeps the 8-fold-unique 8^4 tiles resident: ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, > 288 GB
-            # near nao 740).  Fail with a message instead of an allocator OOM deep inside the fill.
-            need = int(lib.load().dqc_eri_tile_count(tab.nao)) * 4096 * 8
-            free, _total = torch.cuda.mem_get_info(dev)
-            if need > free:
-                raise lib.DqcAmdError(
-                    "the exact-J/K ERI tile store of this basis needs %.1f GB (nao = %d) but only %.1f GB of device memory "
-                    "are free: use the density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...)) "
-                    "for Kohn-Sham runs of this size" % (need / 1e9, tab.nao, free / 1e9))
-            self._tiles = lib.eri_tiles(tab, dev)
-            self._jkwork = lib.jk_workspace(self._nao_ao, dev)
-        else:  # hcgto.py:133-135
+        if self._df is not None:  # hcgto.py:133-135
             self._df.build()
         self.is_built = True
         if self._vext is not None:  # hcgto.py:144-146
@@ -150,10 +195,14 @@ class HamiltonMI355(_Base):
         return self
 
     def setup_grid(self, grid, xc=None) -> None:
+        family = 1 if xc is None else xc.family
+        if family not in (1, 2, 4):
+            raise RuntimeError("unknown xc family %s" % family)
+        if self.is_grid_set and getattr(self, "grid", None) is grid and family == self.xcfamily:
+            self.xc = xc  # same grid, same derivative level: the AO values are already resident
+            return
         self.xc = xc
-        self.xcfamily = 1 if xc is None else xc.family
-        if self.xcfamily not in (1, 2, 4):
-            raise RuntimeError("unknown xc family %s" % self.xcfamily)
+        self.xcfamily = family
         self.grid = grid
         assert grid.coord_type == "cart"
         self.rgrid = grid.get_rgrid().to(self.device)

@@ -57,6 +57,7 @@ def load():
     lib.dqc_int1e_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double, ctypes.c_double] + tab + [c_vp]
     lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
+    lib.dqc_becke_weights.argtypes = [c_dp, c_dp, c_vp, c_dp, c_dp, c_dp, c_int, c_int, ctypes.c_double, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_orth_factor.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_vp]
     lib.dqc_purify_tc2_batched.argtypes = [c_dp, c_dp, c_int, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
@@ -230,6 +231,18 @@ def eri_grad(grad, dcart, kscale, tab, jscale=1.0):
     with _on(grad.device) as st_:
         _check(load().dqc_eri_grad(_ptr(grad), _ptr(dcart), float(jscale), float(kscale), *tab.args(), st_), "dqc_eri_grad")
     return grad
+
+
+def becke_weights(xyz, atom_off, pos, inv_rij, aij, cut):
+    """xyz (ngrid, 3) the atoms' grids concatenated, atom_off (natm + 1,) int32 device tensor -> Becke partition weights (ngrid,)"""
+    ngrid, natm = xyz.shape[0], pos.shape[0]
+    assert atom_off.dtype == torch.int32 and atom_off.is_cuda and atom_off.numel() == natm + 1
+    w = torch.empty(ngrid, dtype=torch.float64, device=xyz.device)
+    with _on(xyz.device) as st_:
+        _check(load().dqc_becke_weights(_ptr(w), _ptr(xyz), ctypes.c_void_p(atom_off.data_ptr()), _ptr(pos.contiguous()),
+                                        _ptr(inv_rij.contiguous()), _ptr(aij.contiguous()), natm, ngrid, float(cut), st_),
+               "dqc_becke_weights")
+    return w
 
 
 def purify_tc2(x_pad, tmp, nocc, iters, tol, state):

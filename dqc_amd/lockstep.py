@@ -116,6 +116,16 @@ class LockstepSCF:
         ferr = (torch.bmm(q, q.transpose(-2, -1)) - p).abs().amax((-2, -1))
         return q, err + ferr
 
+    def occupied_orbitals(self, focks):
+        """orthonormal occupied orbitals (M, n, n_occ) of the stacked Fock matrices -- the `diagonalize` step of hf.py:227-247
+        for the whole batch, eigensolver-free; a matrix whose purification fails (no gap) goes through eigh.  Synchronises."""
+        q, err = self._occupied(focks)
+        bad = (~(err < 1e-9)).nonzero().reshape(-1).tolist()
+        for m in bad:
+            q[m].copy_(self.engines[m].scp2orb(focks[m]))
+            self.eigh_fallbacks += 1
+        return q
+
     def _build(self, q, active, fock, dm, etot, streams):
         """fock[m], dm[m], etot[m] <- Fock build (and total energy) of the orbitals q[m] for the active molecules, dealt to the
         side streams"""

@@ -36,6 +36,8 @@ class _Engine:
         # reference's restricted open-shell treatment; non-uniform occupations take the eigh step (no purification)
         # hf.py:55-57 / ks.py:69-71: the grid is needed by KS always and by HF when the system carries an external
         # potential (vext is integrated on the grid inside build())
+        if not system.requires_grid():
+            self.hamilton.build()  # first: the ERI tile fill runs on a side stream underneath the grid setup that follows
         if is_ks or system.requires_grid():
             system.setup_grid()
             self.hamilton.setup_grid(system.get_grid(), self.xc)

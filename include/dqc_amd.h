@@ -194,6 +194,14 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
 int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, const int *atm, int natm, const int *bas,
                 int nbas, const double *env, int nenv, int sh0, int sh1, int k0, int k1, void *stream);
 
+/* ---- Becke partition weights of the multi-centre grid  (dqc/grid/multiatoms_scheme.py:9-67, becke_grid.py:18-60) ----------
+ * d_xyz (ngrid, 3): the atoms' grids one after the other, atom a owning points [d_atom_off[a], d_atom_off[a + 1]) (natm + 1
+ * ints on the device); d_pos (natm, 3) nuclei; d_inv_rij, d_aij (natm, natm): 1 / |R_i - R_j| (finite on the diagonal) and the
+ * atomic-size adjustment a_ij = clamp(u / (u^2 - 1), +-0.45), u = (rad_j - rad_i) / (rad_j + rad_i); cut: cell functions with
+ * mu >= cut are dropped (the reference's 0.74).  d_w (ngrid) <- P_own / sum_j P_j.  Enqueues only. */
+int dqc_becke_weights(double *d_w, const double *d_xyz, const int *d_atom_off, const double *d_pos,
+                      const double *d_inv_rij, const double *d_aij, int natm, int ngrid, double cut, void *stream);
+
 /* ---- occupied-space projector without an eigensolver  (the `diagonalize` + `ao_orb2dm` step, hf.py:105-113, 227-247) --
  * Trace-correcting purification X <- X^2 | 2X - X^2 (by the sign of tr X - nocc), one fused fp64-MFMA launch per
  * iteration, frozen once max|X^2 - X| < tol; no host decision (hipGraph-capturable).  d_x (ld, ld): X0 = (emax I - F) /
