@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdqc_amd.so")
-SOURCES = ["host.hip", "int1e.hip", "eri.hip", "df.hip", "grad.hip", "jk.hip", "gto.hip", "becke.hip", "grid.hip", "xc.hip", "purify.hip"]
+SOURCES = ["host.hip", "int1e.hip", "eri.hip", "df.hip", "grad.hip", "jk.hip", "gto.hip", "becke.hip", "grid_density.hip", "grid_vxc.hip", "xc.hip", "purify.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -51,19 +51,34 @@ def build(force=False, verbose=False):
     return LIB
 
 
-def build_variant(name, defines):
-    """perf-bisection builds: grid.hip recompiled with -D<define>, linked as libdqc_amd_<name>.so
-    (select with the DQC_AMD_LIB environment variable); never used by tests or bench defaults"""
+GRID_SOURCES = ["grid_density.hip", "grid_vxc.hip"]
+
+
+def build_variant(name, defines, force=False):
+    """variant libraries: the grid sources recompiled with -D<define>, linked as libdqc_amd_<name>.so.  "fused"
+    (-DDQC_WITH_FUSED: the measured-negative fused grid pass, used by its own test only) is part of build_all(); the others are
+    perf-bisection builds selected with the DQC_AMD_LIB environment variable, never used by tests or bench defaults"""
     build()
     hipcc = _hipcc()
-    obj = os.path.join(OBJ, "grid_%s.o" % name)
-    subprocess.check_call([hipcc] + FLAGS + ["-D" + d for d in defines] +
-                          ["-c", os.path.join(CSRC, "grid.hip"), "-o", obj])
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s != "grid.hip"] + [obj]
     out = os.path.join(HERE, "libdqc_amd_%s.so" % name)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))]
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s not in GRID_SOURCES]
+    for src in GRID_SOURCES:
+        obj = os.path.join(OBJ, "%s_%s.o" % (src.replace(".hip", ""), name))
+        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+            subprocess.check_call([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    if force or _stale(out, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 
+def build_all(force=False, verbose=False):
+    """the product library and the fused-pass variant its test loads"""
+    lib = build(force=force, verbose=verbose)
+    build_variant("fused", ["DQC_WITH_FUSED"], force=force)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build_all(force="--force" in sys.argv, verbose=True))

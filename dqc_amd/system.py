@@ -75,7 +75,9 @@ class Mol:
         if efield is not None:
             for i, ef in enumerate(efield):
                 assert ef.numel() == 3 ** (i + 1), "The %d-th tuple element of efield must have %d elements" % (i, 3 ** (i + 1))
-            efield = tuple(ef.reshape(-1) for ef in efield)
+            # no autograd path runs through the field here (the properties are Hellmann-Feynman expectation values): a
+            # requires_grad leaf, as the reference's fixtures pass, is detached
+            efield = tuple(ef.detach().reshape(-1) for ef in efield)
         self._efield, self._vext = efield, vext
         self._orthogonalize_basis, self._aoparamzer = orthogonalize_basis, ao_parameterizer
         self._hamilton = HamiltonMI355(self._atombases, spherical=True, efield=efield, vext=vext,

@@ -95,16 +95,6 @@ int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, co
 int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid,
                      int nao, const double *d_dm, void *stream);
 
-/* ---- fused grid pass: density -> XC potentials -> Vxc matrix from ONE read of the AO matrix ------
- * = dqc_grid_density_lr + dqc_xc_eval + dqc_grid_vxc (HamiltonCGTO.get_vxc, hcgto.py:260-269 with 371-495) for a
- * restricted density given in factor form D = L L^T (d_orb (ld, norb_pad), d_orbt (norb_pad, ld) as for
- * dqc_grid_density_lr), d_ao (4, ngrid, ld), LDA / GGA functional ids.  Covered shapes: dqc_grid_fused_supported(nao,
- * norb_pad) != 0 (ld / 16 in {11, 13}, i.e. 145 <= nao <= 208 except 177..192, norb_pad <= 64); otherwise DQC_EINVAL.
- * Optional outputs (may be NULL): d_rho (ngrid), d_grho (3, ngrid), d_exc (1) = sum_g w_g e_xc(g). */
-int dqc_grid_fused_supported(int nao, int norb_pad);
-int dqc_grid_fused(double *d_vmat, double *d_rho, double *d_grho, double *d_exc, const double *d_ao, int ngrid, int nao,
-                   const double *d_w, const double *d_orb, const double *d_orbt, int norb_pad, const int *ids,
-                   const double *coefs, int nterm, void *stream);
 
 /* ---- exchange-correlation functional  (pylibxc LibXCFunctional.compute, unpolarised) --------
  * Replaces dqc/xc/libxc.py:40-85 + libxc_wrapper.py:380-413 for sums of libxc functionals
