@@ -80,6 +80,57 @@ DQC_DEV D5 sqrt5(D5 a) { const double f = sqrt(a.v); return chain(a, f, 0.5 / f)
 DQC_DEV D5 log1p5(D5 a) { return chain(a, log1p(a.v), 1.0 / (1.0 + a.v)); }
 DQC_DEV D5 expm15(D5 a) { return chain(a, expm1(a.v), exp(a.v)); }
 
+DQC_DEV D5 log5(D5 a) { return chain(a, log(a.v), 1.0 / a.v); }
+DQC_DEV D5 atan5(D5 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
+DQC_DEV D5 exp5(D5 a) { const double e = exp(a.v); return chain(a, e, e); }
+DQC_DEV D5 xasinhx5(D5 y) { double dg; const double v = xasinhx_val(y.v, dg); return chain(y, v, dg); }
+DQC_DEV D5 operator*(D5 a, double b) { return b * a; }
+DQC_DEV D5 operator+(D5 a, double b) { return b + a; }
+DQC_DEV D5 operator-(D5 a, double b) { a.v -= b; return a; }
+DQC_DEV D5 operator/(D5 a, double b) { return (1.0 / b) * a; }
+
+// lda_c_vwn (VWN5), spin-polarised: eps = eps_P + alpha_c f(zeta) (1 - zeta^4) / f''(0) + (eps_F - eps_P) f(zeta) zeta^4
+DQC_DEV D5 vwn_pol_eps(D5 rho, D5 zeta) {
+    const double fz20 = 1.709920934161365617563962776245, Aalpha = -1.0 / (6.0 * kPi * kPi);
+    D5 x = sqrt5(cbrt5((3.0 / (4.0 * kPi)) / rho));
+    auto lg = [](D5 a) { return log5(a); };
+    auto at = [](D5 a) { return atan5(a); };
+    D5 eP = vwn_fit(x, 0.0310907, 3.72744, 12.9352, -0.10498, lg, at);
+    D5 eF = vwn_fit(x, 0.01554535, 7.06042, 18.0578, -0.32500, lg, at);
+    D5 aC = vwn_fit(x, Aalpha, 1.13107, 13.0045, -0.0047584, lg, at);
+    D5 fz = (p5(1.0 + zeta, 4.0 / 3.0) + p5(1.0 - zeta, 4.0 / 3.0) - c5(2.0)) / c5(0.51984209978974632953);
+    D5 z2 = zeta * zeta, z4 = z2 * z2;
+    return eP + aC * fz * (c5(1.0) - z4) / c5(fz20) + (eF - eP) * fz * z4;
+}
+
+// one spin channel of gga_x_b88: -rho_s^(4/3) [Cx + beta x^2 / (1 + 6 beta x asinh x)]
+DQC_DEV D5 b88_spin5(D5 rs_, D5 sss) {
+    const double beta = 0.0042, cx = 0.9305257363491;
+    D5 r43 = rs_ * cbrt5(rs_);
+    D5 y = sss / (r43 * r43);
+    return c5(0.0) - r43 * (cx + beta * y / (1.0 + (6.0 * beta) * xasinhx5(y)));
+}
+
+// gga_c_lyp, general spin form (Miehlich, Savin, Stoll, Preuss, CPL 157, 200 (1989), eq. 2)
+DQC_DEV D5 lyp_pol5(D5 ra, D5 rb, D5 saa, D5 sab, D5 sbb) {
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349, CF = 2.8712340001881915;
+    D5 rho = ra + rb;
+    D5 ir13 = 1.0 / cbrt5(rho);
+    D5 den = 1.0 + d * ir13;
+    D5 delta = c * ir13 + d * ir13 / den;
+    D5 r2 = rho * rho;
+    D5 r113 = r2 * rho / (ir13 * ir13);
+    D5 omega = exp5(c5(0.0) - c * ir13) / (den * r113);
+    D5 sig = saa + 2.0 * sab + sbb;
+    D5 ra83 = ra * ra * cbrt5(ra) * cbrt5(ra), rb83 = rb * rb * cbrt5(rb) * cbrt5(rb);
+    D5 t1 = (12.699208415745595 * CF) * (ra83 + rb83);  // 2^(11/3) C_F (ra^(8/3) + rb^(8/3))
+    D5 t2 = ((47.0 / 18.0) - (7.0 / 18.0) * delta) * sig;
+    D5 t3 = ((5.0 / 2.0) - (1.0 / 18.0) * delta) * (saa + sbb);
+    D5 t4 = ((delta - 11.0) / 9.0) * ((ra / rho) * saa + (rb / rho) * sbb);
+    D5 br = ra * rb * (t1 + t2 - t3 - t4) - (2.0 / 3.0) * r2 * sig + ((2.0 / 3.0) * r2 - ra * ra) * sbb + ((2.0 / 3.0) * r2 - rb * rb) * saa;
+    return c5(0.0) - (4.0 * a) * (ra * rb / (rho * den)) - (a * b) * (omega * br);
+}
+
 DQC_DEV D5 pw92_pol_eps(D5 rho, D5 zeta, const double *a3) {
     const double alpha1[3] = {0.21370, 0.20548, 0.11125}, b1[3] = {7.5957, 14.1189, 10.357},
                  b2[3] = {3.5876, 6.1977, 3.6231}, b3[3] = {1.6382, 3.3662, 0.88026}, b4[3] = {0.49294, 0.62517, 0.49671};
@@ -138,6 +189,9 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                 case DQC_XC_GGA_X_PBE:
                     f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu) + pbe_x_unpol5(2.0 * d, 4.0 * sdd));
                     break;
+                case DQC_XC_LDA_C_VWN: f = rho * vwn_pol_eps(rho, zeta); break;
+                case DQC_XC_GGA_X_B88: f = b88_spin5(u, suu) + b88_spin5(d, sdd); break;
+                case DQC_XC_GGA_C_LYP: f = lyp_pol5(u, d, suu, sud, sdd); break;
                 default: {
                     const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
                     const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
@@ -184,11 +238,8 @@ extern "C" int dqc_xc_eval_quad(double *d_exc, double *d_edens, double *d_vrho, 
     for (int i = 0; i < nterm; i++) {
         t.id[i] = ids[i];
         t.c[i] = coefs[i];
-        switch (ids[i]) {
-        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: break;
-        case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: need_grad = true; break;
-        default: set_error("dqc_xc_eval: unknown functional id"); return DQC_EINVAL;
-        }
+        if (xc_host_is_gga(ids[i])) need_grad = true;
+        else if (!xc_host_is_lda(ids[i])) { set_error("dqc_xc_eval: unknown functional id"); return DQC_EINVAL; }
     }
     if (need_grad && !d_grho) { set_error("dqc_xc_eval: GGA functional needs the density gradient"); return DQC_EINVAL; }
     if (n <= 0) {
@@ -221,10 +272,6 @@ DQC_DEV D5 exp5c(D5 a) {  // exp with the argument clipped at 50 (only active in
     const double f = exp(a.v);
     return chain(a, f, f);
 }
-DQC_DEV D5 operator*(D5 a, double b) { return b * a; }
-DQC_DEV D5 operator/(D5 a, double b) { return (1.0 / b) * a; }
-DQC_DEV D5 operator+(D5 a, double b) { a.v += b; return a; }
-DQC_DEV D5 operator-(D5 a, double b) { a.v -= b; return a; }
 
 // SCAN exchange, unpolarised: slots 0 = rho, 1 = sigma, 2 = tau  (closed form of dqc/test/test_xc.py:427-455)
 DQC_DEV D5 f_mgga_x_scan(D5 r, D5 sg, D5 ta) {
@@ -382,13 +429,7 @@ __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens
                                                                    : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
                     fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
                 } else {
-                    Dual f;
-                    switch (terms.id[t]) {
-                    case DQC_XC_LDA_X: f = f_lda_x(dr); break;
-                    case DQC_XC_LDA_C_PW: f = f_lda_c_pw(dr); break;
-                    case DQC_XC_GGA_X_PBE: f = f_gga_x_pbe(dr, ds); break;
-                    default: f = f_gga_c_pbe(dr, ds); break;
-                    }
+                    const Dual f = f_lda_gga(terms.id[t], dr, ds);
                     fv = f.v; fr = f.r; fs = f.s;
                 }
                 e += terms.c[t] * fv; vr += terms.c[t] * fr; vs += terms.c[t] * fs; vt += terms.c[t] * ft;
@@ -418,10 +459,9 @@ extern "C" int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad
     for (int i = 0; i < nterm; i++) {
         t.id[i] = ids[i];
         t.c[i] = coefs[i];
-        switch (ids[i]) {
-        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: case DQC_XC_MGGA_X_SCAN:
-        case DQC_XC_MGGA_C_SCAN: break;
-        default: set_error("dqc_xc_eval_mgga: unknown functional id"); return DQC_EINVAL;
+        if (!(xc_host_is_lda(ids[i]) || xc_host_is_gga(ids[i]) || ids[i] == DQC_XC_MGGA_X_SCAN || ids[i] == DQC_XC_MGGA_C_SCAN)) {
+            set_error("dqc_xc_eval_mgga: unknown functional id");
+            return DQC_EINVAL;
         }
     }
     if (n <= 0) return DQC_OK;
@@ -445,11 +485,8 @@ extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho
     for (int i = 0; i < nterm; i++) {
         t.id[i] = ids[i];
         t.c[i] = coefs[i];
-        switch (ids[i]) {
-        case DQC_XC_LDA_X: case DQC_XC_LDA_C_PW: break;
-        case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_C_PBE: need_grad = true; break;
-        default: set_error("dqc_xc_eval_pol: unknown functional id"); return DQC_EINVAL;
-        }
+        if (xc_host_is_gga(ids[i])) need_grad = true;
+        else if (!xc_host_is_lda(ids[i])) { set_error("dqc_xc_eval_pol: unknown functional id"); return DQC_EINVAL; }
     }
     const bool gga = d_grho_u && d_grho_d;
     if (need_grad && !gga) { set_error("dqc_xc_eval_pol: GGA functional needs both density gradients"); return DQC_EINVAL; }

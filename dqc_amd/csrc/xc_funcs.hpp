@@ -30,6 +30,18 @@ DQC_DEV Dual dexpm1(Dual a) { double e = exp(a.v); return {expm1(a.v), a.r * e, 
 DQC_DEV Dual dsqrt(Dual a) { double q = sqrt(a.v), d = 0.5 / q; return {q, a.r * d, a.s * d}; }
 DQC_DEV Dual dcbrt(Dual a) { double q = cbrt(a.v), d = q / (3.0 * a.v); return {q, a.r * d, a.s * d}; }
 
+DQC_DEV Dual dlog(Dual a) { double d = 1.0 / a.v; return {log(a.v), a.r * d, a.s * d}; }
+DQC_DEV Dual datan(Dual a) { double d = 1.0 / (1.0 + a.v * a.v); return {atan(a.v), a.r * d, a.s * d}; }
+DQC_DEV Dual dexp(Dual a) { double e = exp(a.v); return {e, a.r * e, a.s * e}; }
+// g(y) = x asinh(x), x = sqrt(y): smooth in y = x^2 (the reduced gradient enters B88 only through it), g'(y) = (asinh(x)/x + 1/sqrt(1+y))/2
+DQC_DEV double xasinhx_val(double y, double &dg) {
+    const double x = sqrt(y);
+    const double ax = x > 1e-4 ? asinh(x) / x : 1.0 - y / 6.0 + 3.0 * y * y / 40.0;
+    dg = 0.5 * (ax + 1.0 / sqrt(1.0 + y));
+    return y * ax;
+}
+DQC_DEV Dual dxasinhx(Dual y) { double dg; const double v = xasinhx_val(y.v, dg); return {v, y.r * dg, y.s * dg}; }
+
 constexpr double kPi = 3.14159265358979323846;
 
 DQC_DEV Dual f_lda_x(Dual rho) {
@@ -73,6 +85,66 @@ DQC_DEV Dual f_gga_c_pbe(Dual rho, Dual sigma) {
     return rho * (eps + H);
 }
 
+// VWN5 correlation energy per particle of one spin channel fit (Vosko, Wilk, Nusair, Can. J. Phys. 58, 1200 (1980), eq. 4.4), x = sqrt(rs)
+template <class T, class FL, class FA>
+DQC_DEV T vwn_fit(T x, double A, double b, double c, double x0, FL flog, FA fatan) {
+    const double Q = sqrt(4.0 * c - b * b), X0 = x0 * x0 + b * x0 + c;
+    T X = x * x + b * x + c;
+    T at = fatan(Q / (2.0 * x + b));
+    T xm = x - x0;
+    return A * (flog(x * x / X) + (2.0 * b / Q) * at - (b * x0 / X0) * (flog(xm * xm / X) + (2.0 * (b + 2.0 * x0) / Q) * at));
+}
+
+// lda_c_vwn (libxc id 7 = VWN5), unpolarised: the paramagnetic fit
+DQC_DEV Dual f_lda_c_vwn(Dual rho) {
+    Dual x = dsqrt(dcbrt(mk(3.0 / (4.0 * kPi)) / rho));
+    return rho * vwn_fit(x, 0.0310907, 3.72744, 12.9352, -0.10498, [](Dual a) { return dlog(a); }, [](Dual a) { return datan(a); });
+}
+
+// gga_x_b88 (Becke, PRA 38, 3098 (1988)): e = sum_s -rho_s^(4/3) [Cx + beta x_s^2 / (1 + 6 beta x_s asinh x_s)], x_s = |grad rho_s| / rho_s^(4/3);
+// unpolarised: rho_s = rho / 2, sigma_ss = sigma / 4
+DQC_DEV Dual f_gga_x_b88(Dual rho, Dual sigma) {
+    const double beta = 0.0042, cx = 0.9305257363491;  // (3/2) (3 / (4 pi))^(1/3)
+    Dual rs_ = 0.5 * rho;
+    Dual r43 = rs_ * dcbrt(rs_);
+    Dual y = (0.25 * sigma) / (r43 * r43);  // x_s^2
+    return -2.0 * (r43 * (cx + beta * y / (1.0 + (6.0 * beta) * dxasinhx(y))));
+}
+
+// gga_c_lyp (Lee, Yang, Parr, PRB 37, 785 (1988) in the gradient-only form of Miehlich et al., CPL 157, 200 (1989)), closed shell:
+//   e = -a rho / (1 + d rho^(-1/3)) - a b omega [ C_F rho^(14/3) - rho^2 sigma (1/24 + 7 delta / 72) ]
+//   omega = exp(-c rho^(-1/3)) / (1 + d rho^(-1/3)) rho^(-11/3),  delta = c rho^(-1/3) + d rho^(-1/3) / (1 + d rho^(-1/3))
+DQC_DEV Dual f_gga_c_lyp(Dual rho, Dual sigma) {
+    const double a = 0.04918, b = 0.132, c = 0.2533, d = 0.349, CF = 2.8712340001881915;  // (3/10) (3 pi^2)^(2/3)
+    Dual r13 = dcbrt(rho);
+    Dual ir13 = 1.0 / r13;
+    Dual den = 1.0 + d * ir13;
+    Dual delta = c * ir13 + d * ir13 / den;
+    Dual r2 = rho * rho;
+    Dual r113 = r2 * rho * r13 * r13;                 // rho^(11/3)
+    Dual omega = dexp(mk(0.0) - c * ir13) / (den * r113);
+    Dual bracket = CF * (r113 * rho) - r2 * sigma * ((1.0 / 24.0) + (7.0 / 72.0) * delta);
+    return mk(0.0) - a * (rho / den) - (a * b) * (omega * bracket);
+}
+
+DQC_DEV bool xc_id_is_lda(int id) { return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_VWN; }
+DQC_DEV bool xc_id_is_gga(int id) { return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP; }
+inline bool xc_host_is_lda(int id) { return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_VWN; }
+inline bool xc_host_is_gga(int id) { return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP; }
+
+// one LDA / GGA functional of the kernel set at (rho, sigma) with its first derivatives
+DQC_DEV Dual f_lda_gga(int id, Dual dr, Dual ds) {
+    switch (id) {
+    case DQC_XC_LDA_X: return f_lda_x(dr);
+    case DQC_XC_LDA_C_PW: return f_lda_c_pw(dr);
+    case DQC_XC_LDA_C_VWN: return f_lda_c_vwn(dr);
+    case DQC_XC_GGA_X_PBE: return f_gga_x_pbe(dr, ds);
+    case DQC_XC_GGA_X_B88: return f_gga_x_b88(dr, ds);
+    case DQC_XC_GGA_C_LYP: return f_gga_c_lyp(dr, ds);
+    default: return f_gga_c_pbe(dr, ds);
+    }
+}
+
 struct XcTerms {
     int n;
     int id[8];
@@ -85,13 +157,7 @@ DQC_DEV void xc_point(const XcTerms &terms, double r, double sigma, double &e, d
     if (r > 1e-15) {
         const Dual dr = mk(r, 1.0, 0.0), ds = mk(sigma, 0.0, 1.0);
         for (int t = 0; t < terms.n; t++) {
-            Dual f;
-            switch (terms.id[t]) {
-            case DQC_XC_LDA_X: f = f_lda_x(dr); break;
-            case DQC_XC_LDA_C_PW: f = f_lda_c_pw(dr); break;
-            case DQC_XC_GGA_X_PBE: f = f_gga_x_pbe(dr, ds); break;
-            default: f = f_gga_c_pbe(dr, ds); break;
-            }
+            const Dual f = f_lda_gga(terms.id[t], dr, ds);
             e += terms.c[t] * f.v;
             vr += terms.c[t] * f.r;
             vs += terms.c[t] * f.s;

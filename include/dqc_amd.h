@@ -102,9 +102,12 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
  * HOST array of nterm weights.  Outputs (any may be NULL): d_edens (n) energy per unit volume
  * (= zk*rho), d_vrho (n), d_vgrad (3,n) = 2*vsigma*grad rho  (libxc.py:239). */
 #define DQC_XC_LDA_X 1
+#define DQC_XC_LDA_C_VWN 7   /* VWN5 */
 #define DQC_XC_LDA_C_PW 12
 #define DQC_XC_GGA_X_PBE 101
+#define DQC_XC_GGA_X_B88 106
 #define DQC_XC_GGA_C_PBE 130
+#define DQC_XC_GGA_C_LYP 131
 #define DQC_XC_MGGA_X_SCAN 263
 #define DQC_XC_MGGA_C_SCAN 267
 int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,

@@ -540,3 +540,130 @@ def get_xc(xcstr):  # noqa: F811  (extends the parser above with the meta-GGA na
             terms.append((float(m.group(1)) if m.group(1) else 1.0, m.group(2)))
         return XCM(terms)
     return _get_xc_plain(xcstr)
+
+
+# =====================================================================================================
+# Round 3: lda_c_vwn (VWN5, libxc id 7), gga_x_b88 (106), gga_c_lyp (131).  The reference reaches them through pylibxc
+# (dqc/api/getxc.py:12-36 accepts any libxc name); it holds no formula for them -- PARITY against an executed libxc is
+# UNPINNED, like gga_c_pbe.  Pins used instead (tests/test_oracle_cpu.py): VWN5 against PW92 (two fits of the same quantum
+# Monte-Carlo data: |difference| < 6e-4 Ha for 0.5 <= rs <= 20, zeta = 0 and 1); B88 on the exact hydrogen-atom density
+# (Becke, PRA 38, 3098, table I: 0.3098 Ha); LYP vanishing on every one-spin density; central differences of every derivative.
+#   VWN : Vosko, Wilk, Nusair, Can. J. Phys. 58, 1200 (1980), eq. 4.4, parameters of the "VWN5" fits (paramagnetic,
+#         ferromagnetic, spin stiffness), interpolation eps_P + alpha_c f (1 - z^4) / f''(0) + (eps_F - eps_P) f z^4
+#   B88 : hand-derived derivatives per spin channel, e_s = -rho_s^(4/3) [Cx + beta y / (1 + 6 beta x asinh x)], y = x^2
+#   LYP : general spin form of Miehlich, Savin, Stoll, Preuss, CPL 157, 200 (1989) eq. 2 on dual arrays; the unpolarised
+#         entry point evaluates it at rho_a = rho_b (the product's closed-shell kernel uses a separately simplified form)
+# =====================================================================================================
+_VWN = {"A": (0.0310907, 0.01554535, -1.0 / (6.0 * np.pi ** 2)), "b": (3.72744, 7.06042, 1.13107),
+        "c": (12.9352, 18.0578, 13.0045), "x0": (-0.10498, -0.32500, -0.0047584)}
+
+
+def _vwn_fit(x, k):
+    """eps(x = sqrt(rs)) and d eps / d x of fit k (0 paramagnetic, 1 ferromagnetic, 2 spin stiffness); plain arrays"""
+    A, b, c, x0 = (_VWN[n][k] for n in ("A", "b", "c", "x0"))
+    Q = np.sqrt(4.0 * c - b * b)
+    X, X0 = x * x + b * x + c, x0 * x0 + b * x0 + c
+    at = np.arctan(Q / (2.0 * x + b))
+    eps = A * (np.log(x * x / X) + 2.0 * b / Q * at
+               - b * x0 / X0 * (np.log((x - x0) ** 2 / X) + 2.0 * (b + 2.0 * x0) / Q * at))
+    dat = -2.0 * Q / ((2.0 * x + b) ** 2 + Q * Q)  # d atan(Q / (2x + b)) / dx
+    deps = A * (2.0 / x - (2.0 * x + b) / X + 2.0 * b / Q * dat
+                - b * x0 / X0 * (2.0 / (x - x0) - (2.0 * x + b) / X + 2.0 * (b + 2.0 * x0) / Q * dat))
+    return eps, deps
+
+
+def lda_c_vwn(rho, sigma=None):
+    mask, r = _safe(rho)
+    rs = (3.0 / (4.0 * np.pi * r)) ** (1.0 / 3)
+    x = np.sqrt(rs)
+    eps, deps_dx = _vwn_fit(x, 0)
+    # v = eps + rho d eps / d rho,  d rs / d rho = -rs / (3 rho),  d x / d rs = 1 / (2 x)
+    v = eps - rs / 3.0 * deps_dx / (2.0 * x)
+    z = np.zeros_like(rho)
+    return np.where(mask, r * eps, 0.0), np.where(mask, v, 0.0), z
+
+
+_B88_BETA, _B88_CX = 0.0042, 1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3)
+
+
+def _b88_spin(rs_, sss):
+    """one spin channel: e_s, d e_s / d rho_s, d e_s / d sigma_ss (hand-derived)"""
+    r43 = rs_ ** (4.0 / 3)
+    y = sss / (r43 * r43)
+    x = np.sqrt(y)
+    small = x < 1e-4
+    xs = np.where(small, 1.0, x)
+    ax = np.where(small, 1.0 - y / 6.0, np.arcsinh(xs) / xs)  # asinh(x) / x
+    g = y * ax                                                 # x asinh x
+    dg = 0.5 * (ax + 1.0 / np.sqrt(1.0 + y))                   # d g / d y
+    den = 1.0 + 6.0 * _B88_BETA * g
+    h = _B88_BETA * y / den
+    dh = _B88_BETA * (den - 6.0 * _B88_BETA * y * dg) / (den * den)
+    e = -r43 * (_B88_CX + h)
+    de_dr = -(4.0 / 3) * rs_ ** (1.0 / 3) * (_B88_CX + h) - r43 * dh * (-(8.0 / 3) * y / rs_)
+    de_ds = -dh / r43
+    return e, de_dr, de_ds
+
+
+def gga_x_b88(rho, sigma):
+    mask, r = _safe(rho)
+    e, dr, ds = _b88_spin(0.5 * r, 0.25 * sigma)
+    return np.where(mask, 2.0 * e, 0.0), np.where(mask, dr, 0.0), np.where(mask, 0.5 * ds, 0.0)
+
+
+_LYP = (0.04918, 0.132, 0.2533, 0.349)
+
+
+def _lyp_dual(ra, rb, saa, sab, sbb):
+    a, b, c, d = _LYP
+    CF = 0.3 * (3.0 * np.pi ** 2) ** (2.0 / 3)
+    rho = ra + rb
+    ir13 = rho.pow(-1.0 / 3)
+    den = 1.0 + d * ir13
+    delta = c * ir13 + d * ir13 / den
+    omega = (-(c * ir13)).fn(np.exp, np.exp) / den * rho.pow(-11.0 / 3)
+    sig = saa + 2.0 * sab + sbb
+    br = ra * rb * (2.0 ** (11.0 / 3) * CF * (ra.pow(8.0 / 3) + rb.pow(8.0 / 3))
+                    + (47.0 / 18 - 7.0 / 18 * delta) * sig
+                    - (2.5 - delta / 18.0) * (saa + sbb)
+                    - (delta - 11.0) / 9.0 * (ra / rho * saa + rb / rho * sbb))
+    br = br - (2.0 / 3) * rho * rho * sig + ((2.0 / 3) * rho * rho - ra * ra) * sbb + ((2.0 / 3) * rho * rho - rb * rb) * saa
+    return -4.0 * a / den * ra * rb / rho - a * b * omega * br
+
+
+def gga_c_lyp_pol(ru, rd, suu, sud, sdd):
+    mask, ru_, rd_ = _masked(ru, rd)
+    u, d, suu_, sud_, sdd_ = _pol_inputs(ru_, rd_, suu, sud, sdd)
+    return _finish(_lyp_dual(u, d, suu_, sud_, sdd_), mask)
+
+
+def gga_c_lyp(rho, sigma):
+    """closed shell = the spin form at rho_a = rho_b = rho / 2, sigma_aa = sigma_ab = sigma_bb = sigma / 4 (chain rule)"""
+    h, q = 0.5 * np.asarray(rho, float), 0.25 * np.asarray(sigma, float)
+    e, (vu, vd), (saa, sab, sbb) = gga_c_lyp_pol(h, h, q, q, q)
+    return e, 0.5 * (vu + vd), 0.25 * (saa + sab + sbb)
+
+
+def lda_c_vwn_pol(ru, rd, suu=None, sud=None, sdd=None):
+    mask, ru_, rd_ = _masked(ru, rd)
+    z0 = np.zeros_like(ru_)
+    u, d, _, _, _ = _pol_inputs(ru_, rd_, z0, z0, z0)
+    rho, zeta = _safe_zeta(u, d)
+    x = ((3.0 / (4.0 * np.pi)) / rho).pow(1.0 / 6)
+    fit = [x.fn(lambda t, k=k: _vwn_fit(t, k)[0], lambda t, k=k: _vwn_fit(t, k)[1]) for k in range(3)]
+    fz = ((1.0 + zeta).pow(4.0 / 3) + (1.0 - zeta).pow(4.0 / 3) - 2.0) / (2.0 ** (4.0 / 3) - 2.0)
+    z4 = (zeta * zeta) * (zeta * zeta)
+    eps = fit[0] + fit[2] * fz * (1.0 - z4) / _FZ20 + (fit[1] - fit[0]) * fz * z4
+    return _finish(rho * eps, mask)
+
+
+def gga_x_b88_pol(ru, rd, suu, sud, sdd):
+    mask, ru_, rd_ = _masked(ru, rd)
+    eu, du, su = _b88_spin(ru_, np.asarray(suu, float))
+    ed, dd, sd = _b88_spin(rd_, np.asarray(sdd, float))
+    z = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+    return z(eu + ed), (z(du), z(dd)), (z(su), np.zeros_like(ru_), z(sd))
+
+
+_FUNCS.update({"lda_c_vwn": (1, lda_c_vwn), "gga_x_b88": (2, gga_x_b88), "gga_c_lyp": (2, gga_c_lyp)})
+_FUNCS_POL.update({"lda_c_vwn": lda_c_vwn_pol, "gga_x_b88": gga_x_b88_pol, "gga_c_lyp": gga_c_lyp_pol})

@@ -108,7 +108,7 @@ def test_xc_closed_forms():
     assert np.allclose(oxc.gga_x_pbe(rho, sig)[0], -0.75 * (3 / np.pi) ** (1 / 3) * rho ** (4 / 3) * fx, rtol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe"])
+@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp"])
 def test_xc_derivatives_finite_difference(name):
     rng = np.random.default_rng(1)
     rho = rng.uniform(0.05, 1.5, 50)
@@ -121,6 +121,35 @@ def test_xc_derivatives_finite_difference(name):
     if oxc._FUNCS[name][0] == 2:
         ds = (f(rho, sig + h)[0] - f(rho, sig - h)[0]) / (2 * h)
         assert np.allclose(vs, ds, rtol=1e-6, atol=1e-9)
+
+
+def test_vwn_b88_lyp_external_pins():
+    """the functionals the reference reaches through pylibxc without holding a formula (getxc.py:12-36), pinned by what is known
+    about them from outside: VWN5 and PW92 are two fits of the same Ceperley-Alder data; Becke's 1988 paper lists the B88
+    exchange energy of the exact hydrogen atom (table I: 0.3098 Ha; LSDA 0.2680); LYP vanishes on any one-spin density and
+    gives about -0.044 Ha for a helium-like 1s^2 density (LYP paper, He: -0.0437 on the Hartree-Fock density)"""
+    rs = np.array([0.5, 1.0, 2.0, 5.0, 10.0, 20.0])
+    rho = 3.0 / (4.0 * np.pi * rs ** 3)
+    assert np.abs(oxc.lda_c_vwn(rho)[0] - oxc.lda_c_pw(rho)[0]).max() / rho.max() < 6e-4
+    assert np.abs((oxc.lda_c_vwn(rho)[0] - oxc.lda_c_pw(rho)[0]) / rho).max() < 6e-4
+    assert abs(oxc.lda_c_vwn(rho[1:2])[0][0] / rho[1] + 0.0600) < 1e-4  # eps_c(rs = 1) of the paramagnetic gas
+    tiny = 1e-12
+    fv = oxc.lda_c_vwn_pol(rho * (1 - tiny), rho * tiny)[0] / rho
+    fp = oxc.lda_c_pw_pol(rho * (1 - tiny), rho * tiny)[0] / rho
+    assert np.abs(fv - fp).max() < 2e-4  # ferromagnetic gas
+    x, w = np.polynomial.legendre.leggauss(400)
+    r, w = 0.5 * (x + 1) * 40.0, 0.5 * 40.0 * w
+    quad = lambda e: float((4 * np.pi * r * r * e * w).sum())  # noqa: E731
+    ra = np.exp(-2 * r) / np.pi  # hydrogen atom, one spin
+    saa, z = 4 * ra * ra, np.zeros_like(ra)
+    assert abs(quad(oxc.gga_x_b88_pol(ra, z, saa, z, z)[0]) + 0.3098) < 2e-4
+    assert abs(quad(oxc.lda_x_pol(ra, z)[0]) + 0.2680) < 1e-4
+    assert np.abs(oxc.gga_c_lyp_pol(ra, z, saa, z, z)[0]).max() < 1e-14
+    zeta = 27.0 / 16.0  # helium-like closed shell
+    rho2 = 2 * zeta ** 3 / np.pi * np.exp(-2 * zeta * r)
+    sig = (2 * zeta * rho2) ** 2
+    assert abs(quad(oxc.gga_c_lyp(rho2, sig)[0]) + 0.0437) < 1e-3
+    assert -1.06 < quad(oxc.gga_x_b88(rho2, sig)[0]) < -1.03  # exact exchange of this density: -5 zeta / 8 = -1.0547
 
 
 def test_overlap_normalisation_all_l():
@@ -240,7 +269,7 @@ def test_cart2sph_tables_agree(golden_dir):
 # ------------------------------------------------------------------------------------------------
 # spin-polarised path: functionals, UHF / UKS engines
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe"])
+@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp"])
 def test_polarised_xc_derivatives_and_unpolarised_limit(name):
     rng = np.random.default_rng(0)
     n = 40
