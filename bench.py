@@ -301,6 +301,28 @@ def main():
             torch.cuda.synchronize()
             out_extra["jk_multi_j_only_ms"] = e0.elapsed_time(e1) / K
             out_extra["eri_fill"] = eri_fill_stats(h0, dev)
+        # deterministic mode (fixed-point integer atomics instead of fp64 atomics in the cross-block sums): cost and proof
+        def _rate(k):
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(k):
+                engines[0].dm2scp(engines[0].hamilton.ao_orb2dm(orbs[0], engines[0].orb_weight))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / k
+        _rate(3)
+        t_at = _rate(20)
+        lib.set_deterministic(True)
+        _rate(3)
+        t_det = _rate(20)
+        fdet = [engines[0].dm2scp(dms[0].clone()) for _ in range(3)]
+        lib.set_deterministic(False)
+        fat = engines[0].dm2scp(dms[0].clone())
+        out_extra["deterministic_mode"] = {"fock_build_ms_fp64_atomics": 1e3 * t_at, "fock_build_ms_deterministic": 1e3 * t_det,
+                                           "cost_percent": 100.0 * (t_det / t_at - 1.0),
+                                           "repeated_builds_bit_identical": bool(all(torch.equal(f, fdet[0]) for f in fdet[1:])),
+                                           "max_abs_fock_diff_vs_fp64_atomics": float((fdet[0] - fat).abs().max()),
+                                           "note": "dqc_set_deterministic(1): J accumulators, split-K Vxc and the purification trace summed as "
+                                                   "fixed-point 64-bit integers (associative); one molecule, one stream"}
         # SURVEY.md 8(d) metric (iv): time to the converged energies of the batch -- KS(...).energy() of every molecule of this
         # rank from the core guess (setup above excluded, reported beside it).  (a) the batch driver: lockstep SCF
         # (dqc_amd/lockstep.py: DIIS, purification and the Cholesky-QR batched over the molecules, one host read per iteration

@@ -17,6 +17,7 @@
 namespace dqc {
 
 void set_error(const std::string &msg);
+bool deterministic_mode();  // dqc_set_deterministic (host.hip)
 
 #define DQC_HIP(call)                                                                      \
     do {                                                                                   \
@@ -134,6 +135,18 @@ inline int ncart(int l) { return (l + 1) * (l + 2) / 2; }
 // ---------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 #define DQC_DEV __device__ __forceinline__
+
+// Accumulation into a shared fp64 slot from many blocks.  scale == 0: fp64 atomic add (order of the additions, hence the last
+// bits, vary from run to run).  scale = 2^k: DETERMINISTIC mode -- the contribution is rounded to a multiple of 2^-k and added
+// as a 64-bit integer; integer addition is associative, so the sum is bit-identical whatever the order (and, two's
+// complement being modular, only the FINAL sum has to fit 63 bits).  The reader converts with det_value().
+__device__ __forceinline__ void acc_add(double *p, double v, double scale) {
+    if (scale == 0.0) atomicAdd(p, v);
+    else atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double2ll_rn(v * scale));
+}
+__device__ __forceinline__ double det_value(double stored, double scale) {
+    return scale == 0.0 ? stored : (double)__double_as_longlong(stored) / scale;
+}
 
 // real solid harmonics (generated, libcint convention)
 #define C2S_QUAL __device__ const

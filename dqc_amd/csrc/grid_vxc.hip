@@ -21,6 +21,9 @@
 
 namespace dqc {
 
+// fixed-point scale of the split-K accumulation into V in deterministic mode (0: fp64 atomics); common.hpp: acc_add
+__device__ double g_vxc_det_scale = 0.0;
+
 // ---------------------------------------------------------------------------------------------
 // Vxc:  M = Phi^T . Psi, split-K over point slabs.  16-point chunks of Phi and Psi live in double-buffered
 // LDS; the next chunk's four AO components are prefetched into registers while the MFMAs run, combined into
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 #ifdef ABL_VXC_NO_ATOMIC
                 if (acc[t][r] == 12345.678)
 #endif
-                    atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+                    acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r], g_vxc_det_scale);
         }
     }
 }
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
             const double sc = (sym && ti != tj) ? 2.0 : 1.0;
 #pragma unroll
 #ifndef ABL_VWS_NO_EPI
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
+            for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r], g_vxc_det_scale);
 #else
             for (int r = 0; r < 4; r++) if (acc[t][r] == 1.2345) vmat[0] = 1.0;
 #endif
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
             const int tl = t0 + t;
             const int ia = (r0 + tl / nc) * 16 + lk, ib = (c0 + tl % nc) * 16 + lr;
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r]);
+            for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r], g_vxc_det_scale);
         }
     }
 }
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
             if (acc[t][0] != 1.2345e300) continue;
 #endif
 #pragma unroll
-            for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r]);
+            for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r], g_vxc_det_scale);
         }
     }
 }
@@ -946,7 +949,7 @@ DQC_DEV void wsd_consumer(double *lds, double *__restrict__ vmat, int nchunk, in
         tile_ij(t, ti, tj);
         const int ia = ti * 16 + lk, ib = tj * 16 + lr;
 #pragma unroll
-        for (int r = 0; r < 4; r++) atomicAdd(&vmat[(size_t)(ia + 4 * r) * LS + ib], acc[t][r]);
+        for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * LS + ib], acc[t][r], g_vxc_det_scale);
     }
 }
 
@@ -978,14 +981,31 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__
 #include "grid_fused.inc"
 #endif
 
-// V = (M + M^T) / 2 on the zero-padded (ld, ld) matrix
+// V = (M + M^T) / 2 on the zero-padded (ld, ld) matrix (deterministic mode: M arrives as fixed-point integers)
 __global__ void symmetrize_kernel(double *m, int ld) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+    const double sc = g_vxc_det_scale;
     if (i < ld && j < i) {
-        const double v = 0.5 * (m[(size_t)i * ld + j] + m[(size_t)j * ld + i]);
+        const double v = 0.5 * (det_value(m[(size_t)i * ld + j], sc) + det_value(m[(size_t)j * ld + i], sc));
         m[(size_t)i * ld + j] = v;
         m[(size_t)j * ld + i] = v;
+    } else if (i < ld && j == i && sc != 0.0) {
+        m[(size_t)i * ld + i] = det_value(m[(size_t)i * ld + i], sc);
     }
+}
+
+// deterministic mode (dqc_set_deterministic): the device-side scale follows the host flag, per device
+static int sync_vxc_det_scale() {
+    static double current[64];  // what each device's g_vxc_det_scale holds (0: fp64 atomics)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    // |V_ij| <= max |v_xc| int |phi_i phi_j| stays far below 2^14 for normalised AOs: 2^47 leaves the sum 63 bits
+    const double want = deterministic_mode() ? 140737488355328.0 : 0.0;
+    if (current[dev] != want) {
+        DQC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vxc_det_scale), &want, sizeof(double)));
+        current[dev] = want;
+    }
+    return 0;
 }
 
 template <int MAXT, int NL, int KCH, bool GGA>
@@ -1104,6 +1124,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
     const bool gga = d_vgrad != nullptr;
     if (gga && ncomp < 4) { set_error("dqc_grid_vxc: vgrad given but ao has < 4 components"); return DQC_EINVAL; }
     const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
+    if (sync_vxc_det_scale()) return DQC_EHIP;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
         static const char *impl_env = getenv("DQC_VXC_IMPL");  // "reg": the unspecialised vxc_kernel (A/B runs)

@@ -7,6 +7,9 @@ namespace dqc {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+static bool g_deterministic = false;
+bool deterministic_mode() { return g_deterministic; }
+
 // ---- pinned staging blocks of the stream-ordered DevPool ----
 static std::mutex g_stg_mu;
 static std::vector<Staging *> g_stg;
@@ -106,6 +109,16 @@ int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st) {
 extern "C" {
 
 const char *dqc_last_error(void) { return dqc::g_err.c_str(); }
+
+int dqc_set_deterministic(int on) {
+    // process-wide: the cross-block accumulations of the Fock build (J / K accumulators, split-K Vxc partial sums, the trace of
+    // the purification iterate) switch from fp64 atomics to fixed-point integer atomics (common.hpp: acc_add), which makes
+    // every result bit-reproducible from run to run.  Returns the previous setting.
+    const int prev = dqc::g_deterministic ? 1 : 0;
+    dqc::g_deterministic = on != 0;
+    return prev;
+}
+int dqc_get_deterministic(void) { return dqc::g_deterministic ? 1 : 0; }
 int dqc_version(void) { return 100; }
 
 int dqc_nao(const int *bas, int nbas) {

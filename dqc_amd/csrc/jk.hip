@@ -42,19 +42,59 @@ __global__ void jk_prep_kernel(double *__restrict__ work, const double *__restri
 }
 
 __global__ void jk_finish_kernel(double *__restrict__ J, double *__restrict__ K, const double *__restrict__ work,
-                                 int nao, int npad) {
+                                 int nao, int npad, const double *__restrict__ dscp) {
+    const double dsc = dscp ? *dscp : 0.0;
     const size_t n2 = (size_t)npad * npad;
     const size_t tot = (size_t)nao * nao;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
         const int i = e / nao, j = e % nao;
-        J[e] = work[n2 + (size_t)i * npad + j] + work[n2 + (size_t)j * npad + i];
-        if (K) K[e] = work[2 * n2 + (size_t)i * npad + j] + work[2 * n2 + (size_t)j * npad + i];
+        J[e] = det_value(work[n2 + (size_t)i * npad + j], dsc) + det_value(work[n2 + (size_t)j * npad + i], dsc);
+        if (K) K[e] = det_value(work[2 * n2 + (size_t)i * npad + j], dsc) + det_value(work[2 * n2 + (size_t)j * npad + i], dsc);
+    }
+}
+
+// deterministic mode: the fixed-point scale of the J / K accumulators of one call, 2^k with 2 gmax sum|D| 2^k < 2^61.
+// |(ij|kl)| <= max_i (ii|ii) = gmax (Cauchy-Schwarz twice), so no accumulator -- each a partial sum of g D terms with
+// weights <= 2 -- can exceed 2 gmax sum_ij |D_ij|.  One block, fixed summation order: the scale itself is reproducible.
+// dms: nmat symmetrised, padded matrices (n2 doubles apart) as the prep kernels leave them in the work buffer.
+__global__ __launch_bounds__(256) void jk_det_scale_kernel(double *__restrict__ slot, const double *__restrict__ dms, int nmat,
+                                                           size_t n2, const double *__restrict__ tiles, int nao) {
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double smax = 0.0;
+    for (int q = 0; q < nmat; q++) {
+        double sacc = 0.0;
+        for (size_t e = t; e < n2; e += 256) sacc += fabs(dms[q * n2 + e]);
+        red[t] = sacc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) red[t] += red[t + o];
+            __syncthreads();
+        }
+        smax = fmax(smax, red[0]);
+        __syncthreads();
+    }
+    double g = 0.0;
+    for (int i = t; i < nao; i += 256) {
+        const long long b = i >> 3, a = i & 7, IJ = b * (b + 1) / 2 + b, T = IJ * (IJ + 1) / 2 + IJ;
+        g = fmax(g, fabs(tiles[(size_t)T * DQC_TILE_SZ + (((a * 8 + a) * 8 + a) * 8 + a)]));
+    }
+    red[t] = g;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] = fmax(red[t], red[t + o]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double bound = 2.0 * fmax(red[0], 1e-300) * fmax(smax, 1e-300);
+        slot[0] = exp2(floor(61.0 - log2(bound)));
     }
 }
 
 template <bool WITH_K>
-__global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ tiles, double *__restrict__ work,
+__global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work,
                                                        int npad, long long ntiles) {
+    const double dsc = dscp ? *dscp : 0.0;  // deterministic mode: fixed-point scale of the accumulators (common.hpp: acc_add)
     constexpr int LDT = 68;  // row stride of the tile parked in LDS: 16-byte aligned rows, bank = 4 row + col (mod 32)
     __shared__ double s_col[4][64];
     __shared__ __attribute__((aligned(16))) double s_g[WITH_K ? 64 * LDT : 2];
@@ -126,7 +166,7 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                atomicAdd(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * f * rs[r]);
+                acc_add(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * f * rs[r], dsc);
         }
         if (lane < 16) {
 #pragma unroll
@@ -135,7 +175,7 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
         __syncthreads();
         if (t < 64) {
             const double v = s_col[0][t] + s_col[1][t] + s_col[2][t] + s_col[3][t];
-            atomicAdd(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v);
+            acc_add(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v, dsc);
         }
         if (WITH_K) {
             // four contractions; thread = output o (64) x partial group pg (4), 16 of the 64 terms each.  Which 16 is chosen
@@ -167,10 +207,10 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
             k3 += __shfl_xor(k3, 1); k3 += __shfl_xor(k3, 2);
             k4 += __shfl_xor(k4, 1); k4 += __shfl_xor(k4, 2);
             if (pg == 0) {
-                atomicAdd(&Kacc[(size_t)(I * 8 + x) * npad + L * 8 + y], f * k1);
-                atomicAdd(&Kacc[(size_t)(J * 8 + x) * npad + L * 8 + y], f * k2);
-                atomicAdd(&Kacc[(size_t)(I * 8 + x) * npad + K * 8 + y], f * k3);
-                atomicAdd(&Kacc[(size_t)(J * 8 + x) * npad + K * 8 + y], f * k4);
+                acc_add(&Kacc[(size_t)(I * 8 + x) * npad + L * 8 + y], f * k1, dsc);
+                acc_add(&Kacc[(size_t)(J * 8 + x) * npad + L * 8 + y], f * k2, dsc);
+                acc_add(&Kacc[(size_t)(I * 8 + x) * npad + K * 8 + y], f * k3, dsc);
+                acc_add(&Kacc[(size_t)(J * 8 + x) * npad + K * 8 + y], f * k4, dsc);
             }
         }
         __syncthreads();  // s_col / s_g reuse
@@ -187,8 +227,9 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
 // work layout (n2 = npad^2 doubles each):  Dj[nj] | Dk[NK] | Jacc[nj] | Kacc[NK].
 // ---------------------------------------------------------------------------------------------
 template <int NK>
-__global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ tiles, double *__restrict__ work,
+__global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work,
                                                                    int npad, long long ntiles, int nj) {
+    const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     constexpr int NKD = NK ? NK : 1;
     __shared__ double s_col[2][4][64];
@@ -267,7 +308,7 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
             double *Jq = Jacc + q * n2;
             if ((lane & 15) == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) atomicAdd(&Jq[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * f * rs[r]);
+                for (int r = 0; r < 4; r++) acc_add(&Jq[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * f * rs[r], dsc);
             }
             if (lane < 16) {
 #pragma unroll
@@ -276,7 +317,7 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
             __syncthreads();  // (also publishes s_g / s_d on the first round; s_col is double-buffered across densities)
             if (t < 64) {
                 const double v = s_col[q & 1][0][t] + s_col[q & 1][1][t] + s_col[q & 1][2][t] + s_col[q & 1][3][t];
-                atomicAdd(&Jq[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v);
+                acc_add(&Jq[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * f * v, dsc);
             }
         }
         if (NK) {
@@ -323,10 +364,10 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
                 a4 += __shfl_xor(a4, 1); a4 += __shfl_xor(a4, 2);
                 if (pg == 0) {
                     double *Kq = Kacc + q * n2;
-                    atomicAdd(&Kq[(size_t)(I * 8 + x) * npad + L * 8 + y], f * a1);
-                    atomicAdd(&Kq[(size_t)(J * 8 + x) * npad + L * 8 + y], f * a2);
-                    atomicAdd(&Kq[(size_t)(I * 8 + x) * npad + K * 8 + y], f * a3);
-                    atomicAdd(&Kq[(size_t)(J * 8 + x) * npad + K * 8 + y], f * a4);
+                    acc_add(&Kq[(size_t)(I * 8 + x) * npad + L * 8 + y], f * a1, dsc);
+                    acc_add(&Kq[(size_t)(J * 8 + x) * npad + L * 8 + y], f * a2, dsc);
+                    acc_add(&Kq[(size_t)(I * 8 + x) * npad + K * 8 + y], f * a3, dsc);
+                    acc_add(&Kq[(size_t)(J * 8 + x) * npad + K * 8 + y], f * a4, dsc);
                 }
             }
         }
@@ -353,14 +394,15 @@ __global__ void jk_multi_prep_kernel(double *__restrict__ work, const double *__
 }
 
 __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *__restrict__ K, int nk, const double *__restrict__ work,
-                                       int nao, int npad) {
+                                       int nao, int npad, const double *__restrict__ dscp) {
+    const double dsc = dscp ? *dscp : 0.0;
     const size_t n2 = (size_t)npad * npad, nn = (size_t)nao * nao;
     const double *acc = work + (size_t)(nj + nk) * n2;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nn * (nj + nk); e += (size_t)gridDim.x * blockDim.x) {
         const int q = e / nn;
         const size_t r = e - (size_t)q * nn;
         const int i = r / nao, j = r % nao;
-        const double v = acc[q * n2 + (size_t)i * npad + j] + acc[q * n2 + (size_t)j * npad + i];
+        const double v = det_value(acc[q * n2 + (size_t)i * npad + j], dsc) + det_value(acc[q * n2 + (size_t)j * npad + i], dsc);
         if (q < nj) J[e] = v;
         else K[e - (size_t)nj * nn] = v;
     }
@@ -375,8 +417,9 @@ __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *_
 // disappear; D[I,J] is reloaded only when IJ changes.  The column sums J[K,L] += g . D[I,J] change target every tile and
 // keep the 2-shuffle + 4-wave LDS combine of jk_tiles_kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ tiles, double *__restrict__ work, int npad,
+__global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work, int npad,
                                                          long long ntiles, long long per_block) {
+    const double dsc = dscp ? *dscp : 0.0;
     __shared__ double s_col[2][4][64];
     const size_t n2 = (size_t)npad * npad;
     const double *Dp = work;
@@ -401,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
         for (int r = 0; r < 4; r++) {
             double v = rsacc[r];
             v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if ((lane & 15) == 0) atomicAdd(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * fI * v);
+            if ((lane & 15) == 0) acc_add(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * fI * v, dsc);
             rsacc[r] = 0.0;
         }
     };
@@ -446,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
         __syncthreads();  // one barrier per tile: s_col is double-buffered
         if (t < 64) {
             const double v = s_col[par][0][t] + s_col[par][1][t] + s_col[par][2][t] + s_col[par][3][t];
-            atomicAdd(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * (I == J ? 0.5 : 1.0) * fk * v);
+            acc_add(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * (I == J ? 0.5 : 1.0) * fk * v, dsc);
         }
         par ^= 1;
     }
@@ -459,7 +502,7 @@ extern "C" {
 
 size_t dqc_jk_work_doubles(int nao) {
     const size_t npad = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
-    return 3 * npad * npad;
+    return 3 * npad * npad + 8;  // D, J, K accumulators + the fixed-point scale of the deterministic mode
 }
 
 int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm, int nao,
@@ -472,28 +515,34 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     const int with_k = d_K != nullptr;
     hipLaunchKernelGGL(jk_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dm, nao, npad, with_k);
     DQC_CHECK_LAUNCH();
+    double *dscp = nullptr;
+    if (deterministic_mode()) {
+        dscp = d_work + 3 * (size_t)npad * npad;
+        hipLaunchKernelGGL(jk_det_scale_kernel, dim3(1), dim3(256), 0, st, dscp, d_work, 1, (size_t)npad * npad, d_tiles, nao);
+        DQC_CHECK_LAUNCH();
+    }
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 256 * 16);
     static const char *jimpl = getenv("DQC_J_IMPL");  // "stride": the grid-stride kernel of round 1 (A/B runs)
     if (with_k) {
-        hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles);
+        hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
     } else if (jimpl && jimpl[0] == 's') {
-        hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles);
+        hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
     } else {
         // contiguous tile ranges, ~6 resident blocks per CU x 2 rounds.  (Tried: 8 x 4 tile rectangles with the column sums in
         // LDS, 24 atomics per tile and no barrier -- 0.396 ms against 0.37 ms for this form: shorter contiguous runs.)
         const long long nblk = std::min<long long>(ntiles, 256 * 12);
         const long long per = (ntiles + nblk - 1) / nblk;
-        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, per);
+        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per);
     }
     DQC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad);
+    hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad, dscp);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
 
 size_t dqc_jk_multi_work_doubles(int nao, int nj, int nk) {
     const size_t npad = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
-    return 2 * (size_t)(nj + (nk > 2 ? 2 : nk)) * npad * npad;
+    return 2 * (size_t)(nj + (nk > 2 ? 2 : nk)) * npad * npad + 8;
 }
 
 int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_K, const double *d_dmK, int nk,
@@ -512,11 +561,17 @@ int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_
         const int njp = first ? nj : 0, nkp = std::min(2, nk - kdone);
         hipLaunchKernelGGL(jk_multi_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dmJ, njp, d_dmK + (size_t)kdone * nn, nkp, nao, npad);
         DQC_CHECK_LAUNCH();
-        if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
-        else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
-        else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, d_tiles, d_work, npad, ntiles, njp);
+        double *dscp = nullptr;
+        if (deterministic_mode()) {
+            dscp = d_work + 2 * (size_t)(njp + nkp) * npad * npad;
+            hipLaunchKernelGGL(jk_det_scale_kernel, dim3(1), dim3(256), 0, st, dscp, d_work, njp + nkp, (size_t)npad * npad, d_tiles, nao);
+            DQC_CHECK_LAUNCH();
+        }
+        if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
+        else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
+        else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
         DQC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(jk_multi_finish_kernel, dim3(64), dim3(256), 0, st, d_J, njp, d_K + (size_t)kdone * nn, nkp, d_work, nao, npad);
+        hipLaunchKernelGGL(jk_multi_finish_kernel, dim3(64), dim3(256), 0, st, d_J, njp, d_K + (size_t)kdone * nn, nkp, d_work, nao, npad, dscp);
         DQC_CHECK_LAUNCH();
         kdone += nkp;
         first = 0;

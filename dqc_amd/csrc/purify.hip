@@ -25,7 +25,8 @@ typedef double pv4d __attribute__((ext_vector_type(4)));
 // state slots `sstride` doubles apart; every molecule freezes on its own.
 __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xout, const double *__restrict__ xin, int ld,
                                                          double nocc, double tol, int k, double *__restrict__ trace,
-                                                         double *__restrict__ idem, size_t xstride, int sstride) {
+                                                         double *__restrict__ idem, size_t xstride, int sstride, double dsc) {
+    // dsc != 0: deterministic mode -- the trace slots hold fixed-point integers (common.hpp: acc_add / det_value)
     __shared__ double red[3][4][64];
     xout += blockIdx.y * xstride;
     xin += blockIdx.y * xstride;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xo
         }
         return;
     }
-    const double tr = trace[k];
+    const double tr = det_value(trace[k], dsc);
     pv4d acc = {0.0, 0.0, 0.0, 0.0};
     // A[i][kk] = X[kk][i] (symmetric): both operands are 4 rows x 128 bytes
     const double *pa = xin + (size_t)lk * ld + ti * 16 + lr;
@@ -89,14 +90,14 @@ __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xo
         emax = fmax(emax, __shfl_xor(emax, o));
     }
     if (lane == 0) {
-        if (ti == tj) atomicAdd(&trace[k + 1], tsum);
+        if (ti == tj) acc_add(&trace[k + 1], tsum, dsc);
         // max of non-negative doubles == max of their bit patterns as unsigned integers
         atomicMax(reinterpret_cast<unsigned long long *>(&idem[k]), (unsigned long long)__double_as_longlong(emax));
     }
 }
 
 __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double *__restrict__ trace0, size_t xstride,
-                                    int sstride) {
+                                    int sstride, double dsc) {
     x += blockIdx.x * xstride;
     trace0 += (size_t)blockIdx.x * sstride;
     double s = 0.0;
@@ -105,7 +106,10 @@ __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) trace0[0] = part[0] + part[1] + part[2] + part[3];
+    if (threadIdx.x == 0) {
+        const double tr = part[0] + part[1] + part[2] + part[3];
+        trace0[0] = dsc == 0.0 ? tr : __longlong_as_double(__double2ll_rn(tr * dsc));
+    }
 }
 
 // Orthonormal basis of the range of a projector from GEMMs + one small launch: Y = P Omega (n x r, Omega a fixed random matrix,
@@ -290,13 +294,15 @@ extern "C" int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nm
     const size_t xstride = (size_t)ld * ld;
     double *trace = d_state, *idem = d_state + (iters + 2);
     DQC_HIP(hipMemsetAsync(d_state, 0, sizeof(double) * (size_t)sstride * nmol, st));
-    hipLaunchKernelGGL(purify_trace_kernel, dim3(nmol), dim3(256), 0, st, d_x, ld, trace, xstride, sstride);
+    // deterministic mode: traces (0 <= tr <= ld < 2^15) as fixed-point integers with 46 fractional bits
+    const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
+    hipLaunchKernelGGL(purify_trace_kernel, dim3(nmol), dim3(256), 0, st, d_x, ld, trace, xstride, sstride, dsc);
     DQC_CHECK_LAUNCH();
     const int T = ld >> 4;
     double *cur = d_x, *nxt = d_tmp;
     for (int k = 0; k < iters; k++) {
         hipLaunchKernelGGL(purify_tc2_kernel, dim3(T * T, nmol), dim3(256), 0, st, nxt, cur, ld, nocc, tol, k, trace, idem, xstride,
-                           sstride);
+                           sstride, dsc);
         DQC_CHECK_LAUNCH();
         std::swap(cur, nxt);
     }

@@ -86,7 +86,16 @@ def load():
     lib.dqc_probe_stream_read.argtypes = [c_dp, c_sz, c_dp, c_vp]
     lib.dqc_probe_mfma_f64.argtypes = [c_dp, c_int, c_vp]
     _lib = lib
+    if os.environ.get("DQC_AMD_DETERMINISTIC", "0") == "1":
+        lib.dqc_set_deterministic(1)
     return lib
+
+
+def set_deterministic(on=True):
+    """bit-reproducible Fock builds: the cross-block sums (J / K accumulators, split-K Vxc, purification trace) use fixed-point
+    integer atomics instead of fp64 atomics (include/dqc_amd.h: dqc_set_deterministic).  Returns the previous setting.
+    Environment: DQC_AMD_DETERMINISTIC=1."""
+    return bool(load().dqc_set_deterministic(1 if on else 0))
 
 
 def _check(rc, what):

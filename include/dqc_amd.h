@@ -243,6 +243,15 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
                       const double *d_w, const double *d_v, void *stream);
 
+/* ---- deterministic mode ----------------------------------------------------------------------
+ * The Fock build sums over blocks with fp64 atomics (J / K accumulators, split-K Vxc partials, the trace of the purification
+ * iterate): the order of the additions, hence the last bits of the result, vary from run to run, while the reference's CPU
+ * path is deterministic.  dqc_set_deterministic(1) switches those sums to fixed-point 64-bit INTEGER atomics (associative:
+ * bit-identical results whatever the order; contributions are rounded to 2^-k with k chosen per call from a rigorous bound
+ * of the sum: 2 max(ii|ii) sum|D_ij| for J / K, 2^14 for V).  Process-wide, returns the previous setting. */
+int dqc_set_deterministic(int on);
+int dqc_get_deterministic(void);
+
 /* ---- micro-benchmarks used by bench.py to price the roofline on the box it runs on ---------- */
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream);
 /* fp64 MFMA (16x16x4) issue-rate probe: 2048 waves x 8 accumulators x iters MFMAs; d_out: 131072 doubles */
