@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     nb = 26
     npair = nb * (nb + 1) // 2
     assert L.dqc_eri_tile_count(208) == npair * (npair + 1) // 2
-    assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8
+    assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8 + 8  # D, J, K accumulators + the deterministic-mode scale slot
 
 
 def test_hamiltonian_fails_loudly_without_gpu():
