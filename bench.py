@@ -372,6 +372,9 @@ def main():
         out_extra["full_scf_iterations_per_s_per_gpu"] = nit / scf_s
         out_extra["full_scf_iterations_per_s_one_molecule_graph_per_gpu"] = one_mol_graph_rate
 
+    if extras and world == 1:
+        out_extra["small_batch"] = small_batch_leg(dev)
+
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components
         norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
@@ -462,6 +465,46 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def small_batch_leg(dev):
+    """batches of SMALL molecules (the sizes of configs C1-C3), where one molecule's kernels fill a fraction
+    of the chip and the one-molecule driver is launch-bound: the lockstep batch driver (one set of DIIS / purification launches
+    for the batch, per-molecule Fock builds replayed as hipGraphs on a few streams) against the one-molecule drivers run
+    concurrently.  Whole SCF runs from the core guess; rate = SCF iterations of all molecules / wall time."""
+    import dqc_amd
+    from dqc_amd.batch import run_concurrent, run_lockstep
+    from tests import molecules as M
+    out = {}
+    for name, base, nmol, xc, grid, sig in (("h2o_ccpvdz_pbe", M.H2O, 256, XC, "sg2", 0.05),
+                                            ("benzene_ccpvdz_lda", M.benzene(), 128, "lda_x+lda_c_pw", "sg3", 0.03)):
+        zs, pos0 = base
+        mols = []
+        for i in range(nmol):
+            pos = np.array(pos0) + np.random.default_rng(100 + i).normal(0.0, sig, (len(zs), 3))
+            mols.append(dqc_amd.Mol((zs, pos.tolist()), basis="cc-pvdz", grid=grid, device=dev))
+        res = {}
+        for label, runner in (("lockstep", lambda q: run_lockstep(q)),
+                              ("one_molecule_drivers", lambda q: run_concurrent(q, max_inflight=16))):
+            qcs = [dqc_amd.KS(m, xc=xc) for m in mols]
+            if label == "lockstep":
+                runner(qcs[:4])  # (kernel / graph warm-up outside the clock)
+                qcs[:4] = [dqc_amd.KS(m, xc=xc) for m in mols[:4]]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            runner(qcs)
+            es = [float(q.energy()) for q in qcs]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[label] = (sum(int(q.niter) for q in qcs) / dt, es, sum(int(q.converged) for q in qcs), dt)
+        out[name] = {"molecules": nmol, "xc": xc, "grid": grid,
+                     "molecule_iterations_per_s_lockstep": res["lockstep"][0],
+                     "molecule_iterations_per_s_one_molecule_drivers": res["one_molecule_drivers"][0],
+                     "converged_lockstep": res["lockstep"][2], "wall_s_lockstep": res["lockstep"][3],
+                     "max_abs_energy_diff_ha": max(abs(a - b) for a, b in zip(res["lockstep"][1], res["one_molecule_drivers"][1]))}
+        del mols, qcs
+        torch.cuda.empty_cache()
+    return out
 
 
 def self_launch(n):

@@ -134,13 +134,15 @@ def run_concurrent(qcs, max_inflight: int = 16, **run_kwargs):
     return qcs
 
 
-def run_lockstep(qcs, group_size: int = 16, inflight: int = 2, nstreams: int = 3, **run_kwargs):
+def run_lockstep(qcs, group_size: int = None, inflight: int = 2, nstreams: int = None, **run_kwargs):
     """Run the SCF of a batch on one GPU with everything but the Fock builds batched across molecules
     (dqc_amd/lockstep.py): calculations are bucketed by (nao, n_occ), every bucket is cut into groups of at most
     `group_size` that advance in lockstep, and `inflight` groups are driven at once on their own streams so that one
     group's latency-bound phase (DIIS, purification: ~1 ms of small launches) overlaps another's Fock builds.
     Calculations that do not qualify (unrestricted, non-uniform occupations, raw AO basis) run through
-    `run_concurrent`.  Returns `qcs`; every element is in the state `qc.run()` leaves it in."""
+    `run_concurrent`.  Returns `qcs`; every element is in the state `qc.run()` leaves it in.
+    Defaults (measured on MI355X, tools/gpu_lockstep_check.py): groups of 128 / 32 / 16 molecules for nao <= 48 / <= 160 /
+    larger, 4 streams per group where the Fock builds replay as hipGraphs (nao <= 160), 3 where they are issued eagerly."""
     from .lockstep import LockstepSCF, signature
     buckets, rest = {}, []
     for q in qcs:
@@ -151,11 +153,14 @@ def run_lockstep(qcs, group_size: int = 16, inflight: int = 2, nstreams: int = 3
         if len(members) == 1:
             rest.extend(members)
             continue
+        nbas = s[1]
+        gsz = group_size if group_size is not None else (128 if nbas <= 48 else (32 if nbas <= 160 else 16))
+        nst = nstreams if nstreams is not None else (4 if nbas <= 160 else 3)
         # equal-sized groups, at least `inflight` of them when there are enough molecules
-        ng = max((len(members) + group_size - 1) // group_size, min(inflight, len(members) // 2))
+        ng = max((len(members) + gsz - 1) // gsz, min(inflight, len(members) // 2))
         size = (len(members) + ng - 1) // ng
         for i in range(0, len(members), size):
-            groups.append(LockstepSCF(members[i:i + size], nstreams=nstreams))
+            groups.append(LockstepSCF(members[i:i + size], nstreams=nst))
     if groups:
         run_concurrent(groups, max_inflight=inflight, **run_kwargs)
     if rest:

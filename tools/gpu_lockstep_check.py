@@ -50,10 +50,11 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 run_concurrent(qa, max_inflight=8)
 ea = [float(q.energy()) for q in qa]
 torch.cuda.synchronize(); ta = time.perf_counter() - t0
-for gs, infl in ((16, 2), (8, 2), (nmol, 1), (max(2, nmol // 4), 4)):
+cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]] or [(16, 2), (8, 2), (nmol, 1), (max(2, nmol // 4), 4)]
+for gs, infl in cfgs:
     qb = fresh()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    run_lockstep(qb, group_size=gs, inflight=infl)
+    run_lockstep(qb, group_size=gs, inflight=infl, nstreams=int(os.environ.get('NSTREAMS', '3')))
     torch.cuda.synchronize(); tl = time.perf_counter() - t0
     eb = [float(q.energy()) for q in qb]
     torch.cuda.synchronize(); tb = time.perf_counter() - t0
