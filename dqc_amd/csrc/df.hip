@@ -23,6 +23,7 @@ static int df_setup(DfSetup &s, const int *atm, int natm, const int *bas, int nb
                     int sh1, int k0, int k1, bool need_orb, hipStream_t st, const char *who) {
     int rc = parse_basis(s.b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
+    if ((rc = boys_table_ensure())) return rc;
     if (sh0 < 0 || sh1 > nbas || sh0 > sh1 || k0 < 0 || k1 > nbas || k0 > k1) {
         set_error(std::string(who) + ": shell ranges outside the table");
         return DQC_EINVAL;
@@ -74,7 +75,7 @@ static int launch_df_class(double *out, const DfSetup &s, hipStream_t st) {
     const int nb = hb.cls_count[cb], nk = s.aux.cls_count[ck];
     if (nb == 0 || nk == 0) return 0;
     const long long ntask = (long long)nb * nk;
-    const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
+    const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, 0, MODE>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, out, s.ds, db, s.daux, hb.cls_start[cb],

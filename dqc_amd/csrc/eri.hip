@@ -62,7 +62,7 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     if (nb == 0 || nk == 0) return 0;
     const int same = cb == ck;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
-    const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
+    const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)Cfg::LDS_BYTES);
     hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
@@ -100,6 +100,7 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
         if (s.l > ERI_LMAX) { set_error("dqc_eri_fill_tiles: shells above f are not supported"); return DQC_EINVAL; }
     DQC_HIP(hipMemsetAsync(d_tiles, 0, sizeof(double) * DQC_TILE_SZ * dqc_eri_tile_count(b.nao), st));
     if (nbas == 0) return DQC_OK;
+    if ((rc = boys_table_ensure())) return rc;
     HostPairs hp;
     build_pairs(b, hp);
     DevPool pool(st);  // stream-ordered scratch: this call only enqueues

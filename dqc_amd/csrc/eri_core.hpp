@@ -9,10 +9,56 @@ namespace dqc {
 
 constexpr int ERI_LMAX = 3;
 
+// Boys functions F_0, F_1 for the one-root classes with closed-form integrals ((ss|ss), (ps|ss): eri_core.hpp).  Table of
+// F_0 .. F_8 on a grid of spacing 1/8 up to X = 40 (host-generated once per device: boys_table_ensure, host.hip), staged in
+// LDS by the block; a lookup is 9 LDS reads + a 7-term Taylor step (|delta| <= 1/16: truncation 3e-16) instead of the two
+// 14-coefficient Clenshaw evaluations of the Rys table; beyond X = 40 the asymptotic forms are exact to round-off.
+constexpr int BOYS_W = 9, BOYS_ROWS = 321, BOYS_DOUBLES = BOYS_W * BOYS_ROWS;
+static __device__ double g_boys_tab[BOYS_DOUBLES];  // one copy per translation unit (no relocatable device code)
+const std::vector<double> &boys_table_host();       // host.hip
+
+// upload of this translation unit's copy, once per device
+static int boys_table_ensure() {
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DQC_EHIP;
+    if (done[dev]) return 0;
+    const std::vector<double> &tab = boys_table_host();
+    DQC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_boys_tab), tab.data(), sizeof(double) * BOYS_DOUBLES));
+    done[dev] = true;
+    return 0;
+}
+
+DQC_DEV void boys_stage_lds(__attribute__((address_space(3))) double *lt, int tid, int nthreads) {
+    for (int e = tid; e < BOYS_DOUBLES; e += nthreads) lt[e] = g_boys_tab[e];
+}
+
+DQC_DEV void boys01_lds(const __attribute__((address_space(3))) double *lt, double X, double &f0, double &f1) {
+    if (X >= 40.0) {
+        const double ix = 1.0 / X;
+        f0 = 0.88622692545275801 * sqrt(ix);  // sqrt(pi) / 2
+        f1 = 0.5 * f0 * ix;
+        return;
+    }
+    const int i = (int)(X * 8.0 + 0.5);
+    const double d = i * 0.125 - X;  // -delta
+    const __attribute__((address_space(3))) double *c = lt + i * BOYS_W;
+    double a = c[7] * (1.0 / 5040.0), b = c[8] * (1.0 / 5040.0);
+    a = a * d + c[6] * (1.0 / 720.0); b = b * d + c[7] * (1.0 / 720.0);
+    a = a * d + c[5] * (1.0 / 120.0); b = b * d + c[6] * (1.0 / 120.0);
+    a = a * d + c[4] * (1.0 / 24.0);  b = b * d + c[5] * (1.0 / 24.0);
+    a = a * d + c[3] * (1.0 / 6.0);   b = b * d + c[4] * (1.0 / 6.0);
+    a = a * d + c[2] * 0.5;           b = b * d + c[3] * 0.5;
+    a = a * d + c[1];                 b = b * d + c[2];
+    f0 = a * d + c[0];
+    f1 = b * d + c[1];
+}
+
+
 struct DevPairs {
     const int *sh;       // (npair, 2): first shell has the higher (or equal) l
     const int *pp_off;   // (npair+1)
-    const double *pp;    // (npp, 5): p, Px, Py, Pz, ca*cb*Kab
+    const double *pp;    // (npp, 5): p, Px, Py, Pz, ca*cb*Kab / p
 };
 
 __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
@@ -43,10 +89,12 @@ struct EriCfg {
     // Rys table of this class's root count staged in LDS behind the regions when it is small (NR <= 2: 3.7 and 8.4 KB; with the 14 KB table of NR = 3 cc-pVTZ fills got 7 % slower).  Lanes of
     // a wave work on different primitive quartets, so a root lookup is a gather: 28 uncoalesced global loads per (direction,
     // root) item -- PMC: one VMEM read per 8.6 VALU instructions and 48 % of the wave cycles in issue stalls for (ps|ss)
+    // (ss|ss) and (ps|ss): the integral is a closed form in F_0, F_1 -- no 2D-integral staging, Boys table instead of the Rys table
+    static constexpr bool BOYS01 = (NR == 1 && LB == 0 && LC == 0 && LD == 0);
 #ifdef ERI_NO_LDS_TAB  // A/B builds
     static constexpr int TAB_DOUBLES = 0;
 #else
-    static constexpr int TAB_DOUBLES = NR <= 2 ? rys_lds_doubles<NR>() : 0;
+    static constexpr int TAB_DOUBLES = BOYS01 ? BOYS_DOUBLES : (NR <= 2 ? rys_lds_doubles<NR>() : 0);
 #endif
     static constexpr size_t REG_DOUBLES = (size_t)REGION * QPB;
     static constexpr size_t LDS_BYTES = sizeof(double) * (REG_DOUBLES + TAB_DOUBLES);
@@ -65,6 +113,14 @@ struct EriCfg {
 //                   the derivative d/dA of (a b|c d); it is contracted on the fly with Cartesian density matrices,
 //                   sum [jfac D_ab D_cd - k (D_ac D_bd + D_ad D_bc)], and added to the gradient of a's atom
 enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3 };
+
+// 256-thread blocks of one class launch: QPB consecutive tasks per block, or -- one-lane-per-quartet classes, wave-transposed
+// task map (see the kernel) -- one (64-bra-pair chunk, ket pair) per wave
+template <class Cfg>
+inline long long eri_num_blocks(int nb, int nk, long long ntask) {
+    if (Cfg::TPQ == 1) return (((long long)(nb + 63) / 64) * nk + 3) / 4;
+    return (ntask + Cfg::QPB - 1) / Cfg::QPB;
+}
 
 struct EriOut {
     int nao;      // orbital AOs (3C: leading dimensions)
@@ -125,15 +181,29 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     typedef __attribute__((address_space(3))) double lds_double_t;
     lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G : Cfg::REG_DOUBLES);
     if constexpr (TAB_LDS) {
-        rys_stage_lds<NR>(ltab, tid, 256);
+        if constexpr (Cfg::BOYS01) boys_stage_lds(ltab, tid, 256);
+        else rys_stage_lds<NR>(ltab, tid, 256);
         __syncthreads();
     }
 
     long long task = (long long)blockIdx.x * QPB + q;
-    const bool active = task < ntask;
+    bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
-    if (same) {
+    if constexpr (TPQ == 1) {
+        // one lane per shell quartet: WAVE-TRANSPOSED task map -- the 64 lanes of a wave take 64 consecutive BRA pairs and ONE
+        // ket pair.  The primitive loops then read the ket pair's data wave-uniformly (one cache line per load instead of 64:
+        // with consecutive KET pairs per lane every primitive quartet was five uncoalesced loads served from L2) and the
+        // ket primitive count is the same for all lanes; the pairs of a class are sorted by primitive count, so neighbouring
+        // bra pairs are equally deep.  `same` classes keep ib >= ik (waves entirely below the diagonal retire at once).
+        const long long wv = (long long)blockIdx.x * 4 + (tid >> 6);
+        const int nchunk = (nb + 63) >> 6;
+        int ikl = (int)(wv / nchunk);
+        int ibl = (int)(wv - (long long)ikl * nchunk) * 64 + (tid & 63);
+        active = ikl < nk && ibl < nb && (!same || ibl >= ikl);
+        ib = ibl < nb ? ibl : nb - 1;
+        ik = ikl < nk ? ikl : nk - 1;
+    } else if (same) {
         long long r = (long long)((sqrt(8.0 * (double)task + 1.0) - 1.0) * 0.5);
         while (r * (r + 1) / 2 > task) r--;
         while ((r + 1) * (r + 2) / 2 <= task) r++;
@@ -188,6 +258,38 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         oidx[m] = ixx | (iyy << 10) | (izz << 20);
     }
 
+    if constexpr (Cfg::BOYS01 && TAB_LDS) {
+        // ---------------- (ss|ss), (ps|ss): [s s|s s] = pref F_0(X),  [p_d s|s s] = pref (F_0 (P - A)_d - F_1 q/(p+q) (P - Q)_d) ----
+        // (the general path below stages three 2D integrals per primitive quartet in LDS and reads them back; these deep s
+        // contractions -- up to 4096 primitive quartets per shell quartet in cc-pVDZ -- were 27 % of a 20-atom fill)
+        static_assert(TPQ == 1, "closed-form classes run one lane per shell quartet");
+        for (int ipb = 0; ipb < (active ? nbp : 0); ipb++) {
+            const double *pb = prs.pp + (size_t)(pb0 + ipb) * 5;
+            const double p = pb[0], P0 = pb[1], P1 = pb[2], P2 = pb[3], kb = pb[4] * 34.986836655249725;  // 2 pi^(5/2) K_ab / p
+            for (int ipk = 0; ipk < nkp; ipk++) {
+                const double *pk = prk.pp + (size_t)(pk0 + ipk) * 5;
+                const double qq = pk[0];
+                const double d0 = P0 - pk[1], d1 = P1 - pk[2], d2 = P2 - pk[3];
+                const double rs_ = rsqrt(p + qq), ipq = rs_ * rs_;  // no division in this loop: the pair table carries K / p
+                const double X = p * qq * ipq * (d0 * d0 + d1 * d1 + d2 * d2);
+                const double pref = kb * pk[4] * rs_;  // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q))
+                double f0, f1;
+                boys01_lds(ltab, X, f0, f1);
+                if constexpr (LA == 0) {
+                    acc[0] += pref * f0;
+                } else {
+                    const double w0 = pref * f0, w1 = pref * f1 * qq * ipq;
+                    const double v[3] = {w0 * (P0 - A[0]) - w1 * d0, w0 * (P1 - A[1]) - w1 * d1, w0 * (P2 - A[2]) - w1 * d2};
+#pragma unroll
+                    for (int m = 0; m < NPT; m++) {
+                        int ax, ay, az;
+                        cart_pow(1, m, ax, ay, az);
+                        acc[m] += ax ? v[0] : (ay ? v[1] : v[2]);
+                    }
+                }
+            }
+        }
+    } else
     for (int iq = 0; iq < maxq; iq++) {
         const bool on = iq < nq;
         // ---------------- phase A: 2D integrals for every (direction, root) ----------------
@@ -201,7 +303,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
             // reciprocals once per primitive quartet: the recurrence coefficients below were five fp64 divisions per item
             const double ipq = 1.0 / pq, ip = 1.0 / p, iqq = 1.0 / qq;
-            const double pref = pb[4] * pk[4] * 34.986836655249725 * (ip * iqq) * sqrt(ipq);  // 2 pi^(5/2) / (p q sqrt(p + q))
+            const double pref = pb[4] * pk[4] * 34.986836655249725 * sqrt(ipq);  // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q)): the table holds K / p
             // the NR roots depend on X only, not on the direction: lane s of the quartet's group evaluates root s % NR ONCE and
             // the (direction, root) items fetch theirs by shuffle (a one-lane group loops over all roots) -- per item this
             // was a Clenshaw evaluation of its own, i.e. three times the work in groups of 1 or 4 lanes
@@ -487,7 +589,7 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
                     const double K = std::exp(-arg);
                     pr.pp.push_back(p);
                     for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
-                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K);
+                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K / p);  // c_a c_b K_ab / p
                 }
             pr.npp = (int)pr.pp.size() / 5;
             all.push_back(std::move(pr));

@@ -57,7 +57,7 @@ static void build_pairs_ordered(const Basis &b, HostPairs &hp, int f0, int f1, i
                     if (arg > 100.0) continue;
                     pr.pp.push_back(p);
                     for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
-                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * std::exp(-arg));
+                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * std::exp(-arg) / p);  // c_a c_b K_ab / p
                 }
             pr.npp = (int)pr.pp.size() / 5;
             all.push_back(std::move(pr));
@@ -95,7 +95,7 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     const int nb = c.hbra->cls_count[cb], nk = c.hket->cls_count[ck];
     if (nb == 0 || nk == 0) return 0;
     const long long ntask = (long long)nb * nk;
-    const long long nblk = (ntask + Cfg::QPB - 1) / Cfg::QPB;
+    const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_G);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_G, st, (double *)nullptr, c.ds, c.dbra, c.dket,
@@ -350,6 +350,7 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     // upload_shells needs l >= 0 everywhere: placeholders become s shells (never referenced by a pair)
     for (HostShell &h : b.shells)
         if (h.l < 0) h.l = 0;
+    if ((rc = boys_table_ensure())) return rc;
     DevPool pool;
     GradCtx c;
     if ((rc = upload_shells(c.ds, b, pool, st))) { set_error("dqc_eri_grad: device upload failed"); return rc; }
@@ -483,6 +484,7 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
     build_pairs(b, hket, k0, k1, unit);
     for (HostShell &h : b.shells)
         if (h.l < 0) h.l = 0;
+    if ((rc = boys_table_ensure())) return rc;
     DevPool pool;
     GradCtx c;
     if ((rc = upload_shells(c.ds, b, pool, st))) { set_error("dqc_df_grad: device upload failed"); return rc; }

@@ -7,6 +7,34 @@ namespace dqc {
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
 
+// F_0 .. F_8 at X_i = i / 8 (series for F_8 in long double, downward recursion): the Boys table of eri_core.hpp
+const std::vector<double> &boys_table_host() {
+    static std::mutex mu;
+    static std::vector<double> tab;
+    std::lock_guard<std::mutex> lk(mu);
+    if (tab.empty()) {
+        constexpr int W = 9, ROWS = 321;
+        tab.resize(W * ROWS);
+        for (int i = 0; i < ROWS; i++) {
+            const long double X = i * 0.125L, ex = expl(-X);
+            const int mtop = W - 1;
+            long double term = 1.0L / (2 * mtop + 1), sum = term;  // F_m(X) = e^-X sum_j (2X)^j / ((2m+1)(2m+3)...(2m+2j+1))
+            for (int j = 1; j < 400; j++) {
+                term *= 2.0L * X / (2 * mtop + 2 * j + 1);
+                sum += term;
+                if (term < 1e-22L * sum) break;
+            }
+            long double f = ex * sum;
+            tab[i * W + mtop] = (double)f;
+            for (int m = mtop; m >= 1; m--) {
+                f = (2.0L * X * f + ex) / (2 * m - 1);
+                tab[i * W + m - 1] = (double)f;
+            }
+        }
+    }
+    return tab;
+}
+
 static bool g_deterministic = false;
 bool deterministic_mode() { return g_deterministic; }
 
