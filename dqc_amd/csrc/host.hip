@@ -157,6 +157,8 @@ int dqc_nao(const int *bas, int nbas) {
 
 int dqc_padded_nao(int nao) {
     int ld = (nao + 15) / 16 * 16;  // multiple of 16 (MFMA tiles) ...
+    // (round 3: plain multiples of 16 -- benzene 144 -> 128 -- are not worth having: the LDA build gets 4 % faster, the
+    // naphthalene / cc-pVTZ one not at all, and the one-block Vxc kernels rely on an odd tile count)
     if ((ld & 31) != 16) ld += 16;  // ... and == 16 (mod 32): LDS fragment reads are bank-conflict-free
     return ld;
 }

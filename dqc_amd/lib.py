@@ -149,8 +149,7 @@ class Tables:
 
 
 def padded_nao(nao):
-    ld = (nao + 15) // 16 * 16
-    return ld if ld % 32 == 16 else ld + 16
+    return int(load().dqc_padded_nao(int(nao)))
 
 
 def int1e(which, tab, device, zs=None):
