@@ -85,9 +85,103 @@ struct ClassLoop {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// direct SCF: J / K straight from the shell quartets (nothing stored)
+// ---------------------------------------------------------------------------------------------
+template <int LA, int LB, int LC, int LD>
+static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st) {
+    using Cfg = EriCfg<LA, LB, LC, LD>;
+    const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
+    const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
+    if (nb == 0 || nk == 0) return 0;
+    const int same = cb == ck;
+    const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+    const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
+    auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_JK);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_JK, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
+                       nb, hp.cls_start[ck], nk, same, ntask, og);
+    DQC_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int CB, int CK>
+struct ClassLoopJK {
+    static int run(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st) {
+        constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
+        constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
+        int rc = launch_class_jk<LA, LB, LC, LD>(ds, dp, hp, og, st);
+        if (rc) return rc;
+        if constexpr (CK > 0) return ClassLoopJK<CB, CK - 1>::run(ds, dp, hp, og, st);
+        else if constexpr (CB > 0) return ClassLoopJK<CB - 1, CB - 1>::run(ds, dp, hp, og, st);
+        else return 0;
+    }
+};
+
+__global__ void jk_direct_prep_kernel(double *__restrict__ dsym, double *__restrict__ a, double *__restrict__ b,
+                                      const double *__restrict__ dm, int nao) {
+    const size_t n2 = (size_t)nao * nao;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = e / nao, j = e % nao;
+        dsym[e] = 0.5 * (dm[e] + dm[(size_t)j * nao + i]);
+        a[e] = 0.0;
+        if (b) b[e] = 0.0;
+    }
+}
+
+__global__ void jk_direct_finish_kernel(double *__restrict__ J, double *__restrict__ K, const double *__restrict__ a,
+                                        const double *__restrict__ b, int nao) {
+    const size_t n2 = (size_t)nao * nao;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = e / nao, j = e % nao;
+        const size_t et = (size_t)j * nao + i;
+        J[e] = 0.5 * (a[e] + a[et]);
+        if (K) K[e] = b[e] + b[et];
+    }
+}
+
 }  // namespace dqc
 
 extern "C" {
+
+int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, int natm, const int *bas, int nbas,
+                  const double *env, int nenv, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    Basis b;
+    int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    for (const HostShell &s : b.shells)
+        if (s.l > ERI_LMAX) { set_error("dqc_jk_direct: shells above f are not supported"); return DQC_EINVAL; }
+    if (nbas == 0 || b.nao == 0) return DQC_OK;
+    if ((rc = boys_table_ensure())) return rc;
+    HostPairs hp;
+    build_pairs(b, hp);
+    DevPool pool(st);
+    DevShells ds;
+    if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_jk_direct: device upload failed"); return rc; }
+    int *d_sh = nullptr, *d_off = nullptr;
+    double *d_pp = nullptr, *d_sym = nullptr, *d_a = nullptr, *d_b = nullptr;
+    const size_t n2 = (size_t)b.nao * b.nao;
+    if ((rc = pool.upload(&d_sh, hp.sh, st)) || (rc = pool.upload(&d_off, hp.pp_off, st)) || (rc = pool.upload(&d_pp, hp.pp, st)) ||
+        (rc = pool.alloc(&d_sym, n2)) || (rc = pool.alloc(&d_a, n2)) || (d_K && (rc = pool.alloc(&d_b, n2)))) {
+        set_error("dqc_jk_direct: device allocation failed");
+        return rc;
+    }
+    hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, d_sym, d_a, d_b, d_dm, b.nao);
+    DQC_CHECK_LAUNCH();
+    DevPairs dp{d_sh, d_off, d_pp};
+    EriOut og{b.nao, 0, 0, 0};
+    og.dmat = d_sym;
+    og.jacc = d_a;
+    og.kacc = d_b;
+    constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
+    rc = ClassLoopJK<NCLS - 1, NCLS - 1>::run(ds, dp, hp, og, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, d_a, d_b, b.nao);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
 
 int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas, int nbas, const double *env,
                        int nenv, void *stream) {

@@ -98,6 +98,11 @@ struct EriCfg {
 #endif
     static constexpr size_t REG_DOUBLES = (size_t)REGION * QPB;
     static constexpr size_t LDS_BYTES = sizeof(double) * (REG_DOUBLES + TAB_DOUBLES);
+    // JK mode (direct SCF): per-quartet partial sums J_ab, J_cd, K_ac, K_ad, K_bc, K_bd behind the region
+    static constexpr int NJK = SA * SB + SC * SD + SA * SC + SA * SD + SB * SC + SB * SD;
+    static constexpr int REGION_JK = (REG0 + NJK) | 1;
+    static constexpr size_t REG_DOUBLES_JK = (size_t)REGION_JK * QPB;
+    static constexpr size_t LDS_BYTES_JK = sizeof(double) * (REG_DOUBLES_JK + TAB_DOUBLES);
     // GRAD mode contracts straight from the accumulators: only the 2D-integral staging area is needed
     static constexpr int REGION_G = GSZ | 1;
     static constexpr size_t REG_DOUBLES_G = (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
@@ -112,7 +117,10 @@ struct EriCfg {
 //                   coefficients 2 alpha c) or "down" (l-1) companion of an orbital shell a, so the Cartesian block IS
 //                   the derivative d/dA of (a b|c d); it is contracted on the fly with Cartesian density matrices,
 //                   sum [jfac D_ab D_cd - k (D_ac D_bd + D_ad D_bc)], and added to the gradient of a's atom
-enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3 };
+//   ERI_OUT_JK    : direct SCF -- nothing is stored; the spherical block of every unique shell quartet is contracted with the
+//                   density on the fly (J_ab += (ab|cd) D_cd, J_cd += (ab|cd) D_ab, four exchange products), summed per
+//                   quartet in LDS and added to the global accumulators with one atomic per (shell-pair) element
+enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3, ERI_OUT_JK = 4 };
 
 // 256-thread blocks of one class launch: QPB consecutive tasks per block, or -- one-lane-per-quartet classes, wave-transposed
 // task map (see the kernel) -- one (64-bra-pair chunk, ket pair) per wave
@@ -141,6 +149,9 @@ struct EriOut {
     //                           gmode 2: (d_A k|l) c_k c_l    -> -1 to k's atom); ccart: fit coefficients, Cartesian
     int gmode = 0;
     const double *ccart = nullptr;
+    // ---- JK mode: symmetric AO density (nao, nao), accumulators A (J = (A + A^T) / 2) and B (K = B + B^T; NULL: J only)
+    const double *dmat = nullptr;
+    double *jacc = nullptr, *kacc = nullptr;
 };
 
 // index of the Cartesian component (lx, ly, lz) of shell l (inverse of cart_pow)
@@ -175,11 +186,15 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 
     const int tid = threadIdx.x;
     const int q = tid / TPQ, s = tid % TPQ;  // quartet slot in the block, lane inside the quartet group
-    constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : Cfg::REGION;
+    constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : (MODE == ERI_OUT_JK ? Cfg::REGION_JK : Cfg::REGION);
     double *reg = lds + (size_t)q * REGION;
     constexpr bool TAB_LDS = Cfg::TAB_DOUBLES > 0;
     typedef __attribute__((address_space(3))) double lds_double_t;
-    lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G : Cfg::REG_DOUBLES);
+    lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G
+                                                 : (MODE == ERI_OUT_JK ? Cfg::REG_DOUBLES_JK : Cfg::REG_DOUBLES));
+    if constexpr (MODE == ERI_OUT_JK) {  // the quartet's partial J / K sums start at zero (synchronised by the phases below)
+        for (int e = s; e < Cfg::NJK; e += TPQ) reg[Cfg::REG0 + e] = 0.0;
+    }
     if constexpr (TAB_LDS) {
         if constexpr (Cfg::BOYS01) boys_stage_lds(ltab, tid, 256);
         else rys_stage_lds<NR>(ltab, tid, 256);
@@ -536,6 +551,25 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             for (int c = 0; c < Cfg::NCD; c++) v += C[md * Cfg::NCD + c] * buf1[mabc * Cfg::NCD + c];
             const int mc = mabc % Cfg::SC, mb = (mabc / Cfg::SC) % Cfg::SB, ma = mabc / (Cfg::SC * Cfg::SB);
             const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
+            if constexpr (MODE == ERI_OUT_JK) {
+                const double *D = og.dmat;
+                const size_t n = og.nao;
+                double *jk = reg + Cfg::REG0;
+                constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
+                              OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
+                auto ladd = [](double *p_, double x) {
+                    if constexpr (TPQ == 1) *p_ += x;   // the lane owns its quartet's sums
+                    else atomicAdd(p_, x);              // ds_add_f64
+                };
+                ladd(&jk[ma * Cfg::SB + mb], v * D[(size_t)k * n + l]);
+                ladd(&jk[OJ2 + mc * Cfg::SD + md], v * D[(size_t)i * n + j]);
+                if (og.kacc) {
+                    ladd(&jk[OK1 + ma * Cfg::SC + mc], v * D[(size_t)j * n + l]);
+                    ladd(&jk[OK2 + ma * Cfg::SD + md], v * D[(size_t)j * n + k]);
+                    ladd(&jk[OK3 + mb * Cfg::SC + mc], v * D[(size_t)i * n + l]);
+                    ladd(&jk[OK4 + mb * Cfg::SD + md], v * D[(size_t)i * n + k]);
+                }
+            } else
             if (MODE == ERI_OUT_TILES) {
                 tile_put(tiles, i, j, k, l, v);
                 tile_put(tiles, j, i, k, l, v);
@@ -551,6 +585,32 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 tiles[(jo * og.nao + io) * og.naux + kx] = v;
             } else {
                 tiles[(size_t)(i - og.aux0) * og.naux + (k - og.aux0)] = v;
+            }
+        }
+    }
+    if constexpr (MODE == ERI_OUT_JK) {
+        // one atomic per element of the six shell-pair blocks.  Every unique quartet is visited once (pairs a >= b, c >= d,
+        // bra pair >= ket pair): the eight permutational images are covered by accumulating A_ab, A_cd (J = (A + A^T) / 2)
+        // and B_ac, B_ad, B_bc, B_bd (K = B + B^T) with 1/2 per coincidence a == b, c == d, (ab) == (cd)
+        eri_group_sync<TPQ>();
+        if (active) {
+            const double deg = (ish == jsh ? 0.5 : 1.0) * (ksh == lsh ? 0.5 : 1.0) * ((ish == ksh && jsh == lsh) ? 0.5 : 1.0);
+            const int ai = sh.ao_off[ish], aj = sh.ao_off[jsh], ak = sh.ao_off[ksh], al = sh.ao_off[lsh];
+            const size_t n = og.nao;
+            const double *jk = reg + Cfg::REG0;
+            constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
+                          OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
+            const int nend = og.kacc ? Cfg::NJK : OK1;
+            for (int e = s; e < nend; e += TPQ) {
+                double *dst;
+                double f = deg;
+                if (e < OJ2) { dst = og.jacc + (size_t)(ai + e / Cfg::SB) * n + aj + e % Cfg::SB; f *= 4.0; }
+                else if (e < OK1) { const int x = e - OJ2; dst = og.jacc + (size_t)(ak + x / Cfg::SD) * n + al + x % Cfg::SD; f *= 4.0; }
+                else if (e < OK2) { const int x = e - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
+                else if (e < OK3) { const int x = e - OK2; dst = og.kacc + (size_t)(ai + x / Cfg::SD) * n + al + x % Cfg::SD; }
+                else if (e < OK4) { const int x = e - OK3; dst = og.kacc + (size_t)(aj + x / Cfg::SC) * n + ak + x % Cfg::SC; }
+                else { const int x = e - OK4; dst = og.kacc + (size_t)(aj + x / Cfg::SD) * n + al + x % Cfg::SD; }
+                atomicAdd(dst, f * jk[e]);
             }
         }
     }

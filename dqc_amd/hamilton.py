@@ -80,6 +80,12 @@ class HamiltonMI355(_Base):
         # build() can put the ERI tile fill on a side stream BEFORE it and the two overlap
         self._X = None
         self._fill_done = None
+        # where the two-electron integrals live: "tiles" (8-fold-unique tiles resident in HBM, streamed per Fock build), "direct"
+        # (nothing stored, the shell quartets are re-evaluated per build: dqc_jk_direct) or "auto" (tiles when they fit)
+        self._eri_mode = os.environ.get("DQC_AMD_ERI", "auto")
+        if self._eri_mode not in ("auto", "tiles", "direct"):
+            raise RuntimeError("DQC_AMD_ERI must be auto, tiles or direct")
+        self._direct = False
         self.orthogonalized = bool(orthozer)  # False: the API's matrices live in the raw AO basis (overlap != 1)
         if df is None:
             self._df = None
@@ -159,11 +165,19 @@ class HamiltonMI355(_Base):
             need = int(lib.load().dqc_eri_tile_count(tab.nao)) * 4096 * 8
             free, _total = torch.cuda.mem_get_info(dev)
             free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)  # blocks cached by the allocator are reusable
-            if need > free:
+            mode = self._eri_mode
+            if mode == "auto":
+                mode = "tiles" if need <= free else "direct"
+            if mode == "tiles" and need > free:
                 raise lib.DqcAmdError(
                     "the exact-J/K ERI tile store of this basis needs %.1f GB (nao = %d) but only %.1f GB of device memory "
-                    "are free: use the density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...)) "
-                    "for Kohn-Sham runs of this size" % (need / 1e9, tab.nao, free / 1e9))
+                    "are free: use eri='direct' (DQC_AMD_ERI=direct: the integrals are re-evaluated in every Fock build) or the "
+                    "density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...))" % (need / 1e9, tab.nao, free / 1e9))
+            self._direct = mode == "direct"
+        if self._df is None and self._direct:
+            # direct SCF: no tile store; every J / K call re-evaluates the shell quartets (dqc_jk_direct)
+            self._tiles_store, self._jkwork = None, None
+        elif self._df is None:
             # the fill (VALU-bound, 18 ms for a 20-atom molecule) runs on a side stream while this stream does the small
             # latency-bound setup work -- eigh of S, T, V, their conversions; the streams join at the end of build()
             main = torch.cuda.current_stream(dev)
@@ -254,7 +268,7 @@ class HamiltonMI355(_Base):
             return c[1], c[2]
         dao = self._unconvert_dm(dm)
         with_k = need_k or self._fuse_k
-        J, K = lib.jk(self._tiles, dao, self._jkwork, with_k)
+        J, K = self._jk_ao(dao, with_k)
         J = self._convert2(J)
         J = (J + J.transpose(-2, -1)) * 0.5
         if K is not None:
@@ -262,6 +276,20 @@ class HamiltonMI355(_Base):
             K = (K + K.transpose(-2, -1)) * 0.5
         self._jk_cache = (dm, J, K, dm._version)
         return J, K
+
+    def use_direct_eri(self, on: bool = True):
+        """before build(): keep no ERI tile store and re-evaluate the integrals in every Fock build (direct SCF) -- for bases
+        whose ~nao^4 bytes of tiles do not fit the GPU; `on=False` insists on the tile store"""
+        if self.is_built:
+            raise RuntimeError("use_direct_eri must be called before build()")
+        self._eri_mode = "direct" if on else "tiles"
+        return self
+
+    def _jk_ao(self, dao, with_k):
+        """(J, K or None) of one AO-basis density: from the resident tiles, or directly from the shell quartets"""
+        if self._direct:
+            return lib.jk_direct(self._tab, dao, with_k)
+        return lib.jk(self._tiles, dao, self._jkwork, with_k)
 
     def _sym_orth(self, m_ao):
         m = self._convert2(m_ao)
@@ -279,6 +307,10 @@ class HamiltonMI355(_Base):
         the ERI tiles (dqc_jk_from_tiles_multi); orthogonalised basis in and out."""
         dj = None if dms_j is None else self._unconvert_dm(dms_j)
         dk = None if dms_k is None else self._unconvert_dm(dms_k)
+        if self._direct:  # one pass over the shell quartets per density
+            J = None if dj is None else torch.stack([lib.jk_direct(self._tab, d, False)[0] for d in dj])
+            K = None if dk is None else torch.stack([lib.jk_direct(self._tab, d, True)[1] for d in dk])
+            return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
         J, K = lib.jk_multi(self._tiles, dj, dk, self._multi_work(0 if dj is None else dj.shape[0], 0 if dk is None else dk.shape[0]))
         return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
 
@@ -546,7 +578,7 @@ class HamiltonMI355(_Base):
         if self._df is not None:
             jao = self._df.coulomb_ao(dao)
         else:
-            jao, _ = lib.jk(self._tiles, dao, self._jkwork, False)
+            jao, _ = self._jk_ao(dao, False)
         densinfo = self._dm2densinfo(dm)
         if hasattr(self.xc, "get_vxc_and_exc"):  # potentials and the E_xc quadrature from one pass over the grid
             potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
@@ -583,7 +615,7 @@ class HamiltonMI355(_Base):
 
         mark()
         if self._df is None:
-            jao, _ = lib.jk(self._tiles, dao_n, self._jkwork, False)
+            jao, _ = self._jk_ao(dao_n, False)
         else:
             jao = lib.df_coulomb(self._df.j3c, self._df._inv_j2c, dao_n, self._df._work)
         mark()

@@ -51,6 +51,7 @@ def load():
     tab = [ip, c_int, ip, c_int, dp, c_int]
     lib.dqc_int1e.argtypes = [c_int, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
+    lib.dqc_jk_direct.argtypes = [c_dp, c_dp, c_dp] + tab + [c_vp]
     lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
     lib.dqc_ncart.argtypes = [ip, c_int]
@@ -325,6 +326,16 @@ def jk(tiles, dm_ao, work, with_k=True):
     with _on(dm_ao.device) as st_:
         _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
                                         st_), "dqc_jk_from_tiles")
+    return J, K
+
+
+def jk_direct(tab, dm_ao, with_k=True):
+    """direct SCF: J, K (K = None if not with_k) of one AO density straight from the shell quartets (no tile store)"""
+    nao = dm_ao.shape[-1]
+    J = torch.empty((nao, nao), dtype=torch.float64, device=dm_ao.device)
+    K = torch.empty_like(J) if with_k else None
+    with _on(dm_ao.device) as st_:
+        _check(load().dqc_jk_direct(_ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), *tab.args(), st_), "dqc_jk_direct")
     return J, K
 
 

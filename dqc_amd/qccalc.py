@@ -187,7 +187,8 @@ class SCF_QCCalc:
         # "diag": "purify" (default for closed shells) replaces eigh by GEMM-only purification inside the same graph
         # (dqc_amd/purify.py); "eigh" keeps the reference's diagonalise-and-occupy step (hf.py:105-113)
         graphed, purified = None, None
-        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0"):
+        # (direct SCF builds allocate stream-ordered scratch and upload pair tables per call: not captured)
+        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "_direct", False):
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)

@@ -243,6 +243,15 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
                       const double *d_w, const double *d_v, void *stream);
 
+/* ---- direct SCF: J and K straight from the shell quartets, nothing stored  ("direct / recompute above") ----
+ * The stored tile form needs ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, beyond one GPU near nao 740); this entry point
+ * re-evaluates every unique shell quartet (the Rys kernel of dqc_eri_fill_tiles) and contracts it with the density on the fly:
+ *   d_J (nao, nao) <- sum_kl (ij|kl) D_kl,   d_K (nao, nao) <- sum_jl (ij|kl) D_jl   (plain K, not -K/2; d_K may be NULL),
+ * D = the symmetric part of d_dm (nao, nao), AO basis.  Same einsum strings as dqc_jk_from_tiles (hcgto.py:209, 234) at the
+ * cost of one integral evaluation per call.  fp64 atomics (not covered by the deterministic mode).  Enqueues only. */
+int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, int natm, const int *bas, int nbas,
+                  const double *env, int nenv, void *stream);
+
 /* ---- deterministic mode ----------------------------------------------------------------------
  * The Fock build sums over blocks with fp64 atomics (J / K accumulators, split-K Vxc partials, the trace of the purification
  * iterate): the order of the additions, hence the last bits of the result, vary from run to run, while the reference's CPU
