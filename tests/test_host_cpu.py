@@ -199,6 +199,43 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     assert rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2
 
 
+def test_run_lockstep_buckets_and_groups_on_cpu(monkeypatch):
+    """host logic of batch.run_lockstep: calculations are bucketed by (device, nao, n_occ, occupation), cut into equal groups of at
+    most group_size (at least `inflight` of them), and whatever does not qualify -- unrestricted, non-uniform occupations, raw
+    AO basis, a bucket of one -- goes to the one-molecule driver (the reference has no batching at all)"""
+    import types
+    from dqc_amd import batch, lockstep
+
+    def fake(n, r, pol=False, w=None, ovlp=None):
+        eng = types.SimpleNamespace(polarized=pol, ovlp=ovlp, orb_weight=torch.full((r,), 2.0) if w is None else w,
+                                    shape=(n, n), norb=r, device=torch.device("cpu"))
+        return types.SimpleNamespace(_engine=eng)
+
+    qcs = [fake(24, 5) for _ in range(9)] + [fake(114, 21) for _ in range(70)] + [fake(208, 46)] + [fake(24, 5, pol=True)] + \
+          [fake(24, 5, w=torch.tensor([2.0, 2.0, 2.0, 1.0, 1.0]))] + [fake(24, 5, ovlp=torch.eye(24))]
+    assert lockstep.signature(qcs[0]) == ("cpu", 24, 5, 2.0) and lockstep.signature(qcs[-1]) is None
+    made, conc = [], []
+
+    class FakeGroup:
+        def __init__(self, members, nstreams=3):
+            self.members, self.nstreams = members, nstreams
+            made.append(self)
+
+    monkeypatch.setattr(lockstep, "LockstepSCF", FakeGroup)
+    monkeypatch.setattr(batch, "run_concurrent", lambda objs, **kw: conc.append((list(objs), kw)))
+    out = batch.run_lockstep(qcs)
+    assert out is qcs
+    sizes = sorted(len(g.members) for g in made)
+    assert sizes == [4, 5, 22, 24, 24]           # 9 tiny molecules -> 2 groups (inflight), 70 benzene-size -> 3 groups of <= 32
+    assert all(g.nstreams == 4 for g in made)     # graph-replayed builds: 4 streams per group
+    assert conc[0][0] == made and conc[0][1]["max_inflight"] == 2
+    assert len(conc[1][0]) == 4                   # the C5-size singleton, the unrestricted, the open-shell and the raw-basis one
+    made.clear(), conc.clear()
+    batch.run_lockstep([fake(208, 46) for _ in range(32)])
+    assert sorted(len(g.members) for g in made) == [16, 16] and all(g.nstreams == 3 for g in made)
+    assert batch.molecule_bytes(208, 353400) > 4.3e9 and batch.molecule_bytes(208, 353400) < 5.0e9
+
+
 def test_cart2sph_matrix_host_function():
     """dqc_cart2sph_matrix (host-side, no GPU): block-diagonal solid-harmonic matrix == the oracle's per-shell tables"""
     import ctypes
