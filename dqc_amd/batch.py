@@ -22,6 +22,7 @@ def molecule_bytes(nao: int, ngrid: int, ncomp: int = 4) -> int:
     nb = (nao + 7) // 8
     npair = nb * (nb + 1) // 2
     ld = (nao + 15) // 16 * 16 + 16
+    # (an upper bound of the packed store: full 8^4 tiles)
     return npair * (npair + 1) // 2 * 4096 * 8 + 8 * ncomp * ngrid * ld + 8 * 16 * ngrid + 64 * ld * ld
 
 

@@ -46,8 +46,8 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
         if ((c >> 3) < (d >> 3)) { int t = c; c = d; d = t; }
         int IJ = (a >> 3) * ((a >> 3) + 1) / 2 + (b >> 3), KL = (c >> 3) * ((c >> 3) + 1) / 2 + (d >> 3);
         if (IJ < KL) { int t = a; a = c; c = t; t = b; b = d; d = t; t = IJ; IJ = KL; KL = t; }
-        const size_t T = (size_t)IJ * (IJ + 1) / 2 + KL;
-        dense[e] = tiles[T * DQC_TILE_SZ + ((((a & 7) * 8 + (b & 7)) * 8 + (c & 7)) * 8 + (d & 7))];
+        const int A = a >> 3, B = b >> 3, Cb = c >> 3, Db = d >> 3;
+        dense[e] = tiles[tile_base(A, B, Cb, KL) + (long long)tile_pidx(A == B, a & 7, b & 7) * tile_dim(Cb == Db) + tile_pidx(Cb == Db, c & 7, d & 7)];
     }
 }
 
@@ -65,8 +65,9 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)Cfg::LDS_BYTES);
+    EriOut og{0, 0, 0, 0};
     hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
-                       dp, hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask, EriOut{0, 0, 0, 0});
+                       dp, hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask, og);
     DQC_CHECK_LAUNCH();
     return 0;
 }
@@ -192,8 +193,8 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     if (rc) return rc;
     for (const HostShell &s : b.shells)
         if (s.l > ERI_LMAX) { set_error("dqc_eri_fill_tiles: shells above f are not supported"); return DQC_EINVAL; }
-    DQC_HIP(hipMemsetAsync(d_tiles, 0, sizeof(double) * DQC_TILE_SZ * dqc_eri_tile_count(b.nao), st));
-    if (nbas == 0) return DQC_OK;
+    if (nbas == 0 || b.nao == 0) return DQC_OK;
+    DQC_HIP(hipMemsetAsync(d_tiles, 0, sizeof(double) * (size_t)eri_store_data_doubles(b.nao), st));  // packed store (common.hpp)
     if ((rc = boys_table_ensure())) return rc;
     HostPairs hp;
     build_pairs(b, hp);

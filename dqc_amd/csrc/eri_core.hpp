@@ -63,13 +63,17 @@ struct DevPairs {
 
 __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
 
+// one image (i, j, k, l) of an integral into the packed tile store (common.hpp): block-canonical images only, and inside a
+// diagonal block pair only the a >= b element (the other image of the same integral writes nothing)
 DQC_DEV void tile_put(double *__restrict__ tiles, int i, int j, int k, int l, double v) {
     const int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
     if (I < J || K < L) return;
     const int IJ = I * (I + 1) / 2 + J, KL = K * (K + 1) / 2 + L;
     if (IJ < KL) return;
-    const size_t T = (size_t)IJ * (IJ + 1) / 2 + KL;
-    tiles[T * DQC_TILE_SZ + ((((i & 7) * 8 + (j & 7)) * 8 + (k & 7)) * 8 + (l & 7))] = v;
+    const int il = i & 7, jl = j & 7, kl = k & 7, ll = l & 7;
+    if ((I == J && il < jl) || (K == L && kl < ll)) return;
+    const int C = tile_dim(K == L);
+    tiles[tile_base(I, J, K, KL) + (long long)tile_pidx(I == J, il, jl) * C + tile_pidx(K == L, kl, ll)] = v;
 }
 
 template <int LA, int LB, int LC, int LD>

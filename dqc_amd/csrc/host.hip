@@ -163,6 +163,11 @@ int dqc_padded_nao(int nao) {
     return ld;
 }
 
+size_t dqc_eri_store_doubles(int nao) {
+    // doubles of the packed tile store (common.hpp): what dqc_eri_fill_tiles writes
+    return nao <= 0 ? 0 : (size_t)dqc::eri_store_data_doubles(nao);
+}
+
 size_t dqc_eri_tile_count(int nao) {
     size_t nb = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B;
     size_t np = nb * (nb + 1) / 2;

@@ -29,6 +29,43 @@ DQC_DEV void decode_tri(long long t, int &a, int &b) {  // t = a(a+1)/2 + b, b <
     b = (int)(t - r * (r + 1) / 2);
 }
 
+// this thread's 4 x 4 patch -- rows r0 .. r0 + 3, columns c0 .. c0 + 3 of the FULL 64 x 64 view g[(i,j)][(k,l)] -- of tile
+// (IJ, KL) of the packed store (common.hpp).  A plain tile is read as four pairs of 16-byte loads.  A tile with a diagonal block
+// pair keeps only its a >= b rows / columns: every element is fetched through its packed index, the a < b ones from their
+// a > b twins -- the same cache lines, so HBM delivers the packed size -- and the arithmetic downstream (the 1/2 weights of
+// the diagonal pairs) is that of the full view, unchanged.
+DQC_DEV void tile_load_patch(const double *__restrict__ tiles, int IJ, int KL, int I, int J, int K, int L, int r0, int c0, double2 &a0, double2 &b0, double2 &a1, double2 &b1, double2 &a2,
+                             double2 &b2, double2 &a3, double2 &b3) {
+    const bool dr = I == J, dc = K == L;
+    const double *tp = tiles + tile_base(I, J, K, KL);
+    if (!dr && !dc) {
+        const double *q = tp + r0 * 64 + c0;
+        a0 = *reinterpret_cast<const double2 *>(q);       b0 = *reinterpret_cast<const double2 *>(q + 2);
+        a1 = *reinterpret_cast<const double2 *>(q + 64);  b1 = *reinterpret_cast<const double2 *>(q + 66);
+        a2 = *reinterpret_cast<const double2 *>(q + 128); b2 = *reinterpret_cast<const double2 *>(q + 130);
+        a3 = *reinterpret_cast<const double2 *>(q + 192); b3 = *reinterpret_cast<const double2 *>(q + 194);
+        return;
+    }
+    const int il = r0 >> 3, j0 = r0 & 7, kl = c0 >> 3, l0 = c0 & 7;
+    if (!dc) {  // only the rows are packed: the four columns stay contiguous and 16-byte aligned
+        const double *q0 = tp + tile_pidx(true, il, j0) * 64 + c0, *q1 = tp + tile_pidx(true, il, j0 + 1) * 64 + c0;
+        const double *q2 = tp + tile_pidx(true, il, j0 + 2) * 64 + c0, *q3 = tp + tile_pidx(true, il, j0 + 3) * 64 + c0;
+        a0 = *reinterpret_cast<const double2 *>(q0); b0 = *reinterpret_cast<const double2 *>(q0 + 2);
+        a1 = *reinterpret_cast<const double2 *>(q1); b1 = *reinterpret_cast<const double2 *>(q1 + 2);
+        a2 = *reinterpret_cast<const double2 *>(q2); b2 = *reinterpret_cast<const double2 *>(q2 + 2);
+        a3 = *reinterpret_cast<const double2 *>(q3); b3 = *reinterpret_cast<const double2 *>(q3 + 2);
+        return;
+    }
+    const int C = 36;
+    const int pc0 = tile_pidx(dc, kl, l0), pc1 = tile_pidx(dc, kl, l0 + 1), pc2 = tile_pidx(dc, kl, l0 + 2), pc3 = tile_pidx(dc, kl, l0 + 3);
+    const double *q0 = tp + tile_pidx(dr, il, j0) * C, *q1 = tp + tile_pidx(dr, il, j0 + 1) * C;
+    const double *q2 = tp + tile_pidx(dr, il, j0 + 2) * C, *q3 = tp + tile_pidx(dr, il, j0 + 3) * C;
+    a0 = make_double2(q0[pc0], q0[pc1]); b0 = make_double2(q0[pc2], q0[pc3]);
+    a1 = make_double2(q1[pc0], q1[pc1]); b1 = make_double2(q1[pc2], q1[pc3]);
+    a2 = make_double2(q2[pc0], q2[pc1]); b2 = make_double2(q2[pc2], q2[pc3]);
+    a3 = make_double2(q3[pc0], q3[pc1]); b3 = make_double2(q3[pc2], q3[pc3]);
+}
+
 __global__ void jk_prep_kernel(double *__restrict__ work, const double *__restrict__ dm, int nao, int npad, int with_k) {
     const size_t n2 = (size_t)npad * npad;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (size_t)gridDim.x * blockDim.x) {
@@ -76,8 +113,9 @@ __global__ __launch_bounds__(256) void jk_det_scale_kernel(double *__restrict__ 
     }
     double g = 0.0;
     for (int i = t; i < nao; i += 256) {
-        const long long b = i >> 3, a = i & 7, IJ = b * (b + 1) / 2 + b, T = IJ * (IJ + 1) / 2 + IJ;
-        g = fmax(g, fabs(tiles[(size_t)T * DQC_TILE_SZ + (((a * 8 + a) * 8 + a) * 8 + a)]));
+        const long long b = i >> 3, IJ = b * (b + 1) / 2 + b;  // (ii|ii): tile (IJ, IJ) of the diagonal block pair (b, b)
+        const int pa = tile_pidx(true, i & 7, i & 7);
+        g = fmax(g, fabs(tiles[tile_base((int)b, (int)b, (int)b, (int)IJ) + pa * 36 + pa]));
     }
     red[t] = g;
     __syncthreads();
@@ -92,8 +130,8 @@ __global__ __launch_bounds__(256) void jk_det_scale_kernel(double *__restrict__ 
 }
 
 template <bool WITH_K>
-__global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work,
-                                                       int npad, long long ntiles) {
+__global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
+                                                       double *__restrict__ work, int npad, long long ntiles) {
     const double dsc = dscp ? *dscp : 0.0;  // deterministic mode: fixed-point scale of the accumulators (common.hpp: acc_add)
     constexpr int LDT = 68;  // row stride of the tile parked in LDS: 16-byte aligned rows, bank = 4 row + col (mod 32)
     __shared__ double s_col[4][64];
@@ -113,7 +151,6 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
         decode_tri(IJ, I, J);
         decode_tri(KL, K, L);
         const double f = (I == J ? 0.5 : 1.0) * (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
-        const double *tp = tiles + (size_t)T * DQC_TILE_SZ;
         // D[K,L](k,l) for the 4 columns, D[I,J](i,j) for the 4 rows of this thread's patch
         const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
         const double *dklp = Dp + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
@@ -123,11 +160,13 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
         for (int q = 0; q < 4; q++) { dkl[q] = dklp[q]; dij[q] = dijp[q]; }
         double rs[4] = {0, 0, 0, 0}, cs[4] = {0, 0, 0, 0};
         double g[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double2 a = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0);
-            const double2 b = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0 + 2);
-            g[r][0] = a.x; g[r][1] = a.y; g[r][2] = b.x; g[r][3] = b.y;
+        {
+            double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+            g[0][0] = ta0.x; g[0][1] = ta0.y; g[0][2] = tb0.x; g[0][3] = tb0.y;
+            g[1][0] = ta1.x; g[1][1] = ta1.y; g[1][2] = tb1.x; g[1][3] = tb1.y;
+            g[2][0] = ta2.x; g[2][1] = ta2.y; g[2][2] = tb2.x; g[2][3] = tb2.y;
+            g[3][0] = ta3.x; g[3][1] = ta3.y; g[3][2] = tb3.x; g[3][3] = tb3.y;
         }
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -227,8 +266,8 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
 // work layout (n2 = npad^2 doubles each):  Dj[nj] | Dk[NK] | Jacc[nj] | Kacc[NK].
 // ---------------------------------------------------------------------------------------------
 template <int NK>
-__global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work,
-                                                                   int npad, long long ntiles, int nj) {
+__global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
+                                                                   double *__restrict__ work, int npad, long long ntiles, int nj) {
     const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     constexpr int NKD = NK ? NK : 1;
@@ -247,11 +286,11 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
     double2 na0, na1, na2, na3, nb0, nb1, nb2, nb3;
 #define JKM_LOAD(TT)                                                                     \
     {                                                                                    \
-        const double *tq_ = tiles + (size_t)(TT) * DQC_TILE_SZ + r0 * 64 + c0;             \
-        na0 = *reinterpret_cast<const double2 *>(tq_);       nb0 = *reinterpret_cast<const double2 *>(tq_ + 2);       \
-        na1 = *reinterpret_cast<const double2 *>(tq_ + 64);  nb1 = *reinterpret_cast<const double2 *>(tq_ + 66);      \
-        na2 = *reinterpret_cast<const double2 *>(tq_ + 128); nb2 = *reinterpret_cast<const double2 *>(tq_ + 130);     \
-        na3 = *reinterpret_cast<const double2 *>(tq_ + 192); nb3 = *reinterpret_cast<const double2 *>(tq_ + 194);     \
+        int ij_, kl_, i_, j_, k_, l_;                                                    \
+        decode_tri((TT), ij_, kl_);                                                      \
+        decode_tri(ij_, i_, j_);                                                         \
+        decode_tri(kl_, k_, l_);                                                         \
+        tile_load_patch(tiles, ij_, kl_, i_, j_, k_, l_, r0, c0, na0, nb0, na1, nb1, na2, nb2, na3, nb3); \
     }
     if ((long long)blockIdx.x < ntiles) JKM_LOAD(blockIdx.x)
     for (long long T = blockIdx.x; T < ntiles; T += gridDim.x) {
@@ -417,8 +456,8 @@ __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *_
 // disappear; D[I,J] is reloaded only when IJ changes.  The column sums J[K,L] += g . D[I,J] change target every tile and
 // keep the 2-shuffle + 4-wave LDS combine of jk_tiles_kernel.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles, double *__restrict__ work, int npad,
-                                                         long long ntiles, long long per_block) {
+__global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
+                                                         double *__restrict__ work, int npad, long long ntiles, long long per_block) {
     const double dsc = dscp ? *dscp : 0.0;
     __shared__ double s_col[2][4][64];
     const size_t n2 = (size_t)npad * npad;
@@ -462,19 +501,19 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
         decode_tri(KL, K, L);
         // factors of the unique-tile weights: (I == J) is applied at the flush, (K == L) and (IJ == KL) here
         const double fk = (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
-        const double *tp = tiles + (size_t)T * DQC_TILE_SZ;
         const double *dklp = Dp + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
         double dkl[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) dkl[q] = fk * dklp[q];
         double cs[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double2 a = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0);
-            const double2 b = *reinterpret_cast<const double2 *>(tp + (r0 + r) * 64 + c0 + 2);
-            const double g0 = a.x, g1 = a.y, g2 = b.x, g3 = b.y;
-            rsacc[r] += g0 * dkl[0] + g1 * dkl[1] + g2 * dkl[2] + g3 * dkl[3];
-            cs[0] += g0 * dij[r]; cs[1] += g1 * dij[r]; cs[2] += g2 * dij[r]; cs[3] += g3 * dij[r];
+        {
+            double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+#define DQC_JS_ROW(R_, A_, B_)                                                                           \
+    rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                          \
+    cs[0] += A_.x * dij[R_]; cs[1] += A_.y * dij[R_]; cs[2] += B_.x * dij[R_]; cs[3] += B_.y * dij[R_];
+            DQC_JS_ROW(0, ta0, tb0) DQC_JS_ROW(1, ta1, tb1) DQC_JS_ROW(2, ta2, tb2) DQC_JS_ROW(3, ta3, tb3)
+#undef DQC_JS_ROW
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) {

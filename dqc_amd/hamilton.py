@@ -162,7 +162,7 @@ class HamiltonMI355(_Base):
         if self._df is None:
             # exact J/K keeps the 8-fold-unique 8^4 tiles resident: ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, > 288 GB
             # near nao 740).  Fail with a message instead of an allocator OOM deep inside the fill.
-            need = int(lib.load().dqc_eri_tile_count(tab.nao)) * 4096 * 8
+            need = lib.eri_store_doubles(tab.nao) * 8
             free, _total = torch.cuda.mem_get_info(dev)
             free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)  # blocks cached by the allocator are reusable
             mode = self._eri_mode

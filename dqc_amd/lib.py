@@ -46,6 +46,9 @@ def load():
     lib.dqc_padded_nao.argtypes = [c_int]
     lib.dqc_eri_tile_count.argtypes = [c_int]
     lib.dqc_eri_tile_count.restype = c_sz
+    if hasattr(lib, "dqc_eri_store_doubles"):  # (absent from the pre-packing A/B build tools/gpu_jk_ab.py loads)
+        lib.dqc_eri_store_doubles.argtypes = [c_int]
+        lib.dqc_eri_store_doubles.restype = c_sz
     lib.dqc_jk_work_doubles.argtypes = [c_int]
     lib.dqc_jk_work_doubles.restype = c_sz
     tab = [ip, c_int, ip, c_int, dp, c_int]
@@ -169,9 +172,13 @@ def int1e(which, tab, device, zs=None):
     return out
 
 
+def eri_store_doubles(nao):
+    """doubles of the packed ERI tile store of `nao` functions"""
+    return int(load().dqc_eri_store_doubles(int(nao)))
+
+
 def eri_tiles(tab, device):
-    ntile = load().dqc_eri_tile_count(tab.nao)
-    tiles = torch.empty(ntile * 4096, dtype=torch.float64, device=device)
+    tiles = torch.empty(eri_store_doubles(tab.nao), dtype=torch.float64, device=device)  # packed tiles
     with _on(device) as st_:
         _check(load().dqc_eri_fill_tiles(_ptr(tiles), *tab.args(), st_), "dqc_eri_fill_tiles")
     return tiles

@@ -50,10 +50,16 @@ int dqc_int1e(int which, double *d_out, const int *atm, int natm, const int *bas
  * Replaces GTOnr2e_fill_drv(int2e_sph, GTOnr2e_fill_s4, prescreen=NULL, ...) + CSYMM().fills4
  * (molintor.py:667-688, symmetry.py:40-69).  Instead of the reference's packed (npair,npair)
  * buffer expanded to a dense nao^4 tensor, the integrals stay on the device in 8-fold-unique
- * TILE storage: AOs are grouped in blocks of 8; tile (I>=J, K>=L, IJ>=KL) holds the full
- * 8x8x8x8 sub-tensor g[i][j][k][l] contiguously (4096 doubles).  dqc_eri_tile_count gives the
- * number of tiles; the buffer must hold 4096*count doubles and is fully overwritten. */
+ * TILE storage: AOs are grouped in blocks of 8; tile (I>=J, K>=L, IJ>=KL) holds the sub-tensor
+ * g[(i,j)][(k,l)] contiguously, R(IJ) rows x C(KL) columns.  PACKED since round 3 (symmetry.py:40-69 packs s4; here the
+ * 8-fold symmetry is packed at block AND element level): a diagonal block pair (I == J, resp. K == L) keeps only its
+ * i >= j (k >= l) elements -- 36 rows (columns), index i (i + 1) / 2 + j -- any other pair all 64 (index 8 i + j).  Tile
+ * (IJ, KL) starts at off(I, J) + R(IJ) * (64 KL - 28 K), off(I, J) = 8 I (64 I^3 + 16 I^2 + 129 I - 47) + 256 J (8 I^2 + I + 8 J + 8)
+ * (the prefix sum of the tile sizes over the block pairs before (I, J)).  dqc_eri_store_doubles(nao) = what d_tiles must hold
+ * (1.895 GB at nao 208; nao^4 / 8 doubles = 1.872 GB is the ideal, full 8^4 tiles were 2.024 GB); dqc_eri_tile_count = number
+ * of tiles.  Fully overwritten; enqueues only. */
 size_t dqc_eri_tile_count(int nao);
+size_t dqc_eri_store_doubles(int nao);
 int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas, int nbas,
                        const double *env, int nenv, void *stream);
 /* expand the tiles into the reference's dense (nao,nao,nao,nao) tensor (tests / small nao only) */

@@ -33,6 +33,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     nb = 26
     npair = nb * (nb + 1) // 2
     assert L.dqc_eri_tile_count(208) == npair * (npair + 1) // 2
+    L.dqc_eri_store_doubles.restype = ctypes.c_size_t
+    # packed store: diagonal block pairs keep 36 of their 64 rows / columns
+    assert L.dqc_eri_store_doubles(7) == 36 * 36 and L.dqc_eri_store_doubles(16) == 36 * 36 + 64 * (36 + 64) + 36 * (36 + 64 + 36)
+    assert 0.93 < L.dqc_eri_store_doubles(208) / (L.dqc_eri_tile_count(208) * 4096) < 0.94
     assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8 + 8  # D, J, K accumulators + the deterministic-mode scale slot
 
 

@@ -17,7 +17,7 @@ for name, geo, basis in (("C5", M.c5_molecule(0), "cc-pvdz"), ("C4", M.naphthale
     h = dqc_amd.Mol(geo, basis=basis).get_hamiltonian()
     tab = h._tab
     D = torch.as_tensor(M.seeded_dm_ao(tab.nao, 60, np.eye(tab.nao), 3), device=dev)
-    tiles = torch.empty(lib.load().dqc_eri_tile_count(tab.nao) * 4096, dtype=torch.float64, device=dev)
+    tiles = torch.empty(lib.eri_store_doubles(tab.nao), dtype=torch.float64, device=dev)
     def fill():
         with lib._on(dev) as st_:
             lib._check(lib.load().dqc_eri_fill_tiles(lib._ptr(tiles), *tab.args(), st_), "fill")
@@ -40,7 +40,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "big":
     h = mol.get_hamiltonian()
     torch.cuda.synchronize()
     print("naphthalene dimer / cc-pVTZ: nao %d, tile store would be %.0f GB -> direct %s; setup %.1f s" % (
-        h._nao_ao, lib.load().dqc_eri_tile_count(h._nao_ao) * 32768 / 1e9, h._direct, time.perf_counter() - t0))
+        h._nao_ao, lib.eri_store_doubles(h._nao_ao) * 8 / 1e9, h._direct, time.perf_counter() - t0))
     t0 = time.perf_counter()
     qc.run(fwd_options={"maxiter": int(sys.argv[2]) if len(sys.argv) > 2 else 6})
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ from tests import molecules as M
 h = dqc_amd.Mol(M.naphthalene(), basis="cc-pvtz").get_hamiltonian()
 tab = h._tab
 L = lib.load()
-tiles = torch.empty(L.dqc_eri_tile_count(tab.nao) * 4096, dtype=torch.float64, device="cuda")
+tiles = torch.empty(lib.eri_store_doubles(tab.nao), dtype=torch.float64, device="cuda")
 for _ in range(3):
     with lib._on(tiles.device) as st_:
         lib._check(L.dqc_eri_fill_tiles(lib._ptr(tiles), *tab.args(), st_), "fill")
