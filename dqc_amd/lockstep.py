@@ -18,8 +18,9 @@ A molecule that has converged is frozen (its Fock builds stop; its slot in the s
 done.  Same numbers as the one-molecule driver (dqc_amd/qccalc.py) up to round-off: same error vector, same history
 length, same least-squares Pulay solve, same purification.
 
-Restricted closed-shell (uniform occupations) engines in an orthogonalised basis only; `signature(qc)` says whether a
-calculation qualifies -- everything else keeps the one-molecule driver (`batch.run_lockstep` sorts that out)."""
+Restricted closed-shell and unrestricted (stacked F_u, F_d; hf.py:93-103) engines with uniform occupations per spin channel in
+an orthogonalised basis; `signature(qc)` says whether a calculation qualifies -- everything else (restricted open-shell,
+fractional occupations, raw AO bases) keeps the one-molecule driver (`batch.run_lockstep` sorts that out)."""
 import os
 import warnings
 
@@ -27,20 +28,38 @@ import torch
 
 from . import lib
 from .purify import _TC2_ITERS
+from .utils.datastruct import SpinParam
+
+
+def _spin_channels(eng):
+    """[(n_occ, occupation)] per spin channel (one entry for a restricted engine), or None when a channel's occupations are
+    not uniform; an empty channel (the reference keeps one orbital of weight 0 there, mol.py:437-441) counts as n_occ = 0"""
+    ws = [eng.orb_weight.u, eng.orb_weight.d] if eng.polarized else [eng.orb_weight]
+    out = []
+    for w in ws:
+        if not w.numel() or bool((w == 0).all()):
+            out.append((0, 0.0))
+        elif bool((w == w[0]).all()):
+            out.append((int(w.numel()), float(w[0])))
+        else:
+            return None
+    return out
 
 
 def signature(qc):
     """key under which calculations can share a lockstep batch, or None when the calculation needs the one-molecule driver"""
     eng = qc._engine
-    if eng.polarized or getattr(eng, "ovlp", None) is not None:
+    if getattr(eng, "ovlp", None) is not None:
         return None
-    w = eng.orb_weight
-    if not w.numel() or not bool((w == w[0]).all()):
+    ch = _spin_channels(eng)
+    if ch is None:
         return None
-    n, r = int(eng.shape[-1]), int(eng.norb)
-    if not (0 < r <= 128 and r < n):
+    n = int(eng.shape[-1])
+    if any(not (r <= 128 and r < n) for r, _ in ch) or all(r == 0 for r, _ in ch):
         return None
-    return (str(eng.device), n, r, float(w[0]))
+    if not eng.polarized:
+        return (str(eng.device), n, ch[0][0], ch[0][1])
+    return (str(eng.device), n, tuple(r for r, _ in ch), tuple(o for _, o in ch))
 
 
 def projectors_from_focks(focks, nocc, iters=None, tol=1e-13):
@@ -81,24 +100,27 @@ class LockstepSCF:
     def __init__(self, qcs, nstreams: int = 3, graph="auto"):
         sigs = {signature(q) for q in qcs}
         if len(sigs) != 1 or None in sigs:
-            raise ValueError("LockstepSCF needs restricted closed-shell calculations of one (device, nao, n_occ) signature")
+            raise ValueError("LockstepSCF needs calculations of one (device, nao, n_occ per spin) signature with uniform occupations")
         self.qcs = list(qcs)
         self.engines = [q._engine for q in qcs]
         e0 = self.engines[0]
         self.device, self.dtype = e0.device, e0.dtype
         self._engine = e0  # (batch.run_concurrent reads the device from here)
-        self.n, self.r = int(e0.shape[-1]), int(e0.norb)
-        self.occ = float(e0.orb_weight[0])
+        self.pol = bool(e0.polarized)
+        self.channels = _spin_channels(e0)            # [(n_occ, occupation)] per spin
+        self.S = len(self.channels)
+        self.n = int(e0.shape[-1])
+        self.r = self.channels[0][0]
         self.nstreams = max(1, min(nstreams, len(qcs)))
         self._graphs = None
         # the per-molecule Fock build replays as a hipGraph where it is launch-bound (small molecules: ~30 launches for
         # 0.1-0.4 ms of kernels); a 20-atom build (1.4 ms of kernels) is issued eagerly -- capturing 32 graphs would cost
         # more than the launches they save
-        self.use_graph = (self.n <= 160) if graph == "auto" else bool(graph)
+        self.use_graph = ((self.n <= 160) if graph == "auto" else bool(graph)) and not self.pol  # (GraphedFock is restricted-only)
         if any(getattr(e.hamilton, "_direct", False) for e in self.engines):
             self.use_graph = False  # direct SCF builds are not capturable (per-call scratch and table uploads)
         gen = torch.Generator().manual_seed(20240229)
-        self.omega = torch.randn((self.n, self.r), dtype=self.dtype, generator=gen).to(self.device)
+        self.omega = [torch.randn((self.n, r), dtype=self.dtype, generator=gen).to(self.device) if r else None for r, _ in self.channels]
         self.eigh_fallbacks = 0
 
     # ------------------------------------------------------------------ pieces
@@ -109,24 +131,38 @@ class LockstepSCF:
         return self._graphs
 
     def _occupied(self, fmix):
-        """(Q (M, n, r) orthonormal occupied-space bases of the Fock matrices, err (M,)) without an eigensolver"""
-        p, err = projectors_from_focks(fmix, self.r)
-        y = torch.matmul(p, self.omega)
-        g = torch.bmm(y.transpose(-2, -1), y)
-        q = lib.orth_factor_batched(y, g)
-        # a failed factorisation (NaN / wrong range) must show in the error so that the molecule falls back to eigh
-        ferr = (torch.bmm(q, q.transpose(-2, -1)) - p).abs().amax((-2, -1))
-        return q, err + ferr
+        """fmix (M, S, n, n) -> ([Q_s (M, n, r_s) orthonormal occupied-space bases per spin channel, None for an empty one],
+        err (M,)) without an eigensolver"""
+        qs, err = [], 0.0
+        for s_, (r, _) in enumerate(self.channels):
+            if r == 0:
+                qs.append(None)
+                continue
+            p, e = projectors_from_focks(fmix[:, s_].contiguous(), r)
+            y = torch.matmul(p, self.omega[s_])
+            g = torch.bmm(y.transpose(-2, -1), y)
+            q = lib.orth_factor_batched(y, g)
+            # a failed factorisation (NaN / wrong range) must show in the error so that the molecule falls back to eigh
+            err = err + e + (torch.bmm(q, q.transpose(-2, -1)) - p).abs().amax((-2, -1))
+            qs.append(q)
+        return qs, err
+
+    def _eigh_orbitals(self, m, fmix_m, qs):
+        """orbitals of molecule m from eigh (hf.py:227-247) into the stacked bases"""
+        for s_, (r, _) in enumerate(self.channels):
+            if r:
+                qs[s_][m].copy_(self.engines[m]._eigvecs(fmix_m[s_])[..., :r])
 
     def occupied_orbitals(self, focks):
-        """orthonormal occupied orbitals (M, n, n_occ) of the stacked Fock matrices -- the `diagonalize` step of hf.py:227-247
-        for the whole batch, eigensolver-free; a matrix whose purification fails (no gap) goes through eigh.  Synchronises."""
-        q, err = self._occupied(focks)
-        bad = (~(err < 1e-9)).nonzero().reshape(-1).tolist()
-        for m in bad:
-            q[m].copy_(self.engines[m].scp2orb(focks[m]))
+        """orthonormal occupied orbitals (M, n, n_occ) of the stacked Fock matrices (restricted batches: (M, n, n) in) -- the
+        `diagonalize` step of hf.py:227-247 for the whole batch, eigensolver-free; a matrix whose purification fails (no gap) goes
+        through eigh.  Synchronises."""
+        f4 = focks if focks.dim() == 4 else focks.unsqueeze(1)
+        qs, err = self._occupied(f4)
+        for m in (~(err < 1e-9)).nonzero().reshape(-1).tolist():
+            self._eigh_orbitals(m, f4[m], qs)
             self.eigh_fallbacks += 1
-        return q
+        return qs[0] if focks.dim() == 3 else qs
 
     def _build(self, q, active, fock, dm, etot, streams):
         """fock[m], dm[m], etot[m] <- Fock build (and total energy) of the orbitals q[m] for the active molecules, dealt to the
@@ -141,17 +177,25 @@ class LockstepSCF:
             with torch.cuda.stream(s):
                 if graphs is not None:
                     g = graphs[m]
-                    g.orb.copy_(q[m])
+                    g.orb.copy_(q[0][m])
                     g.graph.replay()
-                    fock[m].copy_(g.fock)
-                    dm[m].copy_(g.dm)
+                    fock[m, 0].copy_(g.fock)
+                    dm[m, 0].copy_(g.dm)
                     etot[m].copy_(g.energy)
-                else:  # hf.py:105-113 (ao_orb2dm) + the Fock build, as the one-molecule driver issues them
+                elif not self.pol:  # hf.py:105-113 (ao_orb2dm) + the Fock build, as the one-molecule driver issues them
                     e = self.engines[m]
-                    d = e.hamilton.ao_orb2dm(q[m], e.orb_weight)
-                    fock[m].copy_(e.dm2scp(d))
-                    dm[m].copy_(d)
+                    d = e.hamilton.ao_orb2dm(q[0][m], e.orb_weight)
+                    fock[m, 0].copy_(e.dm2scp(d))
+                    dm[m, 0].copy_(d)
                     etot[m].copy_(e.dm2energy(d))  # by-products of the build just made + tr(D h): no second pass
+                else:  # unrestricted (hf.py:93-103): D_u, D_d from their own orbitals, stacked (F_u, F_d) back
+                    e = self.engines[m]
+                    ws = (e.orb_weight.u, e.orb_weight.d)
+                    ds = [e.hamilton.ao_orb2dm(q[s_][m], ws[s_]) if q[s_] is not None else torch.zeros_like(dm[m, s_])
+                          for s_ in range(2)]
+                    fock[m].copy_(e.dm2scp(SpinParam(u=ds[0], d=ds[1])))
+                    dm[m, 0].copy_(ds[0])
+                    dm[m, 1].copy_(ds[1])
         for s in streams[:min(len(streams), len(active))]:
             main.wait_stream(s)
 
@@ -174,13 +218,13 @@ class LockstepSCF:
         opts = {"maxiter": 50, "f_tol": 1e-9, "history": 12}
         opts.update(fwd_options or {})
         H = int(opts["history"])
-        M, n, dev, dt = len(self.qcs), self.n, self.device, self.dtype
+        M, n, S, dev, dt = len(self.qcs), self.n, self.S, self.device, self.dtype
         main = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(device=dev) for _ in range(self.nstreams)]
-        fock = torch.empty((M, n, n), dtype=dt, device=dev)
-        dm = torch.empty((M, n, n), dtype=dt, device=dev)
-        fh = torch.zeros((M, H, n * n), dtype=dt, device=dev)
-        eh = torch.zeros((M, H, n * n), dtype=dt, device=dev)
+        fock = torch.empty((M, S, n, n), dtype=dt, device=dev)   # S = 1 restricted, 2 unrestricted (stacked F_u, F_d: hf.py:93-103)
+        dm = torch.empty((M, S, n, n), dtype=dt, device=dev)
+        fh = torch.zeros((M, H, S * n * n), dtype=dt, device=dev)
+        eh = torch.zeros((M, H, S * n * n), dtype=dt, device=dev)
         gram = torch.zeros((M, H, H), dtype=dt, device=dev)
         coef = torch.zeros((M, H), dtype=dt, device=dev)
         etot = torch.zeros(M, dtype=dt, device=dev)
@@ -194,13 +238,13 @@ class LockstepSCF:
             # purification did not converge (vanishing gap): that molecule's orbitals come from eigh (hf.py:227-247)
             for m in which:
                 if not perr_host[m] < 1e-9:
-                    qmat[m].copy_(self.engines[m].scp2orb(fmix[m]))
+                    self._eigh_orbitals(m, fmix[m], qmat)
                     self.qcs[m].eigh_fallbacks += 1
                     self.eigh_fallbacks += 1
 
         # core guess (scf_qccalc.py:88-91): F0 = dm2scp(0), occupy its lowest orbitals
         z = torch.zeros((n, n), dtype=dt, device=dev)
-        f0 = torch.stack([e.dm2scp(z) for e in self.engines])
+        f0 = torch.stack([e.dm2scp(SpinParam(u=z, d=z) if self.pol else z) for e in self.engines]).reshape(M, S, n, n)
         qmat, perr = self._occupied(f0)
         host = yield perr
         active = list(range(M))
@@ -210,9 +254,9 @@ class LockstepSCF:
         best = [[float("inf"), 0] for _ in range(M)]
         fmix = f0
         for it in range(int(opts["maxiter"])):
-            a = torch.bmm(fock, dm)
-            err = a - a.transpose(-2, -1)  # [F, D] (both symmetric)
-            emax_t = err.abs().amax((-2, -1))
+            a = torch.bmm(fock.reshape(M * S, n, n), dm.reshape(M * S, n, n))
+            err = (a - a.transpose(-2, -1)).reshape(M, S, n, n)  # [F, D] per spin (both symmetric)
+            emax_t = err.abs().amax((-3, -2, -1))
             slot = it % H
             ev = err.reshape(M, -1)
             eh[:, slot] = ev
@@ -223,7 +267,7 @@ class LockstepSCF:
             m_valid = min(it + 1, H)
             if m_valid > 1:
                 lib.diis_solve(gram, m_valid, out=coef)
-                fmix = (coef.unsqueeze(-1) * fh).sum(1).reshape(M, n, n)
+                fmix = (coef.unsqueeze(-1) * fh).sum(1).reshape(M, S, n, n)
             else:
                 fmix = fock.clone()
             # the next projector is formed before the host has seen max|[F, D]| (speculatively: it is ~1 ms for the whole batch)
@@ -254,9 +298,13 @@ class LockstepSCF:
             warnings.warn("SCF did not converge in %d iterations: max|[F,D]| = %.2e (f_tol %.1e)"
                           % (qc.niter, qc.scf_error, opts["f_tol"]))
 
-    @staticmethod
-    def _finish(qc, m, fock, dm, etot):
-        qc._dm = dm[m].clone()
-        qc._fock = fock[m].clone()
-        qc._energy = etot[m].clone()  # engine.dm2energy(dm) as evaluated with the Fock build of this very dm
+    def _finish(self, qc, m, fock, dm, etot):
+        if self.pol:
+            qc._dm = SpinParam(u=dm[m, 0].clone(), d=dm[m, 1].clone())
+            qc._fock = fock[m].clone()
+            qc._energy = None  # (energy() evaluates dm2energy of the stored densities)
+        else:
+            qc._dm = dm[m, 0].clone()
+            qc._fock = fock[m, 0].clone()
+            qc._energy = etot[m].clone()  # engine.dm2energy(dm) as evaluated with the Fock build of this very dm
         qc._has_run = True

@@ -215,9 +215,12 @@ def test_run_lockstep_buckets_and_groups_on_cpu(monkeypatch):
                                     shape=(n, n), norb=r, device=torch.device("cpu"))
         return types.SimpleNamespace(_engine=eng)
 
-    qcs = [fake(24, 5) for _ in range(9)] + [fake(114, 21) for _ in range(70)] + [fake(208, 46)] + [fake(24, 5, pol=True)] + \
+    from dqc_amd.utils.datastruct import SpinParam
+    upol = SpinParam(u=torch.ones(5), d=torch.ones(4))
+    qcs = [fake(24, 5) for _ in range(9)] + [fake(114, 21) for _ in range(70)] + [fake(208, 46)] + [fake(24, 5, pol=True, w=upol)] + \
           [fake(24, 5, w=torch.tensor([2.0, 2.0, 2.0, 1.0, 1.0]))] + [fake(24, 5, ovlp=torch.eye(24))]
     assert lockstep.signature(qcs[0]) == ("cpu", 24, 5, 2.0) and lockstep.signature(qcs[-1]) is None
+    assert lockstep.signature(qcs[80]) == ("cpu", 24, (5, 4), (1.0, 1.0))  # unrestricted: its own bucket
     made, conc = [], []
 
     class FakeGroup:
@@ -233,7 +236,7 @@ def test_run_lockstep_buckets_and_groups_on_cpu(monkeypatch):
     assert sizes == [4, 5, 22, 24, 24]           # 9 tiny molecules -> 2 groups (inflight), 70 benzene-size -> 3 groups of <= 32
     assert all(g.nstreams == 4 for g in made)     # graph-replayed builds: 4 streams per group
     assert conc[0][0] == made and conc[0][1]["max_inflight"] == 2
-    assert len(conc[1][0]) == 4                   # the C5-size singleton, the unrestricted, the open-shell and the raw-basis one
+    assert len(conc[1][0]) == 4                   # the two singletons (C5-size, unrestricted), the open-shell and the raw-basis one
     made.clear(), conc.clear()
     batch.run_lockstep([fake(208, 46) for _ in range(32)])
     assert sorted(len(g.members) for g in made) == [16, 16] and all(g.nstreams == 3 for g in made)
