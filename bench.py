@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--molecules", type=int, default=32, help="size of the batch (whole job; sharded over the ranks)")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="a step is repeated `repeats` times so that the timed region of K steps lasts at least this long")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the batch's Fock builds are dealt to (molecule k -> stream k %% S): independent molecules, so "
                          "the tail of one molecule's kernels overlaps the head of the next one's (SURVEY 8e: each rank, own streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
