@@ -450,6 +450,10 @@ def main():
                                     "ao_orb2dm(C_occ, n): rank-%d factor known to the Hamiltonian" % norb_pad,
             "setup_s_per_rank": setup_s,
             "setup_breakdown_s_rank0": brk,
+            "setup_s_excluding_memory_reserve_rank0": setup_s - brk.get("device_memory_reserve", 0.0),
+            "setup_note": "device_memory_reserve = ONE request for the batch's device memory: the kernel driver clears VRAM that a "
+                          "previous process released at ~35 GB/s before handing it out again (instant on a box that has been idle "
+                          "for seconds; tools/gpu_alloc_cost3.py) -- a property of the box state, paid once per process",
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
