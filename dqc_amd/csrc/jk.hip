@@ -535,6 +535,150 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
     flush_rows();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Coulomb AND exchange of one density (restricted Hartree-Fock, hf.py:198-199) over CONTIGUOUS tile ranges: j_stream_kernel's
+// scheme -- row sums J[I,J] in registers until IJ changes -- plus the four exchange contractions of jk_tiles_kernel on the
+// tile parked in LDS.  Consecutive tiles of a range share (I, J) and, for K + 1 tiles in a row, K: the exchange blocks
+// K[I,K] and K[J,K] keep accumulating in registers until K (or IJ) changes, the other two, K[I,L] and K[J,L], change every
+// tile.  Per tile 64 + 128 fp64 atomics instead of 128 + 256 (ablation of the grid-stride kernel on a 20-atom molecule: the J
+// atomics cost 12 % of its time, the K atomics 6 %, the LDS contraction 16 %).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
+                                                          double *__restrict__ work, int npad, long long ntiles, long long per_block) {
+    const double dsc = dscp ? *dscp : 0.0;
+    constexpr int LDT = 68;
+    __shared__ double s_col[4][64];  // (single buffer: two barriers per tile separate its writers and readers anyway)
+    __shared__ __attribute__((aligned(16))) double s_g[64 * LDT];
+    __shared__ __attribute__((aligned(16))) double s_d[2][72][2];
+    const size_t n2 = (size_t)npad * npad;
+    const double *Dp = work;
+    double *Jacc = work + n2, *Kacc = work + 2 * n2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+    const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
+    const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;  // exchange part: output (x, y), partial group pg
+    const long long T0 = (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
+    if (T0 >= T1) return;
+    int IJ, KL, I, J, K, L;
+    decode_tri(T0, IJ, KL);
+    decode_tri(IJ, I, J);
+    decode_tri(KL, K, L);
+    double rsacc[4] = {0, 0, 0, 0}, dij[4];
+    double k3acc = 0.0, k4acc = 0.0;  // K[I,K](x, y), K[J,K](x, y): this lane's share, carried over the tiles of one K
+    {
+        const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+    }
+    auto flush_rows = [&]() {
+        const double fI = (I == J ? 0.5 : 1.0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = rsacc[r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if ((lane & 15) == 0) acc_add(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * fI * v, dsc);
+            rsacc[r] = 0.0;
+        }
+    };
+    auto flush_k34 = [&]() {  // (weights were applied tile by tile)
+        double a3 = k3acc, a4 = k4acc;
+        a3 += __shfl_xor(a3, 1); a3 += __shfl_xor(a3, 2);
+        a4 += __shfl_xor(a4, 1); a4 += __shfl_xor(a4, 2);
+        if (pg == 0) {
+            acc_add(&Kacc[(size_t)(I * 8 + x) * npad + K * 8 + y], a3, dsc);
+            acc_add(&Kacc[(size_t)(J * 8 + x) * npad + K * 8 + y], a4, dsc);
+        }
+        k3acc = k4acc = 0.0;
+    };
+    for (long long T = T0; T < T1; T++) {
+        const double f = (I == J ? 0.5 : 1.0) * (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const double fk = (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const double *dklp = Dp + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
+        double dkl[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) dkl[q] = fk * dklp[q];
+        double cs[4] = {0, 0, 0, 0};
+        {
+            double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+#define DQC_JS_ROW(R_, A_, B_)                                                                           \
+    rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                          \
+    cs[0] += A_.x * dij[R_]; cs[1] += A_.y * dij[R_]; cs[2] += B_.x * dij[R_]; cs[3] += B_.y * dij[R_]; \
+    *reinterpret_cast<double2 *>(&s_g[(r0 + R_) * LDT + c0]) = A_;                                       \
+    *reinterpret_cast<double2 *>(&s_g[(r0 + R_) * LDT + c0 + 2]) = B_;
+            // (the barrier at the end of the previous iteration has retired that tile's LDS readers)
+            DQC_JS_ROW(0, ta0, tb0) DQC_JS_ROW(1, ta1, tb1) DQC_JS_ROW(2, ta2, tb2) DQC_JS_ROW(3, ta3, tb3)
+#undef DQC_JS_ROW
+        }
+        {   // D blocks of the exchange part: thread t loads element (t & 63) of block (t >> 6)
+            const int blk = t >> 6, e = t & 63, xx = e >> 3, yy = e & 7;
+            const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
+            s_d[blk >> 1][xx * 9 + yy][blk & 1] = Dp[(size_t)(R * 8 + xx) * npad + Cb * 8 + yy];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double v = cs[c];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            cs[c] = v;
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_col[wave][c0 + c] = cs[c];
+        }
+        __syncthreads();
+        if (t < 64) {
+            const double v = s_col[0][t] + s_col[1][t] + s_col[2][t] + s_col[3][t];
+            acc_add(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * (I == J ? 0.5 : 1.0) * fk * v, dsc);
+        }
+        {   // exchange: lane mapping and bank analysis as in jk_tiles_kernel
+            double k1 = 0, k2 = 0, k3 = 0, k4 = 0;
+#pragma unroll 1
+            for (int u = 0; u < 2; u++) {
+                const int q = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
+#pragma unroll
+                for (int a = 0; a < 8; a++) {
+                    typedef double vd2_ __attribute__((ext_vector_type(2)));
+                    const vd2_ d12 = *reinterpret_cast<const vd2_ *>(&s_d[0][a * 9 + q][0]);
+                    const vd2_ d34 = *reinterpret_cast<const vd2_ *>(&s_d[1][a * 9 + q4][0]);
+                    k1 += s_g[(x * 8 + a) * LDT + q * 8 + y] * d12.x;    // g[x][a][v=q][y]  D[J,K](a,v)  -> K[I,L]
+                    k2 += s_g[(a * 8 + x) * LDT + q * 8 + y] * d12.y;    // g[a][x][v=q][y]  D[I,K](a,v)  -> K[J,L]
+                    k3 += s_g[(x * 8 + a) * LDT + y * 8 + q4] * d34.x;   // g[x][a][y][v=q4] D[J,L](a,v)  -> K[I,K]
+                    k4 += s_g[(a * 8 + x) * LDT + y * 8 + q4] * d34.y;   // g[a][x][y][v=q4] D[I,L](a,v)  -> K[J,K]
+                }
+            }
+            k1 += __shfl_xor(k1, 1); k1 += __shfl_xor(k1, 2);
+            k2 += __shfl_xor(k2, 1); k2 += __shfl_xor(k2, 2);
+            if (pg == 0) {
+                acc_add(&Kacc[(size_t)(I * 8 + x) * npad + L * 8 + y], f * k1, dsc);
+                acc_add(&Kacc[(size_t)(J * 8 + x) * npad + L * 8 + y], f * k2, dsc);
+            }
+            k3acc += f * k3;
+            k4acc += f * k4;
+        }
+        // ---- next tile of the range
+        if (T + 1 < T1) {
+            if (KL == IJ) {  // next bra block pair: everything carried over goes out
+                flush_rows();
+                flush_k34();
+                IJ++;
+                KL = 0; K = 0; L = 0;
+                decode_tri(IJ, I, J);
+                const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+            } else {
+                KL++;
+                if (L == K) { flush_k34(); K++; L = 0; }
+                else L++;
+            }
+        }
+        __syncthreads();  // s_g / s_d reuse by the next tile
+    }
+    flush_rows();
+    flush_k34();
+}
+
 }  // namespace dqc
 
 extern "C" {
@@ -562,7 +706,13 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     }
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 256 * 16);
     static const char *jimpl = getenv("DQC_J_IMPL");  // "stride": the grid-stride kernel of round 1 (A/B runs)
-    if (with_k) {
+    if (with_k && !(jimpl && jimpl[0] == 's')) {
+        // contiguous tile ranges of >= 8 tiles, 1024 ... 6144 blocks (4 resident per CU; sweep 1024 ... 8192 on benzene, 20-atom
+        // cc-pVDZ and naphthalene / cc-pVTZ: flat within 3 % inside this window)
+        const long long nblk = std::min<long long>(ntiles, std::max<long long>(1024, std::min<long long>(6144, ntiles / 8)));
+        const long long per = (ntiles + nblk - 1) / nblk;
+        hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per);
+    } else if (with_k) {
         hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
     } else if (jimpl && jimpl[0] == 's') {
         hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
