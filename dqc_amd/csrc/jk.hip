@@ -679,6 +679,170 @@ __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restr
     flush_k34();
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same stream scheme for the unrestricted Hartree-Fock trio (hf.py:93-103): J of NJ (0 or 1) densities and K of NK (1 or 2)
+// exchange densities from ONE pass over contiguous tile ranges; work layout as jk_multi_kernel: Dj[NJ] | Dk[NK] | Jacc[NJ] |
+// Kacc[NK].  (More Coulomb densities than one -- batched density matrices -- keep the grid-stride jk_multi_kernel.)
+// ---------------------------------------------------------------------------------------------
+template <int NJ, int NK>
+__global__ __launch_bounds__(256, 3) void jk_multi_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
+                                                                double *__restrict__ work, int npad, long long ntiles,
+                                                                long long per_block) {
+    const double dsc = dscp ? *dscp : 0.0;
+    constexpr int LDT = 68;
+    __shared__ double s_col[4][64];  // (single buffer: two barriers per tile separate its writers and readers anyway)
+    __shared__ __attribute__((aligned(16))) double s_g[64 * LDT];
+    __shared__ __attribute__((aligned(16))) double s_d[4][72][NK];  // D[J,K], D[I,K], D[J,L], D[I,L] of the NK exchange densities
+    const size_t n2 = (size_t)npad * npad;
+    const double *Dp = work, *Dk = work + (size_t)NJ * n2;
+    double *Jacc = work + (size_t)(NJ + NK) * n2, *Kacc = Jacc + (size_t)NJ * n2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
+    const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
+    const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;  // exchange part: output (x, y), partial group pg
+    const long long T0 = (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
+    if (T0 >= T1) return;
+    int IJ, KL, I, J, K, L;
+    decode_tri(T0, IJ, KL);
+    decode_tri(IJ, I, J);
+    decode_tri(KL, K, L);
+    double rsacc[4] = {0, 0, 0, 0}, dij[4];
+    double k3acc[NK], k4acc[NK];  // K[I,K](x, y), K[J,K](x, y) per exchange density: this lane's share, carried over the tiles of one K
+#pragma unroll
+    for (int q = 0; q < NK; q++) k3acc[q] = k4acc[q] = 0.0;
+    if (NJ) {
+        const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+    }
+    auto flush_rows = [&]() {
+        if (!NJ) return;
+        const double fI = (I == J ? 0.5 : 1.0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double v = rsacc[r];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if ((lane & 15) == 0) acc_add(&Jacc[(size_t)(I * 8 + ii) * npad + J * 8 + j0 + r], 2.0 * fI * v, dsc);
+            rsacc[r] = 0.0;
+        }
+    };
+    auto flush_k34 = [&]() {  // (weights were applied tile by tile)
+#pragma unroll
+        for (int q = 0; q < NK; q++) {
+            double a3 = k3acc[q], a4 = k4acc[q];
+            a3 += __shfl_xor(a3, 1); a3 += __shfl_xor(a3, 2);
+            a4 += __shfl_xor(a4, 1); a4 += __shfl_xor(a4, 2);
+            if (pg == 0) {
+                acc_add(&Kacc[q * n2 + (size_t)(I * 8 + x) * npad + K * 8 + y], a3, dsc);
+                acc_add(&Kacc[q * n2 + (size_t)(J * 8 + x) * npad + K * 8 + y], a4, dsc);
+            }
+            k3acc[q] = k4acc[q] = 0.0;
+        }
+    };
+    for (long long T = T0; T < T1; T++) {
+        const double f = (I == J ? 0.5 : 1.0) * (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const double fk = (K == L ? 0.5 : 1.0) * (IJ == KL ? 0.5 : 1.0);
+        const double *dklp = Dp + (size_t)(K * 8 + kk) * npad + L * 8 + l0;
+        double dkl[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) dkl[q] = NJ ? fk * dklp[q] : 0.0;
+        double cs[4] = {0, 0, 0, 0};
+        {
+            double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+#define DQC_JS_ROW(R_, A_, B_)                                                                           \
+    if (NJ) {                                                                                            \
+        rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                      \
+        cs[0] += A_.x * dij[R_]; cs[1] += A_.y * dij[R_]; cs[2] += B_.x * dij[R_]; cs[3] += B_.y * dij[R_]; \
+    }                                                                                                    \
+    *reinterpret_cast<double2 *>(&s_g[(r0 + R_) * LDT + c0]) = A_;                                       \
+    *reinterpret_cast<double2 *>(&s_g[(r0 + R_) * LDT + c0 + 2]) = B_;
+            // (the barrier at the end of the previous iteration has retired that tile's LDS readers)
+            DQC_JS_ROW(0, ta0, tb0) DQC_JS_ROW(1, ta1, tb1) DQC_JS_ROW(2, ta2, tb2) DQC_JS_ROW(3, ta3, tb3)
+#undef DQC_JS_ROW
+        }
+        {   // D blocks of the exchange part: thread t loads element (t & 63) of block (t >> 6)
+            const int blk = t >> 6, e = t & 63, xx = e >> 3, yy = e & 7;
+            const int R = (blk & 1) ? I : J, Cb = (blk & 2) ? L : K;
+#pragma unroll
+            for (int q = 0; q < NK; q++) s_d[blk][xx * 9 + yy][q] = Dk[q * n2 + (size_t)(R * 8 + xx) * npad + Cb * 8 + yy];
+        }
+        if (NJ) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double v = cs[c];
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                cs[c] = v;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) s_col[wave][c0 + c] = cs[c];
+            }
+        }
+        __syncthreads();
+        if (NJ && t < 64) {
+            const double v = s_col[0][t] + s_col[1][t] + s_col[2][t] + s_col[3][t];
+            acc_add(&Jacc[(size_t)(K * 8 + (t >> 3)) * npad + L * 8 + (t & 7)], 2.0 * (I == J ? 0.5 : 1.0) * fk * v, dsc);
+        }
+        {   // exchange: lane mapping and bank analysis as in jk_tiles_kernel; the tile reads are shared by the NK densities
+            double k1[NK], k2[NK], k3[NK], k4[NK];
+#pragma unroll
+            for (int q = 0; q < NK; q++) k1[q] = k2[q] = k3[q] = k4[q] = 0.0;
+#pragma unroll 1
+            for (int u = 0; u < 2; u++) {
+                const int qq = pg + 4 * u, q4 = pg + 4 * (u ^ yh);
+#pragma unroll 4
+                for (int a = 0; a < 8; a++) {
+                    const double g1 = s_g[(x * 8 + a) * LDT + qq * 8 + y], g2 = s_g[(a * 8 + x) * LDT + qq * 8 + y];
+                    const double g3 = s_g[(x * 8 + a) * LDT + y * 8 + q4], g4 = s_g[(a * 8 + x) * LDT + y * 8 + q4];
+#pragma unroll
+                    for (int q = 0; q < NK; q++) {
+                        k1[q] += g1 * s_d[0][a * 9 + qq][q];   // D[J,K](a,v) -> K[I,L]
+                        k2[q] += g2 * s_d[1][a * 9 + qq][q];   // D[I,K](a,v) -> K[J,L]
+                        k3[q] += g3 * s_d[2][a * 9 + q4][q];   // D[J,L](a,v) -> K[I,K]
+                        k4[q] += g4 * s_d[3][a * 9 + q4][q];   // D[I,L](a,v) -> K[J,K]
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                double a1 = k1[q], a2 = k2[q];
+                a1 += __shfl_xor(a1, 1); a1 += __shfl_xor(a1, 2);
+                a2 += __shfl_xor(a2, 1); a2 += __shfl_xor(a2, 2);
+                if (pg == 0) {
+                    acc_add(&Kacc[q * n2 + (size_t)(I * 8 + x) * npad + L * 8 + y], f * a1, dsc);
+                    acc_add(&Kacc[q * n2 + (size_t)(J * 8 + x) * npad + L * 8 + y], f * a2, dsc);
+                }
+                k3acc[q] += f * k3[q];
+                k4acc[q] += f * k4[q];
+            }
+        }
+        // ---- next tile of the range
+        if (T + 1 < T1) {
+            if (KL == IJ) {  // next bra block pair: everything carried over goes out
+                flush_rows();
+                flush_k34();
+                IJ++;
+                KL = 0; K = 0; L = 0;
+                decode_tri(IJ, I, J);
+                if (NJ) {
+                    const double *dijp = Dp + (size_t)(I * 8 + ii) * npad + J * 8 + j0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dij[q] = dijp[q];
+                }
+            } else {
+                KL++;
+                if (L == K) { flush_k34(); K++; L = 0; }
+                else L++;
+            }
+        }
+        __syncthreads();  // s_g / s_d reuse by the next tile
+    }
+    flush_rows();
+    flush_k34();
+}
+
+
 }  // namespace dqc
 
 extern "C" {
@@ -756,7 +920,17 @@ int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_
             hipLaunchKernelGGL(jk_det_scale_kernel, dim3(1), dim3(256), 0, st, dscp, d_work, njp + nkp, (size_t)npad * npad, d_tiles, nao);
             DQC_CHECK_LAUNCH();
         }
-        if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
+        // at most one Coulomb density in the pass: the stream form (contiguous ranges, sums carried in registers)
+        const long long nblk_s = std::min<long long>(ntiles, std::max<long long>(1024, std::min<long long>(6144, ntiles / 8)));
+        const long long per_s = (ntiles + nblk_s - 1) / nblk_s;
+        const dim3 grid_s((unsigned)((ntiles + per_s - 1) / per_s));
+        static const char *mimpl = getenv("DQC_JK_MULTI_IMPL");  // "grid": the grid-stride kernel (A/B runs)
+        const bool stream_ok = njp <= 1 && nkp >= 1 && !(mimpl && mimpl[0] == 'g');
+        if (stream_ok && njp == 1 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
+        else if (stream_ok && njp == 1 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
+        else if (stream_ok && njp == 0 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
+        else if (stream_ok && njp == 0 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
+        else if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
         else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
         else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
         DQC_CHECK_LAUNCH();
