@@ -8,7 +8,7 @@ HBM, MFMA = 8000.0, 78.6
 out = {"_how": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc MfmaUtil (separate passes) of tools/config_step.py <config>: "
                "steady-state Fock builds dm2scp(ao_orb2dm(C_occ)) of ONE molecule on one stream; peaks 8000 GB/s, 78.6 TF fp64 MFMA",
        "configs": {}}
-HOT = ("j_stream_kernel", "jk_tiles_kernel", "density_lr_kernel", "vxc_wsd_kernel", "vxc_ws_kernel", "vxc_ws2_kernel",
+HOT = ("j_stream_kernel", "jk_stream_kernel", "jk_tiles_kernel", "density_lr_kernel", "vxc_wsd_kernel", "vxc_ws_kernel", "vxc_ws2_kernel",
        "vxc_wsu_kernel", "vxc_wst_kernel", "xc_kernel")
 for c in ("C2", "C3", "C3pbe", "C4", "C5"):
     if not os.path.exists(os.path.join(src, c + "_step.json")):
@@ -28,9 +28,9 @@ for c in ("C2", "C3", "C3pbe", "C4", "C5"):
                 kern[m.group(1)][key] = float(m.group(3)) * scale
     for k, v in kern.items():
         t = v["avg_us"] * 1e-6
-        if k in ("j_stream_kernel", "jk_tiles_kernel"):
-            by, fl = float(n) ** 4 + 3 * 8.0 * n * n, (4.0 if k == "jk_tiles_kernel" else 2.0) * float(n) ** 4
-            v["what"] = "J + K from the stored ERI tiles (RHF)" if k == "jk_tiles_kernel" else "J from the stored ERI tiles"
+        if k in ("j_stream_kernel", "jk_stream_kernel", "jk_tiles_kernel"):
+            by, fl = float(n) ** 4 + 3 * 8.0 * n * n, (2.0 if k == "j_stream_kernel" else 4.0) * float(n) ** 4
+            v["what"] = "J + K from the stored ERI tiles (RHF)" if k != "j_stream_kernel" else "J from the stored ERI tiles"
         elif k == "density_lr_kernel":
             by, fl = 8.0 * comp * G * n + 8.0 * G * (4 if comp == 4 else 1), 4.0 * G * n * r + 2.0 * comp * G * n
             v["what"] = "density (+ gradient) on the grid from the rank-n_occ factor"
@@ -43,7 +43,7 @@ for c in ("C2", "C3", "C3pbe", "C4", "C5"):
         v["algorithmic_bytes"], v["algorithmic_flops"] = by, fl
         v["hbm_gbs"], v["tflops"] = by / t / 1e9, fl / t / 1e12
         fh, fm = v["hbm_gbs"] / HBM, v["tflops"] / MFMA
-        v["bound"], v["frac"] = ("mfma", fm) if (fm > fh and k not in ("j_stream_kernel", "jk_tiles_kernel", "xc_kernel")) else ("hbm", fh)
+        v["bound"], v["frac"] = ("mfma", fm) if (fm > fh and k not in ("j_stream_kernel", "jk_stream_kernel", "jk_tiles_kernel", "xc_kernel")) else ("hbm", fh)
         if "hbm_read_bytes" in v:
             v["traffic_over_algorithmic"] = v["hbm_read_bytes"] / by
     out["configs"][c] = {"shape": step, "kernels": kern}
