@@ -42,6 +42,7 @@ inline long long eri_store_data_doubles(int nao) { return tile_row_off((nao + DQ
 
 void set_error(const std::string &msg);
 bool deterministic_mode();  // dqc_set_deterministic (host.hip)
+bool generic_eri_forced();  // dqc_set_generic_eri (host.hip)
 
 #define DQC_HIP(call)                                                                      \
     do {                                                                                   \

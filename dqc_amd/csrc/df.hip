@@ -6,7 +6,7 @@
 // same construction is used here: one extra shell with exponent 0 and coefficient sqrt(4 pi) (cancelling the l = 0
 // solid-harmonic factor) is appended to the shell table, the ket "pair" list is (auxiliary shell, unit), and the
 // Rys shell-quartet kernel of eri_core.hpp runs unchanged in its 3C / 2C output modes: <LA,LB,LC,0> and <LA,0,LC,0>.
-#include "eri_core.hpp"
+#include "eri_generic.hpp"
 
 namespace dqc {
 
@@ -27,13 +27,6 @@ static int df_setup(DfSetup &s, const int *atm, int natm, const int *bas, int nb
     if (sh0 < 0 || sh1 > nbas || sh0 > sh1 || k0 < 0 || k1 > nbas || k0 > k1) {
         set_error(std::string(who) + ": shell ranges outside the table");
         return DQC_EINVAL;
-    }
-    for (int i = 0; i < nbas; i++) {
-        const bool used = (need_orb && i >= sh0 && i < sh1) || (i >= k0 && i < k1);
-        if (used && s.b.shells[i].l > ERI_LMAX) {
-            set_error(std::string(who) + ": shells above f are not supported");
-            return DQC_EINVAL;
-        }
     }
     auto ao_of = [&](int sh) { return sh < nbas ? s.b.shells[sh].ao_off : s.b.nao; };
     s.og.ao0 = ao_of(sh0);
@@ -73,7 +66,7 @@ static int launch_df_class(double *out, const DfSetup &s, hipStream_t st) {
     const DevPairs &db = MODE == ERI_OUT_3C ? s.dorb : s.daux;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2;
     const int nb = hb.cls_count[cb], nk = s.aux.cls_count[ck];
-    if (nb == 0 || nk == 0) return 0;
+    if (nb == 0 || nk == 0 || hl_forced()) return 0;
     const long long ntask = (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, 0, MODE>;
@@ -102,6 +95,23 @@ static int launch_2c_ket(double *out, const DfSetup &s, hipStream_t st) {
     if ((rc = launch_df_class<LA, 0, LC, ERI_OUT_2C>(out, s, st))) return rc;
     DQC_2C(0) DQC_2C(1) DQC_2C(2) DQC_2C(3)
 #undef DQC_2C
+    return 0;
+}
+
+// classes with a g shell (orbital or auxiliary) through the runtime kernel (eri_generic.hpp); DQC_ERI_GENERIC=1: all classes
+template <int MODE>
+static int launch_df_generic(double *out, const DfSetup &s, hipStream_t st) {
+    const HostPairs &hb = MODE == ERI_OUT_3C ? s.orb : s.aux;
+    const DevPairs &db = MODE == ERI_OUT_3C ? s.dorb : s.daux;
+    for (int la = 0; la <= DQC_LMAX; la++)
+        for (int lb = 0; lb <= (MODE == ERI_OUT_3C ? la : 0); lb++)
+            for (int lc = 0; lc <= DQC_LMAX; lc++) {
+                if (!hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX) continue;
+                const int cb = la * (la + 1) / 2 + lb, ck = lc * (lc + 1) / 2;
+                int rc = launch_hl<MODE>(out, s.ds, db, s.daux, hb.cls_start[cb], hb.cls_count[cb], s.aux.cls_start[ck],
+                                         s.aux.cls_count[ck], 0, s.og, la, lb, lc, 0, st);
+                if (rc) return rc;
+            }
     return 0;
 }
 
@@ -189,7 +199,8 @@ int dqc_int3c2e(double *d_out, const int *atm, int natm, const int *bas, int nba
     if (rc) return rc;
     if (s.og.nao == 0 || s.og.naux == 0) return DQC_OK;
     if ((rc = launch_3c_ket<0>(d_out, s, st)) || (rc = launch_3c_ket<1>(d_out, s, st)) ||
-        (rc = launch_3c_ket<2>(d_out, s, st)) || (rc = launch_3c_ket<3>(d_out, s, st)))
+        (rc = launch_3c_ket<2>(d_out, s, st)) || (rc = launch_3c_ket<3>(d_out, s, st)) ||
+        (rc = launch_df_generic<ERI_OUT_3C>(d_out, s, st)))
         return rc;
     DQC_HIP(hipStreamSynchronize(st));
     return DQC_OK;
@@ -204,7 +215,8 @@ int dqc_int2c2e(double *d_out, const int *atm, int natm, const int *bas, int nba
     if (rc) return rc;
     if (s.og.naux == 0) return DQC_OK;
     if ((rc = launch_2c_ket<0>(d_out, s, st)) || (rc = launch_2c_ket<1>(d_out, s, st)) ||
-        (rc = launch_2c_ket<2>(d_out, s, st)) || (rc = launch_2c_ket<3>(d_out, s, st)))
+        (rc = launch_2c_ket<2>(d_out, s, st)) || (rc = launch_2c_ket<3>(d_out, s, st)) ||
+        (rc = launch_df_generic<ERI_OUT_2C>(d_out, s, st)))
         return rc;
     DQC_HIP(hipStreamSynchronize(st));
     return DQC_OK;

@@ -30,7 +30,7 @@
 //     bound (48 % of the wave cycles in issue stalls: Clenshaw recurrences, fp64 divisions), ~35 % VALU utilisation.
 //   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
 //   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
-#include "eri_core.hpp"
+#include "eri_generic.hpp"
 
 namespace dqc {
 
@@ -59,7 +59,7 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
-    if (nb == 0 || nk == 0) return 0;
+    if (nb == 0 || nk == 0 || hl_forced()) return 0;
     const int same = cb == ck;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
@@ -94,7 +94,7 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
-    if (nb == 0 || nk == 0) return 0;
+    if (nb == 0 || nk == 0 || hl_forced()) return 0;
     const int same = cb == ck;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
@@ -118,6 +118,25 @@ struct ClassLoopJK {
         else return 0;
     }
 };
+
+// the classes the compile-time kernels leave out -- any pair class with a g shell -- through the runtime kernel
+// (eri_generic.hpp); DQC_ERI_GENERIC=1: all classes
+template <int MODE>
+static int run_generic_classes(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og,
+                               hipStream_t st) {
+    for (int la = 0; la <= DQC_LMAX; la++)
+        for (int lb = 0; lb <= la; lb++)
+            for (int lc = 0; lc <= la; lc++)
+                for (int ld = 0; ld <= lc; ld++) {
+                    const int cb = la * (la + 1) / 2 + lb, ck = lc * (lc + 1) / 2 + ld;
+                    if (ck > cb) continue;
+                    if (!hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX) continue;
+                    int rc = launch_hl<MODE>(tiles, ds, dp, dp, hp.cls_start[cb], hp.cls_count[cb], hp.cls_start[ck],
+                                             hp.cls_count[ck], cb == ck, og, la, lb, lc, ld, st);
+                    if (rc) return rc;
+                }
+    return 0;
+}
 
 __global__ void jk_direct_prep_kernel(double *__restrict__ dsym, double *__restrict__ a, double *__restrict__ b,
                                       const double *__restrict__ dm, int nao) {
@@ -152,8 +171,6 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
-    for (const HostShell &s : b.shells)
-        if (s.l > ERI_LMAX) { set_error("dqc_jk_direct: shells above f are not supported"); return DQC_EINVAL; }
     if (nbas == 0 || b.nao == 0) return DQC_OK;
     if ((rc = boys_table_ensure())) return rc;
     HostPairs hp;
@@ -179,6 +196,7 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     rc = ClassLoopJK<NCLS - 1, NCLS - 1>::run(ds, dp, hp, og, st);
     if (rc) return rc;
+    if ((rc = run_generic_classes<ERI_OUT_JK>(nullptr, ds, dp, hp, og, st))) return rc;
     hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, d_a, d_b, b.nao);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
@@ -191,8 +209,6 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
-    for (const HostShell &s : b.shells)
-        if (s.l > ERI_LMAX) { set_error("dqc_eri_fill_tiles: shells above f are not supported"); return DQC_EINVAL; }
     if (nbas == 0 || b.nao == 0) return DQC_OK;
     DQC_HIP(hipMemsetAsync(d_tiles, 0, sizeof(double) * (size_t)eri_store_data_doubles(b.nao), st));  // packed store (common.hpp)
     if ((rc = boys_table_ensure())) return rc;
@@ -212,6 +228,7 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st);
     if (rc) return rc;
+    if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, EriOut{0, 0, 0, 0}, st))) return rc;
     return DQC_OK;
 }
 

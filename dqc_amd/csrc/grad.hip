@@ -12,8 +12,9 @@
 // an (l-1)-shell; the 2e term therefore reuses the Rys shell-quartet kernel unchanged, with those companion shells
 // first in the bra pair, in its GRAD output mode (eri_core.hpp).  Densities enter in the Cartesian AO basis
 // (D_cart = T^T D T, T = dqc_cart2sph_matrix), so no solid-harmonic transform is needed on the device.
-// Supported: shells up to f (companions up to g).
-#include "eri_core.hpp"
+// Supported: shells up to g (companions up to h: the classes with a g shell or an h companion run through the runtime
+// kernel of eri_generic.hpp).
+#include "eri_generic.hpp"
 
 namespace dqc {
 
@@ -26,7 +27,7 @@ namespace hostc2s {
 #undef C2S_QUAL
 }  // namespace hostc2s
 
-constexpr int GRAD_LMAX = 3;  // orbital shells up to f in the gradient path (companions up to g)
+constexpr int GRAD_LMAX = 3;  // orbital shells up to f in the compile-time classes (companions up to g); above: eri_generic.hpp
 
 static void cart_offsets(const Basis &b, int nsh, std::vector<int> &cao, int &ncart) {
     cao.resize(nsh);
@@ -93,7 +94,7 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * 8 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = c.hbra->cls_count[cb], nk = c.hket->cls_count[ck];
-    if (nb == 0 || nk == 0) return 0;
+    if (nb == 0 || nk == 0 || hl_forced()) return 0;
     const long long ntask = (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
@@ -125,8 +126,11 @@ static int launch_grad_bra_df(const GradCtx &c, hipStream_t st) {
     return 0;
 }
 
+static int launch_grad_generic(const GradCtx &c, bool df, int lbmax, hipStream_t st);
+
 static int launch_grad_df3c(const GradCtx &c, hipStream_t st) {
     int rc;
+    if ((rc = launch_grad_generic(c, true, DQC_LMAX, st))) return rc;
 #define DQC_GB(LA) \
     if ((rc = launch_grad_bra_df<LA, 0>(c, st)) || (rc = launch_grad_bra_df<LA, 1>(c, st)) || (rc = launch_grad_bra_df<LA, 2>(c, st)) || (rc = launch_grad_bra_df<LA, 3>(c, st))) return rc;
     DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3) DQC_GB(4)
@@ -136,14 +140,32 @@ static int launch_grad_df3c(const GradCtx &c, hipStream_t st) {
 
 static int launch_grad_df2c(const GradCtx &c, hipStream_t st) {
     int rc;
+    if ((rc = launch_grad_generic(c, true, 0, st))) return rc;
     if ((rc = launch_grad_bra_df<0, 0>(c, st)) || (rc = launch_grad_bra_df<1, 0>(c, st)) || (rc = launch_grad_bra_df<2, 0>(c, st)) ||
         (rc = launch_grad_bra_df<3, 0>(c, st)) || (rc = launch_grad_bra_df<4, 0>(c, st)))
         return rc;
     return 0;
 }
 
+// the classes outside the compile-time set (h companions, g shells) through the runtime kernel; ket pairs (lc >= ld), or
+// (auxiliary shell, unit) when `df`
+static int launch_grad_generic(const GradCtx &c, bool df, int lbmax, hipStream_t st) {
+    for (int la = 0; la <= DQC_LMAX + 1; la++)
+        for (int lb = 0; lb <= lbmax; lb++)
+            for (int lc = 0; lc <= DQC_LMAX; lc++)
+                for (int ld = 0; ld <= (df ? 0 : lc); ld++) {
+                    if (!hl_forced() && la <= GRAD_LMAX + 1 && lb <= GRAD_LMAX && lc <= GRAD_LMAX) continue;
+                    const int cb = la * 8 + lb, ck = lc * (lc + 1) / 2 + ld;
+                    int rc = launch_hl<ERI_OUT_GRAD>(nullptr, c.ds, c.dbra, c.dket, c.hbra->cls_start[cb], c.hbra->cls_count[cb],
+                                                     c.hket->cls_start[ck], c.hket->cls_count[ck], 0, c.og, la, lb, lc, ld, st);
+                    if (rc) return rc;
+                }
+    return 0;
+}
+
 static int launch_grad_all(const GradCtx &c, hipStream_t st) {
     int rc;
+    if ((rc = launch_grad_generic(c, false, DQC_LMAX, st))) return rc;
 #define DQC_GB(LA) \
     if ((rc = launch_grad_bra<LA, 0>(c, st)) || (rc = launch_grad_bra<LA, 1>(c, st)) || (rc = launch_grad_bra<LA, 2>(c, st)) || (rc = launch_grad_bra<LA, 3>(c, st))) return rc;
     DQC_GB(0) DQC_GB(1) DQC_GB(2) DQC_GB(3) DQC_GB(4)
@@ -154,7 +176,7 @@ static int launch_grad_all(const GradCtx &c, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // one-electron part: one thread per ORDERED shell pair (a, b), derivative on a's centre
 // ---------------------------------------------------------------------------------------------
-constexpr int G1 = DQC_LMAX + 1, G3 = DQC_LMAX + 3;
+constexpr int G1 = DQC_LMAX + 2, G3 = DQC_LMAX + 3;  // bra index up to l + 1 (the derivative), ket index up to l + 2 (kinetic)
 
 DQC_DEV void overlap_1d_g(double s[G1][G3], int la, int lb, double PA, double PB, double hp) {
     s[0][0] = 1.0;
@@ -322,8 +344,6 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
     if (nbas == 0) return DQC_OK;
-    for (const HostShell &s : b.shells)
-        if (s.l > GRAD_LMAX) { set_error("dqc_eri_grad: shells above f are not supported in the gradient path"); return DQC_EINVAL; }
     const int N = nbas;
     std::vector<int> cao, sh_atom(N);
     int ncart;
@@ -406,8 +426,6 @@ int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart,
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, zs);
     if (rc) return rc;
     if (nbas == 0) return DQC_OK;
-    for (const HostShell &s : b.shells)
-        if (s.l >= DQC_LMAX) { set_error("dqc_int1e_grad: shells above f are not supported in the gradient path"); return DQC_EINVAL; }
     std::vector<int> cao, sh_atom(nbas);
     int ncart;
     cart_offsets(b, nbas, cao, ncart);
@@ -436,7 +454,7 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
     //   d_grad (natm, 3) += sum D_ij c_k d(ij|k) - 1/2 sum c_k c_l d(k|l)
     // over the CONCATENATED tables (orbital shells [sh0, sh1), auxiliary shells [k0, k1)); d_dcart (ncart, ncart) and
     // d_ccart (ncart): density matrix and fit coefficients in the Cartesian basis of ALL shells of the table
-    // (zero outside the orbital block / auxiliary segment).  Orbital shells up to d, auxiliary shells up to f.
+    // (zero outside the orbital block / auxiliary segment).
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     Basis b;
@@ -444,11 +462,6 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
     if (rc) return rc;
     if (sh0 < 0 || sh1 > nbas || sh0 > sh1 || k0 < 0 || k1 > nbas || k0 > k1) { set_error("dqc_df_grad: shell ranges outside the table"); return DQC_EINVAL; }
     if (sh0 == sh1 || k0 == k1) return DQC_OK;
-    for (int i = 0; i < nbas; i++) {
-        const int l = b.shells[i].l;
-        if (i >= sh0 && i < sh1 && l > GRAD_LMAX) { set_error("dqc_df_grad: orbital shells above f are not supported in the gradient path"); return DQC_EINVAL; }
-        if (i >= k0 && i < k1 && l > ERI_LMAX) { set_error("dqc_df_grad: auxiliary shells above f are not supported"); return DQC_EINVAL; }
-    }
     const int N = nbas;
     std::vector<int> cao, sh_atom(3 * N + 1, 0);
     int ncart;

@@ -1,4 +1,6 @@
 // host.hip -- error handling, table parsing and small utilities of libdqc_amd.so
+#include <cstdlib>
+
 #include "common.hpp"
 #include <mutex>
 
@@ -37,6 +39,14 @@ const std::vector<double> &boys_table_host() {
 
 static bool g_deterministic = false;
 bool deterministic_mode() { return g_deterministic; }
+static int g_generic_eri = -1;  // -1: not set (environment DQC_ERI_GENERIC decides)
+bool generic_eri_forced() {
+    if (g_generic_eri < 0) {
+        const char *e = std::getenv("DQC_ERI_GENERIC");
+        g_generic_eri = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_generic_eri == 1;
+}
 
 // ---- pinned staging blocks of the stream-ordered DevPool ----
 static std::mutex g_stg_mu;
@@ -147,6 +157,14 @@ int dqc_set_deterministic(int on) {
     return prev;
 }
 int dqc_get_deterministic(void) { return dqc::g_deterministic ? 1 : 0; }
+
+int dqc_set_generic_eri(int on) {
+    // process-wide: every shell-quartet class through the runtime-angular-momentum kernel (eri_generic.hpp) instead of only the
+    // classes with a g shell -- the cross-check of the two implementations.  Returns the previous setting.
+    const int prev = dqc::generic_eri_forced() ? 1 : 0;
+    dqc::g_generic_eri = on != 0;
+    return prev;
+}
 int dqc_version(void) { return 100; }
 
 int dqc_nao(const int *bas, int nbas) {

@@ -95,6 +95,12 @@ def load():
     return lib
 
 
+def set_generic_eri(on=True):
+    """every shell-quartet class through the runtime-angular-momentum integral kernel (include/dqc_amd.h:
+    dqc_set_generic_eri) -- normally only the classes with a g shell take it.  Returns the previous setting."""
+    return bool(load().dqc_set_generic_eri(1 if on else 0))
+
+
 def set_deterministic(on=True):
     """bit-reproducible Fock builds: the cross-block sums (J / K accumulators, split-K Vxc, purification trace) use fixed-point
     integer atomics instead of fp64 atomics (include/dqc_amd.h: dqc_set_deterministic).  Returns the previous setting.

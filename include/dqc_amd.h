@@ -267,6 +267,14 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
 int dqc_set_deterministic(int on);
 int dqc_get_deterministic(void);
 
+/* ---- integral-kernel selection (diagnostic) ---------------------------------------------------
+ * Shell-quartet classes s ... f run compile-time instantiations of the Rys kernel; classes holding a g shell (an h companion
+ * in the gradients) run the runtime-angular-momentum kernel (csrc/eri_generic.hpp).  dqc_set_generic_eri(1) sends EVERY class
+ * of dqc_eri_fill_tiles / dqc_jk_direct / dqc_int3c2e / dqc_int2c2e / dqc_eri_grad / dqc_df_grad through the runtime kernel, so
+ * that the two implementations can be compared on the same basis.  Process-wide (environment: DQC_ERI_GENERIC=1), returns the
+ * previous setting. */
+int dqc_set_generic_eri(int on);
+
 /* ---- micro-benchmarks used by bench.py to price the roofline on the box it runs on ---------- */
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream);
 /* fp64 MFMA (16x16x4) issue-rate probe: 2048 waves x 8 accumulators x iters MFMAs; d_out: 131072 doubles */
