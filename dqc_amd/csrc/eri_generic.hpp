@@ -28,6 +28,7 @@ struct HlClass {
     int full;    // 1: one slice holding every Cartesian component of shell a; 0: one component per slice
     int region;  // doubles per shell quartet in LDS (odd)
     int off_h, off_G, off_c, off_jk, off_s;  // areas of a region: g at 0, h, G, transfer coefficients, J/K sums, spherical block
+    int tab_doubles;                         // block-level element descriptors of the two transfer steps, in front of the regions
 };
 
 // root r of the n-point rule (n at run time; tables and asymptotics as rys_root1)
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
     __shared__ int s_maxq;
     const int tid = threadIdx.x;
     const int q = tid / TPQ, s = tid % TPQ;
-    double *reg = lds + (size_t)q * hc.region;
+    double *reg = lds + hc.tab_doubles + (size_t)q * hc.region;
     const int la = hc.la, lb = hc.lb, lc = hc.lc, ld = hc.ld, nr = hc.nr;
     const int nmax = la + lb, mmax = lc + ld, M1 = mmax + 1;
     const int nca = c_ncart(la), ncb = c_ncart(lb), ncc = c_ncart(lc), ncd = c_ncart(ld);
@@ -71,6 +72,24 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
     const int hsz = ni * (lb + 1) * M1;
     const int g1 = (lb + 1) * (lc + 1) * (ld + 1), Gsz = ni * g1;
     double *gl = reg, *hl = reg + hc.off_h, *Gl = reg + hc.off_G, *ctab = reg + hc.off_c;
+    // element descriptors of the transfer steps A2 / A3, the same for every quartet, slice and primitive quartet of the launch:
+    // decoded once per block (five integer divisions per element -- inside the primitive loop they cost more than the sums)
+    const int nA2 = nitem * hsz, nA3 = nitem * Gsz;
+    int *tabA2 = reinterpret_cast<int *>(lds), *tabA3 = tabA2 + nA2;
+    {
+        const int jm = (lb + 1) * M1, kl = (lc + 1) * (ld + 1);
+        for (int e = tid; e < nA2; e += 256) {
+            const int item = e / hsz, rem = e - item * hsz;
+            const int isel = rem / jm, j = (rem / M1) % (lb + 1), m = rem % M1;
+            tabA2[e] = (item * gsz + isel * M1 + m) | ((item / nr) << 12) | (j << 14);
+        }
+        for (int e = tid; e < nA3; e += 256) {
+            const int item = e / Gsz, rem = e - item * Gsz;
+            const int ij = rem / kl, r2 = rem - ij * kl, k = r2 / (ld + 1), l = r2 - k * (ld + 1);
+            tabA3[e] = (item * hsz + ij * M1 + k) | ((item / nr) << 13) | (l << 15);
+        }
+        __syncthreads();
+    }
 
     long long task = (long long)blockIdx.x * QPB + q;
     const bool active = task < ntask;
@@ -137,27 +156,31 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
     const int nslice = hc.full ? 1 : nca, ncas = hc.full ? nca : 1;
     const int rcd = ncc * ncd, rbcd = ncb * rcd, nouts = ncas * rbcd;
 
+    // 2D-table indices of the outputs a lane owns.  They do not depend on the slice: a slice's tables hold i = a_d only
+    // (index 0), the one-slice form holds every i
+    int oidx[HL_NPT];
+#pragma unroll
+    for (int m = 0; m < HL_NPT; m++) {
+        int n = s + TPQ * m;
+        if (n >= nouts) n = nouts - 1;
+        const int cd = n % ncd, cc = (n / ncd) % ncc, cb = (n / rcd) % ncb, cal = n / rbcd;
+        int ax = 0, ay = 0, az = 0, bx, by, bz, cx, cy, cz, dx, dy, dz;
+        if (hc.full) cart_pow(la, cal, ax, ay, az);
+        cart_pow(lb, cb, bx, by, bz);
+        cart_pow(lc, cc, cx, cy, cz);
+        cart_pow(ld, cd, dx, dy, dz);
+        const int ixx = ((ax * (lb + 1) + bx) * (lc + 1) + cx) * (ld + 1) + dx;
+        const int iyy = ((ay * (lb + 1) + by) * (lc + 1) + cy) * (ld + 1) + dy;
+        const int izz = ((az * (lb + 1) + bz) * (lc + 1) + cz) * (ld + 1) + dz;
+        oidx[m] = ixx | (iyy << 10) | (izz << 20);
+    }
+
     for (int slice = 0; slice < nslice; slice++) {
         int i0[3] = {0, 0, 0};  // first bra-a index of the 2D tables, per direction
         if (!hc.full) cart_pow(la, slice, i0[0], i0[1], i0[2]);
-        int oidx[HL_NPT];
         double acc[HL_NPT];
 #pragma unroll
-        for (int m = 0; m < HL_NPT; m++) {
-            acc[m] = 0.0;
-            int n = s + TPQ * m;
-            if (n >= nouts) n = nouts - 1;
-            const int cd = n % ncd, cc = (n / ncd) % ncc, cb = (n / rcd) % ncb, cal = n / rbcd;
-            int ax, ay, az, bx, by, bz, cx, cy, cz, dx, dy, dz;
-            cart_pow(la, hc.full ? cal : slice, ax, ay, az);
-            cart_pow(lb, cb, bx, by, bz);
-            cart_pow(lc, cc, cx, cy, cz);
-            cart_pow(ld, cd, dx, dy, dz);
-            const int ixx = (((ax - i0[0]) * (lb + 1) + bx) * (lc + 1) + cx) * (ld + 1) + dx;
-            const int iyy = (((ay - i0[1]) * (lb + 1) + by) * (lc + 1) + cy) * (ld + 1) + dy;
-            const int izz = (((az - i0[2]) * (lb + 1) + bz) * (lc + 1) + cz) * (ld + 1) + dz;
-            oidx[m] = ixx | (iyy << 10) | (izz << 20);
-        }
+        for (int m = 0; m < HL_NPT; m++) acc[m] = 0.0;
         eri_group_sync<TPQ>();  // the previous slice's transform buffers are free (they alias the tables below)
 
         for (int iq = 0; iq < maxq; iq++) {
@@ -213,13 +236,9 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
             eri_group_sync<TPQ>();
             // ---------------- A2: bra transfer h[item][i][j][m] = sum_a C(j, a) AB^(j-a) g[item][i + a][m] ----------------
             if (on) {
-                const int jm = (lb + 1) * M1;
-                for (int e = s; e < nitem * hsz; e += TPQ) {
-                    const int item = e / hsz, rem = e - item * hsz;
-                    const int isel = rem / jm, j = (rem / M1) % (lb + 1), m = rem % M1;
-                    const int d = item / nr;
-                    const int i = (d == 0 ? i0[0] : (d == 1 ? i0[1] : i0[2])) + isel;
-                    const double *gi = gl + (size_t)item * gsz + i * M1 + m;
+                for (int e = s; e < nA2; e += TPQ) {
+                    const int ds_ = tabA2[e], d = (ds_ >> 12) & 3, j = ds_ >> 14;
+                    const double *gi = gl + (ds_ & 4095) + (d == 0 ? i0[0] : (d == 1 ? i0[1] : i0[2])) * M1;
                     const double *cf = ctab + d * 25 + j * 5;
                     double v = 0.0;
                     for (int a = 0; a <= j; a++) v += cf[a] * gi[a * M1];
@@ -229,12 +248,9 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
             eri_group_sync<TPQ>();
             // ---------------- A3: ket transfer G[item][i][j][k][l] = sum_b C(l, b) CD^(l-b) h[item][i][j][k + b] ----------------
             if (on) {
-                const int kl = (lc + 1) * (ld + 1);
-                for (int e = s; e < nitem * Gsz; e += TPQ) {
-                    const int item = e / Gsz, rem = e - item * Gsz;
-                    const int ij = rem / kl, r2 = rem - ij * kl, k = r2 / (ld + 1), l = r2 - k * (ld + 1);
-                    const int d = item / nr;
-                    const double *hi = hl + (size_t)item * hsz + ij * M1 + k;
+                for (int e = s; e < nA3; e += TPQ) {
+                    const int ds_ = tabA3[e], d = (ds_ >> 13) & 3, l = ds_ >> 15;
+                    const double *hi = hl + (ds_ & 8191);
                     const double *cf = ctab + 75 + d * 25 + l * 5;
                     double v = 0.0;
                     for (int b = 0; b <= l; b++) v += cf[b] * hi[b];
@@ -481,16 +497,18 @@ inline bool hl_plan(int mode, int la, int lb, int lc, int ld, HlPlan &p) {
         }
         HlClass hc{la, lb, lc, ld, nr, full, 0, nitem * gsz, nitem * (gsz + hsz), core, core + 150, core + 150 + njk};
         hc.region = (core + 150 + njk + nsph) | 1;
+        if (nitem * gsz > 4095 || nitem * hsz > 8191) continue;  // packed descriptors
+        hc.tab_doubles = ((nitem * (hsz + Gsz) + 1) / 2 + 1) & ~1;
         const int tpqs[3] = {16, 64, 256};
         for (int t = 0; t < 3; t++) {
             const int tpq = tpqs[t];
             if (nouts > HL_NPT * tpq) continue;
-            const size_t bytes = sizeof(double) * (size_t)hc.region * (256 / tpq);
+            const size_t bytes = sizeof(double) * ((size_t)hc.region * (256 / tpq) + hc.tab_doubles);
             if (bytes > (size_t)HL_LDS_LIMIT) continue;
             if (mode == ERI_OUT_GRAD && tpq == 256 && hc.region < 16) hc.region = 17;
             p.hc = hc;
             p.tpq = tpq;
-            p.lds_bytes = sizeof(double) * (size_t)hc.region * (256 / tpq);
+            p.lds_bytes = sizeof(double) * ((size_t)hc.region * (256 / tpq) + hc.tab_doubles);
             return true;
         }
     }

@@ -155,7 +155,7 @@ int dqc_xc_eval_mgga_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, do
  * (dqc/hamilton/intor/molintor.py:36-72, 121-130).  atm/bas/env are the CONCATENATED host tables of
  * LibcintWrapper.concatenate (dqc/hamilton/intor/lcintwrap.py:299-370): orbital shells [sh0, sh1), auxiliary
  * shells [k0, k1) -- the `shell_idxs` of the two sub-wrappers.  Outputs are row-major device arrays:
- * d_j3c (nao, nao, naux) and d_j2c (naux, naux).  Shells up to f. */
+ * d_j3c (nao, nao, naux) and d_j2c (naux, naux).  Shells up to g. */
 int dqc_int3c2e(double *d_j3c, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
                 int sh0, int sh1, int k0, int k1, void *stream);
 int dqc_int2c2e(double *d_j2c, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
@@ -177,7 +177,7 @@ int dqc_df_coulomb(double *d_j, const double *d_j3c, const double *d_inv_j2c, co
  *   dqc_int1e_grad: 2 sum_{a in A} sum_b [D_ab (d_A a|T+V|b) - W_ab (d_A a|b)]  + Hellmann-Feynman term of every nucleus
  *   dqc_eri_grad  : sum_{a in A} sum_bcd (d_A a b|c d) [2 jscale D_ab D_cd - kscale D_ac D_bd]
  *                   (RHF: (1, 1); RKS: (1, 0); UHF: (1, 0) with the total density plus (0, 2) with each spin density)
- * Shells up to f. */
+ * Shells up to g (companions up to h). */
 int dqc_ncart(const int *bas, int nbas);
 int dqc_cart2sph_matrix(double *h_out, const int *bas, int nbas);
 int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart, const int *atm, int natm,
@@ -189,7 +189,7 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
  * over the concatenated tables of dqc_int3c2e; d_dcart (ncart, ncart) / d_ccart (ncart): density matrix and fit
  * coefficients in the Cartesian basis of ALL shells of the table (T^T . T with T = dqc_cart2sph_matrix of the whole table;
  * zero outside the orbital block / the auxiliary segment).  d_grad has one row per atom OF THE TABLE (the concatenated
- * table lists the molecule's atoms twice: the caller folds the two halves).  Shells up to f. */
+ * table lists the molecule's atoms twice: the caller folds the two halves).  Shells up to g. */
 int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, const int *atm, int natm, const int *bas,
                 int nbas, const double *env, int nenv, int sh0, int sh1, int k0, int k1, void *stream);
 
