@@ -26,16 +26,28 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _deps(path, seen=None):
+    """the file and every header it includes with quotes, transitively (an edit of eri_core.hpp does not rebuild the grid kernels)"""
+    import re
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as f:
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), flags=re.M):
+            _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
-    headers.append(os.path.join(HERE, "..", "include", "dqc_amd.h"))
     hipcc = _hipcc()
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, sorted(_deps(src))):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):
@@ -61,11 +73,10 @@ def build_variant(name, defines, force=False):
     build()
     hipcc = _hipcc()
     out = os.path.join(HERE, "libdqc_amd_%s.so" % name)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc", ".h"))]
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES if s not in GRID_SOURCES]
     for src in GRID_SOURCES:
         obj = os.path.join(OBJ, "%s_%s.o" % (src.replace(".hip", ""), name))
-        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+        if force or _stale(obj, sorted(_deps(os.path.join(CSRC, src)))):
             subprocess.check_call([hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj])
         objs.append(obj)
     if force or _stale(out, objs):

@@ -30,6 +30,9 @@
 //     bound (48 % of the wave cycles in issue stalls: Clenshaw recurrences, fp64 divisions), ~35 % VALU utilisation.
 //   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
 //   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
+#include <algorithm>
+#include <memory>
+
 #include "eri_generic.hpp"
 
 namespace dqc {
@@ -89,32 +92,71 @@ struct ClassLoop {
 // ---------------------------------------------------------------------------------------------
 // direct SCF: J / K straight from the shell quartets (nothing stored)
 // ---------------------------------------------------------------------------------------------
+// screened task maps of one J / K pass (direct-SCF context below): per class pair (cb >= ck) the slice of the device array of
+// prefix offsets (EriOut::toff) and the number of surviving tasks (waves, for the one-lane-per-quartet classes)
+constexpr int NCLS_ALL = (DQC_LMAX + 1) * (DQC_LMAX + 2) / 2;
+struct ScreenPlan {
+    const long long *d_toff = nullptr;
+    const int *d_bins = nullptr;  // (NCLS_ALL, SCREEN_NBIN + 1) bin starts of every pair class, relative to the class start
+    long long start[NCLS_ALL][NCLS_ALL], total[NCLS_ALL][NCLS_ALL];
+};
+
 template <int LA, int LB, int LC, int LD>
-static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st) {
+static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st,
+                           const ScreenPlan *sp = nullptr) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
     if (nb == 0 || nk == 0 || hl_forced()) return 0;
     const int same = cb == ck;
-    const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
-    const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
+    long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+    long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
+    EriOut o2 = og;
+    if (sp) {
+        ntask = sp->total[cb][ck];
+        if (ntask == 0) return 0;
+        o2.toff = sp->d_toff + sp->start[cb][ck];
+        o2.pbin = sp->d_bins + (Cfg::TPQ == 1 ? cb : ck) * (SCREEN_NBIN + 1);  // bins of the PARTNER list the prefixes run over
+        nblk = Cfg::TPQ == 1 ? (ntask + 3) / 4 : (ntask + Cfg::QPB - 1) / Cfg::QPB;
+    }
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_JK);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_JK, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
-                       nb, hp.cls_start[ck], nk, same, ntask, og);
+                       nb, hp.cls_start[ck], nk, same, ntask, o2);
     DQC_CHECK_LAUNCH();
     return 0;
 }
 
 template <int CB, int CK>
 struct ClassLoopJK {
-    static int run(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st) {
+    static int run(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st,
+                   const ScreenPlan *sp = nullptr) {
         constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
         constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
-        int rc = launch_class_jk<LA, LB, LC, LD>(ds, dp, hp, og, st);
+        int rc = launch_class_jk<LA, LB, LC, LD>(ds, dp, hp, og, st, sp);
         if (rc) return rc;
-        if constexpr (CK > 0) return ClassLoopJK<CB, CK - 1>::run(ds, dp, hp, og, st);
-        else if constexpr (CB > 0) return ClassLoopJK<CB - 1, CB - 1>::run(ds, dp, hp, og, st);
+        if constexpr (CK > 0) return ClassLoopJK<CB, CK - 1>::run(ds, dp, hp, og, st, sp);
+        else if constexpr (CB > 0) return ClassLoopJK<CB - 1, CB - 1>::run(ds, dp, hp, og, st, sp);
+        else return 0;
+    }
+};
+
+// Schwarz bounds: the diagonal quartets (ab|ab) of every pair class (task map `same` = 2), max |.| into d_q[pair]
+template <int CB>
+struct ClassLoopSchwarz {
+    static int run(double *d_q, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st) {
+        constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
+        using Cfg = EriCfg<LA, LB, LA, LB>;
+        const int nb = hp.cls_count[CB];
+        if (nb > 0 && !hl_forced()) {
+            auto kern = eri_kernel<LA, LB, LA, LB, ERI_OUT_SCHWARZ>;
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+            const long long nblk = ((long long)nb + Cfg::QPB - 1) / Cfg::QPB;
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, d_q, ds, dp, dp, hp.cls_start[CB], nb,
+                               hp.cls_start[CB], nb, 2, (long long)nb, EriOut{0, 0, 0, 0});
+            DQC_CHECK_LAUNCH();
+        }
+        if constexpr (CB > 0) return ClassLoopSchwarz<CB - 1>::run(d_q, ds, dp, hp, st);
         else return 0;
     }
 };
@@ -123,7 +165,7 @@ struct ClassLoopJK {
 // (eri_generic.hpp); DQC_ERI_GENERIC=1: all classes
 template <int MODE>
 static int run_generic_classes(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og,
-                               hipStream_t st) {
+                               hipStream_t st, const ScreenPlan *sp = nullptr) {
     for (int la = 0; la <= DQC_LMAX; la++)
         for (int lb = 0; lb <= la; lb++)
             for (int lc = 0; lc <= la; lc++)
@@ -131,8 +173,16 @@ static int run_generic_classes(double *tiles, const DevShells &ds, const DevPair
                     const int cb = la * (la + 1) / 2 + lb, ck = lc * (lc + 1) / 2 + ld;
                     if (ck > cb) continue;
                     if (!hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX) continue;
+                    if (MODE == ERI_OUT_SCHWARZ && ck != cb) continue;  // diagonal quartets only
+                    EriOut o2 = og;
+                    long long nscr = -1;
+                    if (sp) {
+                        nscr = sp->total[cb][ck];
+                        o2.toff = sp->d_toff + sp->start[cb][ck];
+                        o2.pbin = sp->d_bins + ck * (SCREEN_NBIN + 1);
+                    }
                     int rc = launch_hl<MODE>(tiles, ds, dp, dp, hp.cls_start[cb], hp.cls_count[cb], hp.cls_start[ck],
-                                             hp.cls_count[ck], cb == ck, og, la, lb, lc, ld, st);
+                                             hp.cls_count[ck], MODE == ERI_OUT_SCHWARZ ? 2 : (cb == ck), o2, la, lb, lc, ld, st, nscr);
                     if (rc) return rc;
                 }
     return 0;
@@ -160,6 +210,155 @@ __global__ void jk_direct_finish_kernel(double *__restrict__ J, double *__restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// direct-SCF context: pair tables and Schwarz bounds resident on the device, screened J / K passes
+// ---------------------------------------------------------------------------------------------
+// Round-3 direct builds re-parsed the basis and re-built / re-uploaded the pair tables in every call and evaluated every unique
+// shell quartet.  The context keeps the tables on the device, holds Q_ab = sqrt(max |(ab|ab)|) for every shell pair (one pass
+// over the diagonal quartets at creation) and sorts the pairs of every class by Q, descending.  A J / K pass of a density D
+// then launches, per class pair, only the tasks with Q_ab Q_cd 4 max|D| >= tau -- for a bra pair these are a PREFIX of the ket
+// list, so the surviving tasks are described by one prefix-offset array (two-pointer sweep on the host, O(pairs) per class
+// pair) and the kernel finds its bra pair by bisection; inside the kernel the same test runs per quartet with the maxima of
+// the shell-pair density blocks that quartet actually touches.  tau = 0: no screening (every quartet, as dqc_jk_direct).
+// J and K are linear in D, so the SCF driver hands over density DIFFERENCES (hamilton.py): as the SCF converges max|dD| falls
+// and the screened share of the quartets with it.
+struct DirectCtx {
+    Basis b;
+    HostPairs hp;           // Schwarz-sorted inside every class
+    std::vector<double> q;  // bound of every pair, table order
+    DevPool pool;           // synchronous pool: owns the context's device memory until destroy
+    DevShells ds;
+    DevPairs dp{nullptr, nullptr, nullptr};
+    double *d_q = nullptr, *d_dsh = nullptr, *d_sym = nullptr, *d_a = nullptr, *d_b = nullptr, *d_dmax = nullptr;
+    long long *d_toff = nullptr;
+    int *d_bins = nullptr;
+    std::vector<int> bins;  // (NCLS_ALL, SCREEN_NBIN + 1): starts of the contraction-depth bins of every class (relative)
+    std::vector<long long> h_toff;
+    long long stat_total = 0, stat_launched = 0;  // unique quartets / quartets launched, last pass
+    double stat_dmax = 0.0;
+};
+
+static void class_l(int c, int &la, int &lb) {
+    la = 0;
+    while ((la + 1) * (la + 2) / 2 <= c) la++;
+    lb = c - la * (la + 1) / 2;
+}
+
+// pairs of every class re-ordered by contraction-depth bin (deepest first), then by their Schwarz bound, descending;
+// bins: (NCLS_ALL, SCREEN_NBIN + 1) bin starts relative to the class start
+static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vector<int> &bins) {
+    const size_t np = q.size();
+    std::vector<int> perm(np);
+    for (size_t i = 0; i < np; i++) perm[i] = (int)i;
+    auto binof = [&](int x) { return screen_bin(hp.pp_off[x + 1] - hp.pp_off[x]); };
+    bins.assign((size_t)NCLS_ALL * (SCREEN_NBIN + 1), 0);
+    for (int c = 0; c < NCLS_ALL; c++) {
+        if (hp.cls_count[c] == 0) continue;
+        std::stable_sort(perm.begin() + hp.cls_start[c], perm.begin() + hp.cls_start[c] + hp.cls_count[c], [&](int x, int y) {
+            const int bx = binof(x), by = binof(y);
+            if (bx != by) return bx < by;
+            return q[x] > q[y];
+        });
+        int *bs = bins.data() + (size_t)c * (SCREEN_NBIN + 1);
+        for (int i = 0; i < hp.cls_count[c]; i++) bs[binof(perm[hp.cls_start[c] + i]) + 1]++;
+        for (int k = 0; k < SCREEN_NBIN; k++) bs[k + 1] += bs[k];
+    }
+    HostPairs n;
+    for (int c = 0; c < 48; c++) { n.cls_start[c] = hp.cls_start[c]; n.cls_count[c] = hp.cls_count[c]; }
+    std::vector<double> nq(np);
+    n.pp_off.push_back(0);
+    n.sh.reserve(hp.sh.size());
+    n.pp.reserve(hp.pp.size());
+    for (size_t i = 0; i < np; i++) {
+        const int o = perm[i];
+        nq[i] = q[o];
+        n.sh.push_back(hp.sh[2 * o]);
+        n.sh.push_back(hp.sh[2 * o + 1]);
+        n.pp.insert(n.pp.end(), hp.pp.begin() + (size_t)hp.pp_off[o] * 5, hp.pp.begin() + (size_t)hp.pp_off[o + 1] * 5);
+        n.pp_off.push_back((int)n.pp.size() / 5);
+    }
+    hp = std::move(n);
+    q = std::move(nq);
+}
+
+// prefix offsets of the surviving tasks of every class pair for the coarse test Q_b Q_k >= tc: SCREEN_NBIN entries per pair,
+// one per contraction-depth bin of the partner class (inside a bin the partners are sorted by their bound, descending, so the
+// survivors are a prefix and a two-pointer sweep per (bin, bin) block finds them all)
+static void plan_screen(DirectCtx &c, double tc, ScreenPlan &sp) {
+    c.h_toff.clear();
+    c.stat_total = c.stat_launched = 0;
+    std::vector<long long> cnt;
+    for (int cb = 0; cb < NCLS_ALL; cb++)
+        for (int ck = 0; ck <= cb; ck++) {
+            sp.start[cb][ck] = (long long)c.h_toff.size();
+            sp.total[cb][ck] = 0;
+            const int nb = c.hp.cls_count[cb], nk = c.hp.cls_count[ck];
+            if (nb == 0 || nk == 0) continue;
+            int la, lb, lc, ld;
+            class_l(cb, la, lb);
+            class_l(ck, lc, ld);
+            const bool same = cb == ck;
+            c.stat_total += same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+            const bool tpq1 = !hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX && eri_tpq(ncart(la) * ncart(lb) * ncart(lc) * ncart(ld)) == 1;
+            const double *qb = c.q.data() + c.hp.cls_start[cb], *qk = c.q.data() + c.hp.cls_start[ck];
+            const int *bb = c.bins.data() + (size_t)cb * (SCREEN_NBIN + 1), *bk = c.bins.data() + (size_t)ck * (SCREEN_NBIN + 1);
+            const int nown = tpq1 ? nk : nb;  // the list the entries belong to: ket pairs (one lane per quartet) or bra pairs
+            cnt.assign((size_t)nown * SCREEN_NBIN, 0);
+            for (int ab = 0; ab < SCREEN_NBIN; ab++)      // bra bin
+                for (int kb = 0; kb < SCREEN_NBIN; kb++) {  // ket bin
+                    const int b0 = bb[ab], b1 = bb[ab + 1], k0 = bk[kb], k1 = bk[kb + 1];
+                    if (b0 == b1 || k0 == k1) continue;
+                    if (tpq1) {  // per ket pair: 64-bra-pair chunks of bra bin `ab` (the triangle keeps bra >= ket)
+                        int ptr = b1 - b0;
+                        for (int ik = k0; ik < k1; ik++) {
+                            while (ptr > 0 && !(qb[b0 + ptr - 1] * qk[ik] >= tc)) ptr--;
+                            const int c0 = (same && ik > b0) ? ((ik - b0) >> 6) : 0;
+                            int chunks = (ptr + 63) / 64 - c0;
+                            if (chunks < 0) chunks = 0;
+                            cnt[(size_t)ik * SCREEN_NBIN + ab] = chunks;
+                            const int lo = same ? std::max(ik - b0, 0) : 0;
+                            c.stat_launched += ptr > lo ? ptr - lo : 0;
+                        }
+                    } else {  // per bra pair: a prefix of ket bin `kb`
+                        int ptr = k1 - k0;
+                        for (int ib = b0; ib < b1; ib++) {
+                            while (ptr > 0 && !(qb[ib] * qk[k0 + ptr - 1] >= tc)) ptr--;
+                            int n = ptr;
+                            if (same) n = std::max(0, std::min(n, ib + 1 - k0));
+                            cnt[(size_t)ib * SCREEN_NBIN + kb] = n;
+                            c.stat_launched += n;
+                        }
+                    }
+                }
+            long long run = 0;
+            c.h_toff.push_back(0);
+            for (size_t e = 0; e < cnt.size(); e++) {
+                run += cnt[e];
+                c.h_toff.push_back(run);
+            }
+            sp.total[cb][ck] = run;
+        }
+}
+
+// max |D| over the AO block of every shell pair, and over the whole matrix (non-negative doubles order like their bit patterns)
+__global__ void shell_dmax_kernel(double *__restrict__ dsh, double *__restrict__ dmax, const double *__restrict__ dsym,
+                                  const int *__restrict__ ao_off, const int *__restrict__ shl, int nsh, int nao) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double m = 0.0;
+    if (e < (long long)nsh * nsh) {
+        const int i = (int)(e / nsh), j = (int)(e % nsh);
+        const int ni = 2 * shl[i] + 1, nj = 2 * shl[j] + 1;
+        const double *p = dsym + (size_t)ao_off[i] * nao + ao_off[j];
+        for (int a = 0; a < ni; a++)
+            for (int b_ = 0; b_ < nj; b_++) m = fmax(m, fabs(p[(size_t)a * nao + b_]));
+        dsh[e] = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long *>(dmax), (unsigned long long)__double_as_longlong(m));
+}
 }  // namespace dqc
 
 extern "C" {
@@ -198,6 +397,136 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
     if (rc) return rc;
     if ((rc = run_generic_classes<ERI_OUT_JK>(nullptr, ds, dp, hp, og, st))) return rc;
     hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, d_a, d_b, b.nao);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+int dqc_direct_create(void **ctx_out, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
+                      void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx_out) { set_error("dqc_direct_create: null handle"); return DQC_EINVAL; }
+    *ctx_out = nullptr;
+    std::unique_ptr<DirectCtx> c(new DirectCtx());
+    int rc = parse_basis(c->b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    if (nbas == 0 || c->b.nao == 0) { set_error("dqc_direct_create: empty basis"); return DQC_EINVAL; }
+    if ((rc = boys_table_ensure())) return rc;
+    build_pairs(c->b, c->hp);
+    const size_t np = c->hp.sh.size() / 2, n2 = (size_t)c->b.nao * c->b.nao, nsh = c->b.shells.size();
+    if ((rc = upload_shells(c->ds, c->b, c->pool, st))) { set_error("dqc_direct_create: device upload failed"); return rc; }
+    c->q.assign(np, 0.0);
+    {   // Schwarz bounds from the unsorted tables (scratch of this block only)
+        DevPool tmp;
+        int *d_sh = nullptr, *d_off = nullptr;
+        double *d_pp = nullptr, *d_q0 = nullptr;
+        if ((rc = tmp.upload(&d_sh, c->hp.sh, st)) || (rc = tmp.upload(&d_off, c->hp.pp_off, st)) || (rc = tmp.upload(&d_pp, c->hp.pp, st)) ||
+            (rc = tmp.alloc(&d_q0, np))) {
+            set_error("dqc_direct_create: device allocation failed");
+            return rc;
+        }
+        DQC_HIP(hipMemsetAsync(d_q0, 0, sizeof(double) * np, st));
+        DevPairs dp0{d_sh, d_off, d_pp};
+        constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
+        if ((rc = ClassLoopSchwarz<NCLS - 1>::run(d_q0, c->ds, dp0, c->hp, st))) return rc;
+        if ((rc = run_generic_classes<ERI_OUT_SCHWARZ>(d_q0, c->ds, dp0, c->hp, EriOut{0, 0, 0, 0}, st))) return rc;
+        DQC_HIP(hipMemcpyAsync(c->q.data(), d_q0, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+        DQC_HIP(hipStreamSynchronize(st));
+    }
+    for (double &v : c->q) v = std::sqrt(v);
+    sort_pairs_by_bound(c->hp, c->q, c->bins);
+    int *d_sh = nullptr, *d_off = nullptr;
+    double *d_pp = nullptr;
+    size_t ntoff = 0;
+    for (int cb = 0; cb < NCLS_ALL; cb++)
+        for (int ck = 0; ck <= cb; ck++)
+            if (c->hp.cls_count[cb] && c->hp.cls_count[ck])
+                ntoff += (size_t)std::max(c->hp.cls_count[cb], c->hp.cls_count[ck]) * SCREEN_NBIN + 1;
+    if ((rc = c->pool.upload(&d_sh, c->hp.sh, st)) || (rc = c->pool.upload(&d_off, c->hp.pp_off, st)) ||
+        (rc = c->pool.upload(&d_pp, c->hp.pp, st)) || (rc = c->pool.upload(&c->d_q, c->q, st)) || (rc = c->pool.upload(&c->d_bins, c->bins, st)) || (rc = c->pool.alloc(&c->d_dsh, nsh * nsh)) ||
+        (rc = c->pool.alloc(&c->d_sym, n2)) || (rc = c->pool.alloc(&c->d_a, n2)) || (rc = c->pool.alloc(&c->d_b, n2)) ||
+        (rc = c->pool.alloc(&c->d_dmax, 2)) || (rc = c->pool.alloc(&c->d_toff, ntoff))) {
+        set_error("dqc_direct_create: device allocation failed");
+        return rc;
+    }
+    DQC_HIP(hipStreamSynchronize(st));  // the uploads read host vectors that may move
+    c->dp = DevPairs{d_sh, d_off, d_pp};
+    c->h_toff.reserve(ntoff);
+    *ctx_out = c.release();
+    return DQC_OK;
+}
+
+int dqc_direct_destroy(void *ctx) {
+    delete static_cast<dqc::DirectCtx *>(ctx);  // the pool frees the device memory
+    return DQC_OK;
+}
+
+int dqc_direct_npairs(void *ctx) { return ctx ? (int)static_cast<dqc::DirectCtx *>(ctx)->q.size() : 0; }
+
+int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells) {
+    // HOST arrays: the Schwarz bound of every shell pair (npairs) and its two shells (npairs, 2), in table order
+    if (!ctx) { dqc::set_error("dqc_direct_bounds: null context"); return DQC_EINVAL; }
+    const dqc::DirectCtx &c = *static_cast<dqc::DirectCtx *>(ctx);
+    for (size_t i = 0; i < c.q.size(); i++) {
+        if (h_q) h_q[i] = c.q[i];
+        if (h_shells) { h_shells[2 * i] = c.hp.sh[2 * i]; h_shells[2 * i + 1] = c.hp.sh[2 * i + 1]; }
+    }
+    return DQC_OK;
+}
+
+int dqc_direct_stats(void *ctx, long long *quartets_total, long long *quartets_launched, double *dmax) {
+    if (!ctx) { dqc::set_error("dqc_direct_stats: null context"); return DQC_EINVAL; }
+    const dqc::DirectCtx &c = *static_cast<dqc::DirectCtx *>(ctx);
+    if (quartets_total) *quartets_total = c.stat_total;
+    if (quartets_launched) *quartets_launched = c.stat_launched;
+    if (dmax) *dmax = c.stat_dmax;
+    return DQC_OK;
+}
+
+int dqc_direct_jk(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx) { set_error("dqc_direct_jk: null context"); return DQC_EINVAL; }
+    if (!(tau >= 0.0)) { set_error("dqc_direct_jk: tau must be >= 0"); return DQC_EINVAL; }
+    DirectCtx &c = *static_cast<DirectCtx *>(ctx);
+    const int nao = c.b.nao, nsh = (int)c.b.shells.size();
+    hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, c.d_sym, c.d_a, d_K ? c.d_b : nullptr, d_dm, nao);
+    DQC_CHECK_LAUNCH();
+    EriOut og{nao, 0, 0, 0};
+    og.dmat = c.d_sym;
+    og.jacc = c.d_a;
+    og.kacc = d_K ? c.d_b : nullptr;
+    ScreenPlan sp;
+    const ScreenPlan *spp = nullptr;
+    int rc;
+    if (tau > 0.0) {
+        DQC_HIP(hipMemsetAsync(c.d_dmax, 0, sizeof(double) * 2, st));
+        const long long npr = (long long)nsh * nsh;
+        hipLaunchKernelGGL(shell_dmax_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dsh, c.d_dmax, c.d_sym, c.ds.ao_off,
+                           c.ds.l, nsh, nao);
+        DQC_CHECK_LAUNCH();
+        double dmax = 0.0;
+        DQC_HIP(hipMemcpyAsync(&dmax, c.d_dmax, sizeof(double), hipMemcpyDeviceToHost, st));
+        DQC_HIP(hipStreamSynchronize(st));  // the launch sizes of this pass depend on max |D|
+        c.stat_dmax = dmax;
+        plan_screen(c, dmax > 0.0 ? tau / (4.0 * dmax) : INFINITY, sp);
+        if (!c.h_toff.empty())
+            DQC_HIP(hipMemcpyAsync(c.d_toff, c.h_toff.data(), sizeof(long long) * c.h_toff.size(), hipMemcpyHostToDevice, st));
+        sp.d_toff = c.d_toff;
+        sp.d_bins = c.d_bins;
+        spp = &sp;
+        og.pq = c.d_q;
+        og.dsh = c.d_dsh;
+        og.tau = tau;
+        og.nsh = nsh;
+    } else {
+        plan_screen(c, 0.0, sp);  // statistics only: every quartet is launched through the dense maps
+        c.stat_launched = c.stat_total;
+    }
+    constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
+    if ((rc = ClassLoopJK<NCLS - 1, NCLS - 1>::run(c.ds, c.dp, c.hp, og, st, spp))) return rc;
+    if ((rc = run_generic_classes<ERI_OUT_JK>(nullptr, c.ds, c.dp, c.hp, og, st, spp))) return rc;
+    hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, c.d_a, c.d_b, nao);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

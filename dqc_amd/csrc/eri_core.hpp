@@ -83,7 +83,7 @@ struct EriCfg {
     static constexpr int SA = 2 * LA + 1, SB = 2 * LB + 1, SC = 2 * LC + 1, SD = 2 * LD + 1;
     static constexpr int NOUT = NCA * NCB * NCC * NCD;
     static constexpr int G1 = (LA + 1) * (LB + 1) * (LC + 1) * (LD + 1);
-    static constexpr int TPQ = NOUT <= 9 ? 1 : (NOUT <= 81 ? 4 : (NOUT <= 324 ? 16 : (NOUT <= 1296 ? 64 : 256)));
+    static constexpr int TPQ = NOUT <= 9 ? 1 : (NOUT <= 81 ? 4 : (NOUT <= 324 ? 16 : (NOUT <= 1296 ? 64 : 256)));  // = eri_tpq(NOUT)
     static constexpr int QPB = 256 / TPQ;
     static constexpr int NPT = (NOUT + TPQ - 1) / TPQ;
     static constexpr int GSZ = 3 * NR * G1;
@@ -124,7 +124,13 @@ struct EriCfg {
 //   ERI_OUT_JK    : direct SCF -- nothing is stored; the spherical block of every unique shell quartet is contracted with the
 //                   density on the fly (J_ab += (ab|cd) D_cd, J_cd += (ab|cd) D_ab, four exchange products), summed per
 //                   quartet in LDS and added to the global accumulators with one atomic per (shell-pair) element
-enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3, ERI_OUT_JK = 4 };
+//   ERI_OUT_SCHWARZ : the diagonal quartets (ab|ab) only (task map `same` = 2): max over the spherical block of |(ab|ab)| per
+//                   shell pair -> tiles[pair] (as the bit pattern of a non-negative double, atomicMax) -- the Schwarz bounds
+//                   Q_ab = sqrt(max |(ab|ab)|), |(ab|cd)| <= Q_ab Q_cd, of the screened direct SCF (dqc_direct_*)
+enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3, ERI_OUT_JK = 4, ERI_OUT_SCHWARZ = 5 };
+
+// lane-group size of a compile-time class by its Cartesian block size (EriCfg::TPQ; the host's screened task maps need it too)
+__host__ __device__ constexpr int eri_tpq(int nout) { return nout <= 9 ? 1 : (nout <= 81 ? 4 : (nout <= 324 ? 16 : (nout <= 1296 ? 64 : 256))); }
 
 // 256-thread blocks of one class launch: QPB consecutive tasks per block, or -- one-lane-per-quartet classes, wave-transposed
 // task map (see the kernel) -- one (64-bra-pair chunk, ket pair) per wave
@@ -156,7 +162,47 @@ struct EriOut {
     // ---- JK mode: symmetric AO density (nao, nao), accumulators A (J = (A + A^T) / 2) and B (K = B + B^T; NULL: J only)
     const double *dmat = nullptr;
     double *jacc = nullptr, *kacc = nullptr;
+    // ---- screened task map (JK mode of the direct-SCF context, eri.hip): pairs sorted by their Schwarz bound inside a class
+    //   toff  : prefix offsets of the surviving tasks.  Lane groups of > 1 lane: per BRA pair ib the kets [0, toff[ib+1] -
+    //           toff[ib]) survive (a prefix: the ket list is sorted too), task -> ib by bisection.  One lane per quartet
+    //           (wave-transposed map): per KET pair the number of 64-bra-pair chunks, wave -> ket by bisection.
+    //   pq    : Schwarz bound of every pair (index = position in the pair table)
+    //   dsh   : (nsh, nsh) max |D| over the AO block of every shell pair -- the per-quartet test
+    //           Q_ab Q_cd max(4 |D_ab|, 4 |D_cd|, |D_ac|, |D_ad|, |D_bc|, |D_bd|) < tau skips the quartet (exchange blocks only with K)
+    //   pbin  : the pairs of a class are ordered by contraction-depth bin (SCREEN_NBIN bins of the primitive-pair count, deepest
+    //           first), then by bound: neighbouring lanes keep equally deep primitive loops (sorted by the bound alone a C5-size
+    //           pass was 37 % slower), and the surviving partners of a pair are one prefix PER BIN -- toff has SCREEN_NBIN
+    //           entries per pair, pbin the SCREEN_NBIN + 1 bin starts of the partner class (relative to the class start)
+    const long long *toff = nullptr;
+    const double *pq = nullptr, *dsh = nullptr;
+    const int *pbin = nullptr;
+    double tau = 0.0;
+    int nsh = 0;
 };
+constexpr int SCREEN_NBIN = 8;
+// contraction-depth bin of a pair with npp surviving primitive pairs: 0 = deepest (> 64) ... 7 = one primitive pair (or none)
+__host__ __device__ constexpr int screen_bin(int npp) {
+    return npp > 64 ? 0 : (npp > 32 ? 1 : (npp > 16 ? 2 : (npp > 8 ? 3 : (npp > 4 ? 4 : (npp > 2 ? 5 : (npp > 1 ? 6 : 7))))));
+}
+
+// largest i in [0, n) with off[i] <= t (off has n + 1 non-decreasing entries, off[0] = 0 <= t < off[n])
+DQC_DEV int screen_find(const long long *__restrict__ off, int n, long long t) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// the per-quartet density-weighted Schwarz test of the screened direct SCF: true = the quartet contributes less than tau
+DQC_DEV bool screen_skip(const EriOut &og, int ib, int ik, int ish, int jsh, int ksh, int lsh) {
+    const double *d = og.dsh;
+    const size_t n = og.nsh;
+    double m = 4.0 * fmax(d[ish * n + jsh], d[ksh * n + lsh]);
+    if (og.kacc) m = fmax(fmax(m, fmax(d[ish * n + ksh], d[ish * n + lsh])), fmax(d[jsh * n + ksh], d[jsh * n + lsh]));
+    return og.pq[ib] * og.pq[ik] * m < og.tau;
+}
 
 // index of the Cartesian component (lx, ly, lz) of shell l (inverse of cart_pow)
 DQC_DEV int cart_index(int l, int lx, int lz) {
@@ -209,6 +255,29 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
+    if (same == 2) {  // diagonal quartets (ab|ab) only (Schwarz bounds): ntask = nb
+        ib = ik = (int)task;
+    } else if (og.toff != nullptr) {
+        // screened map (direct SCF): the surviving tasks of every bra pair -- or, one lane per quartet, the surviving 64-bra-pair
+        // chunks of every ket pair -- are a prefix of the Schwarz-sorted partner list; ntask counts tasks (waves)
+        if constexpr (TPQ == 1) {
+            const long long wv = (long long)blockIdx.x * 4 + (tid >> 6);
+            const bool inr = wv < ntask;
+            const long long w2 = inr ? wv : ntask - 1;
+            const int e = screen_find(og.toff, nk * SCREEN_NBIN, w2);
+            const int ikl = e / SCREEN_NBIN, bin = e % SCREEN_NBIN;
+            const int bs = og.pbin[bin];                             // the bra bin [bs, be) of this wave's chunk
+            const int c0 = (same && ikl > bs) ? ((ikl - bs) >> 6) : 0;  // (triangle: chunks wholly below the ket pair are not launched)
+            const int ibl = bs + (int)(w2 - og.toff[e] + c0) * 64 + (tid & 63);
+            active = inr && ibl < og.pbin[bin + 1] && (!same || ibl >= ikl);
+            ib = ibl < nb ? ibl : nb - 1;
+            ik = ikl;
+        } else {
+            const int e = screen_find(og.toff, nb * SCREEN_NBIN, task);
+            ib = e / SCREEN_NBIN;
+            ik = og.pbin[e % SCREEN_NBIN] + (int)(task - og.toff[e]);
+        }
+    } else
     if constexpr (TPQ == 1) {
         // one lane per shell quartet: WAVE-TRANSPOSED task map -- the 64 lanes of a wave take 64 consecutive BRA pairs and ONE
         // ket pair.  The primitive loops then read the ket pair's data wave-uniformly (one cache line per load instead of 64:
@@ -235,6 +304,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     ib += b0;
     ik += k0;
     const int ish = prs.sh[2 * ib], jsh = prs.sh[2 * ib + 1], ksh = prk.sh[2 * ik], lsh = prk.sh[2 * ik + 1];
+    if constexpr (MODE == ERI_OUT_JK)
+        if (og.pq != nullptr && active && screen_skip(og, ib, ik, ish, jsh, ksh, lsh)) active = false;
     double A[3], Cc[3], AB[3], CD[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -555,6 +626,10 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             for (int c = 0; c < Cfg::NCD; c++) v += C[md * Cfg::NCD + c] * buf1[mabc * Cfg::NCD + c];
             const int mc = mabc % Cfg::SC, mb = (mabc / Cfg::SC) % Cfg::SB, ma = mabc / (Cfg::SC * Cfg::SB);
             const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
+            if constexpr (MODE == ERI_OUT_SCHWARZ) {
+                if (ma == mc && mb == md)  // non-negative doubles order like their bit patterns
+                    atomicMax(reinterpret_cast<unsigned long long *>(tiles) + ib, (unsigned long long)__double_as_longlong(fabs(v)));
+            } else
             if constexpr (MODE == ERI_OUT_JK) {
                 const double *D = og.dmat;
                 const size_t n = og.nao;

@@ -92,9 +92,16 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
     }
 
     long long task = (long long)blockIdx.x * QPB + q;
-    const bool active = task < ntask;
+    bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
+    if (same == 2) {  // diagonal quartets only (Schwarz bounds)
+        ib = ik = (int)task;
+    } else if (og.toff != nullptr) {  // screened map of the direct-SCF context (eri_core.hpp)
+        const int e = screen_find(og.toff, nb * SCREEN_NBIN, task);
+        ib = e / SCREEN_NBIN;
+        ik = og.pbin[e % SCREEN_NBIN] + (int)(task - og.toff[e]);
+    } else
     if (same) {
         long long r = (long long)((sqrt(8.0 * (double)task + 1.0) - 1.0) * 0.5);
         while (r * (r + 1) / 2 > task) r--;
@@ -108,6 +115,8 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
     ib += b0;
     ik += k0;
     const int ish = prs.sh[2 * ib], jsh = prs.sh[2 * ib + 1], ksh = prk.sh[2 * ik], lsh = prk.sh[2 * ik + 1];
+    if constexpr (MODE == ERI_OUT_JK)
+        if (og.pq != nullptr && active && screen_skip(og, ib, ik, ish, jsh, ksh, lsh)) active = false;
     double A[3], Cc[3], AB[3], CD[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
@@ -414,6 +423,10 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
                 const double v = sphl[e];
                 const int md = e % sd, mc = (e / sd) % sc, mb = (e / (sd * sc)) % sb, ma = e / (sd * sc * sb);
                 const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
+                if constexpr (MODE == ERI_OUT_SCHWARZ) {
+                    if (ma == mc && mb == md)
+                        atomicMax(reinterpret_cast<unsigned long long *>(tiles) + ib, (unsigned long long)__double_as_longlong(fabs(v)));
+                } else
                 if constexpr (MODE == ERI_OUT_JK) {
                     const double *D = og.dmat;
                     const size_t n = og.nao;
@@ -517,15 +530,17 @@ inline bool hl_plan(int mode, int la, int lb, int lc, int ld, HlPlan &p) {
 
 template <int MODE>
 static int launch_hl(double *tiles, const DevShells &ds, const DevPairs &db, const DevPairs &dk, int b0, int nb, int k0, int nk,
-                     int same, const EriOut &og, int la, int lb, int lc, int ld, hipStream_t st) {
+                     int same, const EriOut &og, int la, int lb, int lc, int ld, hipStream_t st, long long ntask_screened = -1) {
     if (nb == 0 || nk == 0) return 0;
     HlPlan p;
-    if (!hl_plan(MODE, la, lb, lc, ld, p)) {
+    if (!hl_plan(MODE == ERI_OUT_SCHWARZ ? ERI_OUT_TILES : MODE, la, lb, lc, ld, p)) {
         set_error("shell quartet class (" + std::to_string(la) + std::to_string(lb) + "|" + std::to_string(lc) + std::to_string(ld) +
                   ") is beyond the integral kernels (angular momentum above g)");
         return DQC_EINVAL;
     }
-    const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+    // task map: dense rectangle / triangle; `same` = 2: the nb diagonal quartets; ntask_screened >= 0: og.toff's total
+    const long long ntask = ntask_screened >= 0 ? ntask_screened : (same == 2 ? (long long)nb : (same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk));
+    if (ntask == 0) return 0;
     const int qpb = 256 / p.tpq;
     const long long nblk = (ntask + qpb - 1) / qpb;
 #define DQC_HL(T)                                                                                                            \

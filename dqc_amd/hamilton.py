@@ -175,8 +175,11 @@ class HamiltonMI355(_Base):
                     "density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...))" % (need / 1e9, tab.nao, free / 1e9))
             self._direct = mode == "direct"
         if self._df is None and self._direct:
-            # direct SCF: no tile store; every J / K call re-evaluates the shell quartets (dqc_jk_direct)
+            # direct SCF: no tile store; every J / K call re-evaluates the shell quartets -- those the
+            # Schwarz bounds do not rule out (dqc_direct_*: tables and bounds stay on the device)
             self._tiles_store, self._jkwork = None, None
+            self._dctx = lib.DirectContext(tab, dev)
+            self._dinc = {}
         elif self._df is None:
             # the fill (VALU-bound, 18 ms for a 20-atom molecule) runs on a side stream while this stream does the small
             # latency-bound setup work -- eigh of S, T, V, their conversions; the streams join at the end of build()
@@ -285,10 +288,37 @@ class HamiltonMI355(_Base):
         self._eri_mode = "direct" if on else "tiles"
         return self
 
-    def _jk_ao(self, dao, with_k):
+    # direct SCF: shell quartets bounded by this much are skipped (DQC_AMD_DIRECT_TAU; 0 = none), and a build adds
+    # G[D - D_prev] to the previous one for at most this many calls in a row before it is redone from D itself
+    _DIRECT_TAU = float(os.environ.get("DQC_AMD_DIRECT_TAU", "1e-13"))
+    _DIRECT_RESET = int(os.environ.get("DQC_AMD_DIRECT_RESET", "12"))
+
+    def _jk_direct(self, dao, with_k, slot):
+        """J, K of one AO density from the shell quartets (screened, dqc_direct_jk).  J and K are linear in D: the builds of
+        one `slot` (one density stream of the SCF loop) are INCREMENTAL -- G[D] = G[D_prev] + G[D - D_prev] -- so that the
+        density-weighted screening sees max |D - D_prev|, which falls as the SCF converges; every _DIRECT_RESET-th build of a
+        slot (or a change of shape / of the K request, or a difference that is no smaller than the density) starts again from D"""
+        tau = self._DIRECT_TAU
+        st = self._dinc.get(slot)
+        if tau > 0 and st is not None and st["n"] < self._DIRECT_RESET and st["k"] == with_k and st["d"].shape == dao.shape:
+            dd = dao - st["d"]
+            J, K = self._dctx.jk(dd, with_k, tau)
+            J += st["J"]
+            if with_k:
+                K += st["K"]
+            n = st["n"] + 1
+        else:
+            J, K = self._dctx.jk(dao, with_k, tau)
+            n = 0
+        self._direct_stats = self._dctx.stats()
+        if tau > 0:
+            self._dinc[slot] = {"d": dao.clone(), "J": J.clone(), "K": None if K is None else K.clone(), "k": with_k, "n": n}
+        return J, K
+
+    def _jk_ao(self, dao, with_k, slot=0):
         """(J, K or None) of one AO-basis density: from the resident tiles, or directly from the shell quartets"""
         if self._direct:
-            return lib.jk_direct(self._tab, dao, with_k)
+            return self._jk_direct(dao, with_k, slot)
         return lib.jk(self._tiles, dao, self._jkwork, with_k)
 
     def _sym_orth(self, m_ao):
@@ -308,8 +338,8 @@ class HamiltonMI355(_Base):
         dj = None if dms_j is None else self._unconvert_dm(dms_j)
         dk = None if dms_k is None else self._unconvert_dm(dms_k)
         if self._direct:  # one pass over the shell quartets per density
-            J = None if dj is None else torch.stack([lib.jk_direct(self._tab, d, False)[0] for d in dj])
-            K = None if dk is None else torch.stack([lib.jk_direct(self._tab, d, True)[1] for d in dk])
+            J = None if dj is None else torch.stack([self._jk_direct(d, False, ("j", i))[0] for i, d in enumerate(dj)])
+            K = None if dk is None else torch.stack([self._jk_direct(d, True, ("k", i))[1] for i, d in enumerate(dk)])
             return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
         J, K = lib.jk_multi(self._tiles, dj, dk, self._multi_work(0 if dj is None else dj.shape[0], 0 if dk is None else dk.shape[0]))
         return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))

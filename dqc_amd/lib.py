@@ -55,6 +55,12 @@ def load():
     lib.dqc_int1e.argtypes = [c_int, c_dp] + tab + [dp, c_vp]
     lib.dqc_eri_fill_tiles.argtypes = [c_dp] + tab + [c_vp]
     lib.dqc_jk_direct.argtypes = [c_dp, c_dp, c_dp] + tab + [c_vp]
+    lib.dqc_direct_create.argtypes = [ctypes.POINTER(c_vp)] + tab + [c_vp]
+    lib.dqc_direct_jk.argtypes = [c_vp, c_dp, c_dp, c_dp, ctypes.c_double, c_vp]
+    lib.dqc_direct_stats.argtypes = [c_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), dp]
+    lib.dqc_direct_npairs.argtypes = [c_vp]
+    lib.dqc_direct_bounds.argtypes = [c_vp, dp, ip]
+    lib.dqc_direct_destroy.argtypes = [c_vp]
     lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
     lib.dqc_ncart.argtypes = [ip, c_int]
@@ -350,6 +356,51 @@ def jk_direct(tab, dm_ao, with_k=True):
     with _on(dm_ao.device) as st_:
         _check(load().dqc_jk_direct(_ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), *tab.args(), st_), "dqc_jk_direct")
     return J, K
+
+
+class DirectContext:
+    """screened direct SCF (include/dqc_amd.h: dqc_direct_*): pair tables and Schwarz bounds resident on the device.
+    `jk(dm, with_k, tau)` skips the shell quartets whose contribution is bounded by `tau` (0: none skipped)."""
+
+    def __init__(self, tab, device):
+        self.device = torch.device(device)
+        self.nao = tab.nao
+        self._h = ctypes.c_void_p()
+        with _on(self.device) as st_:
+            _check(load().dqc_direct_create(ctypes.byref(self._h), *tab.args(), st_), "dqc_direct_create")
+
+    def jk(self, dm_ao, with_k=True, tau=0.0):
+        J = torch.empty((self.nao, self.nao), dtype=torch.float64, device=dm_ao.device)
+        K = torch.empty_like(J) if with_k else None
+        with _on(dm_ao.device) as st_:
+            _check(load().dqc_direct_jk(self._h, _ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), float(tau), st_), "dqc_direct_jk")
+        return J, K
+
+    def stats(self):
+        """(unique shell quartets, quartets launched, max |D|) of the last jk call"""
+        a, b, d = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_double()
+        _check(load().dqc_direct_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(d)), "dqc_direct_stats")
+        return a.value, b.value, d.value
+
+    def bounds(self):
+        """(Q (npairs,), shells (npairs, 2)): Schwarz bound sqrt(max |(ab|ab)|) of every shell pair, table order"""
+        n = int(load().dqc_direct_npairs(self._h))
+        q, sh = np.zeros(n), np.zeros((n, 2), dtype=np.int32)
+        _check(load().dqc_direct_bounds(self._h, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                        sh.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), "dqc_direct_bounds")
+        return q, sh
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            with _on(self.device):
+                load().dqc_direct_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def jk_multi(tiles, dms_j, dms_k, work=None):

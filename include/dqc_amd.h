@@ -258,6 +258,30 @@ int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b
 int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, int natm, const int *bas, int nbas,
                   const double *env, int nenv, void *stream);
 
+/* ---- direct SCF with integral screening: a context that keeps the pair tables and the Schwarz bounds on the device -------
+ * The reference passes prescreen = NULL to libcint (dqc/hamilton/intor/molintor.py:667-688) because it stores the whole
+ * tensor; a direct build pays for every quartet in every iteration, so here the Cauchy-Schwarz bound |(ab|cd)| <= Q_ab Q_cd,
+ * Q_ab = sqrt(max |(ab|ab)|), decides what is evaluated:
+ *   dqc_direct_create  parses the tables, evaluates the diagonal quartets (one device pass, one host synchronisation), sorts the
+ *                      shell pairs of every angular-momentum class by Q and leaves tables + bounds resident on the device;
+ *   dqc_direct_jk      J and K of one density as dqc_jk_direct, skipping every shell quartet whose contribution is bounded by
+ *                      tau:  Q_ab Q_cd max(4 |D_ab|, 4 |D_cd|, |D_ac|, |D_ad|, |D_bc|, |D_bd|) < tau  (block maxima of D; the
+ *                      exchange blocks only when d_K is given).  Quartets are dropped at launch (prefix of the Q-sorted partner
+ *                      list, global max |D|) and per quartet inside the kernel.  tau = 0: every quartet (bit-for-bit the
+ *                      unscreened sums up to the order of the atomics).  One 8-byte device->host read per call (max |D| sets the
+ *                      launch sizes).  J and K are linear in D: hand over density DIFFERENCES to let the screening bite as the
+ *                      SCF converges (HamiltonMI355 does).  The error of an element of J / K is bounded by tau times the number
+ *                      of skipped quartets that touch it; tau = 1e-13 keeps SCF energies within 1e-10 Ha of the unscreened path
+ *                      on the systems of the test suite.
+ *   dqc_direct_stats   unique shell quartets / quartets launched / max |D| of the last dqc_direct_jk call (host scalars);
+ *   dqc_direct_bounds  host copies of the bounds and the shell pairs they belong to (tests). */
+int dqc_direct_create(void **ctx, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);
+int dqc_direct_jk(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, void *stream);
+int dqc_direct_stats(void *ctx, long long *quartets_total, long long *quartets_launched, double *dmax);
+int dqc_direct_npairs(void *ctx);
+int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells);
+int dqc_direct_destroy(void *ctx);
+
 /* ---- deterministic mode ----------------------------------------------------------------------
  * The Fock build sums over blocks with fp64 atomics (J / K accumulators, split-K Vxc partials, the trace of the purification
  * iterate): the order of the additions, hence the last bits of the result, vary from run to run, while the reference's CPU
