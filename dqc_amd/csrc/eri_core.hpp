@@ -704,6 +704,18 @@ struct HostPairs {
     int cls_start[48], cls_count[48];  // class c(la,lb) = la(la+1)/2+lb  (grad.hip: la*8+lb... see there)
 };
 
+// A primitive pair enters every integral through c_a c_b K_ab / p times factors of order one (Boys functions <= 1, root
+// weights, |P - A|^l <= R^l): below PRIM_PAIR_EPS times (1 + R)^(la + lb) it cannot move any integral by more than ~1e-18,
+// six orders under the 1e-12 parity bar -- but the exp(-100) cut alone keeps, e.g., two 21-bohr^-2 s primitives on neighbouring
+// carbons (K = 6e-29).  On a 20-atom cc-pVDZ molecule 32 % of the primitive quartets go (naphthalene / cc-pVTZ: 26 %).
+constexpr double PRIM_PAIR_EPS = 1e-20;
+inline bool prim_pair_negligible(double ck, double ab2, int lsum) {
+    double f = std::fabs(ck);
+    const double r1 = 1.0 + std::sqrt(ab2);
+    for (int i = 0; i < lsum; i++) f *= r1;
+    return f < PRIM_PAIR_EPS;
+}
+
 // shell pairs (i >= j) of the shells [s0, s1); unit >= 0: instead the "pairs" (i, unit shell) used by the 2- and
 // 3-centre integrals (the unit shell has exponent 0, so P = A and K = 1)
 static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, int unit = -1) {
@@ -726,6 +738,7 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
                     const double arg = ea * eb / p * ab2;
                     if (arg > 100.0) continue;  // exp(-100) ~ 4e-44: numerically zero contribution
                     const double K = std::exp(-arg);
+                    if (prim_pair_negligible(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K / p, ab2, A.l + B.l)) continue;
                     pr.pp.push_back(p);
                     for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
                     pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K / p);  // c_a c_b K_ab / p

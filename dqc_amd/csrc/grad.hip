@@ -56,6 +56,7 @@ static void build_pairs_ordered(const Basis &b, HostPairs &hp, int f0, int f1, i
                     const double ea = b.exps[A.prim_off + ip], eb = b.exps[B.prim_off + jp], p = ea + eb;
                     const double arg = ea * eb / p * ab2;
                     if (arg > 100.0) continue;
+                    if (prim_pair_negligible(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * std::exp(-arg) / p, ab2, A.l + B.l)) continue;
                     pr.pp.push_back(p);
                     for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
                     pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * std::exp(-arg) / p);  // c_a c_b K_ab / p
