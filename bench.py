@@ -374,6 +374,7 @@ def main():
 
     if extras and world == 1:
         out_extra["small_batch"] = small_batch_leg(dev)
+        out_extra["direct_scf"] = direct_scf_leg(dev)
 
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components
@@ -469,6 +470,46 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def direct_scf_leg(dev):
+    """the path above the tile store's reach (nao > ~740: dqc_direct_*, Schwarz-screened, incremental builds), timed where both
+    forms exist: C4 (naphthalene / cc-pVTZ, nao 412) once from the stored tiles and once direct, same energy"""
+    import dqc_amd
+    from tests import molecules as M
+    out = {}
+    old = os.environ.get("DQC_AMD_ERI")
+    try:
+        for mode in ("tiles", "direct"):
+            os.environ["DQC_AMD_ERI"] = mode
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            mol = dqc_amd.Mol(M.naphthalene(), basis="cc-pvtz", grid="sg3", device=dev)
+            qc = dqc_amd.KS(mol, xc="gga_x_pbe+gga_c_pbe")
+            mol.get_hamiltonian()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            qc.run()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            h = mol.get_hamiltonian()
+            out[mode] = {"setup_s": t1 - t0, "scf_s": t2 - t1, "iterations": int(qc.niter), "energy_ha": float(qc.energy()),
+                         "converged": bool(qc.converged)}
+            if mode == "direct":
+                tot, lau, dmax = h._direct_stats
+                out[mode].update({"unique_shell_quartets": int(tot), "launched_share_last_build": lau / max(tot, 1),
+                                  "max_abs_density_difference_last_build": dmax, "tau": h._DIRECT_TAU})
+            del qc, mol, h
+            torch.cuda.empty_cache()
+    finally:
+        if old is None:
+            os.environ.pop("DQC_AMD_ERI", None)
+        else:
+            os.environ["DQC_AMD_ERI"] = old
+    out["energy_diff_ha"] = out["direct"]["energy_ha"] - out["tiles"]["energy_ha"]
+    out["note"] = ("C4 naphthalene RKS PBE / cc-pVTZ sg3 from the core guess: stored 8-fold-unique tiles (30 GB) vs direct SCF "
+                   "(no store: Schwarz-screened shell quartets re-evaluated per build, G[D] = G[D_prev] + G[D - D_prev])")
+    return out
 
 
 def small_batch_leg(dev):

@@ -252,6 +252,7 @@ class LockstepSCF:
         self._build(qmat, active, fock, dm, etot, streams)
 
         best = [[float("inf"), 0] for _ in range(M)]
+        restarts = [0] * M
         fmix = f0
         for it in range(int(opts["maxiter"])):
             a = torch.bmm(fock.reshape(M * S, n, n), dm.reshape(M * S, n, n))
@@ -282,7 +283,18 @@ class LockstepSCF:
                 if emax[m] < best[m][0] * 0.9:
                     best[m] = [float(emax[m]), it]
                 done = emax[m] < opts["f_tol"]
-                stalled = (not done) and emax[m] < 100 * opts["f_tol"] and it - best[m][1] >= 8
+                stagnant = (not done) and emax[m] < 100 * opts["f_tol"]
+                if stagnant and it - best[m][1] >= 5 and restarts[m] < 2:
+                    # five steps without progress close to the tolerance (seen once in ~200 molecule runs of the C5 batch:
+                    # 3e-9 at step 42): restart this molecule's Pulay subspace from the current iterate -- every slot holds
+                    # the present (F, [F, D]) pair, a rank-one Gram block whose minimum-norm solution is F itself -- before
+                    # calling it stalled
+                    restarts[m] += 1
+                    best[m][1] = it
+                    eh[m, :] = eh[m, slot].clone()
+                    fh[m, :] = fh[m, slot].clone()
+                    gram[m, :, :] = gram[m, slot, slot].clone()
+                stalled = stagnant and it - best[m][1] >= 8
                 if done or stalled:
                     qc.converged, qc.stalled = bool(done), bool(stalled)
                     self._finish(qc, m, fock, dm, etot)
