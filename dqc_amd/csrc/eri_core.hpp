@@ -63,17 +63,25 @@ struct DevPairs {
 
 __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
 
-// one image (i, j, k, l) of an integral into the packed tile store (common.hpp): block-canonical images only, and inside a
-// diagonal block pair only the a >= b element (the other image of the same integral writes nothing)
-DQC_DEV void tile_put(double *__restrict__ tiles, int i, int j, int k, int l, double v) {
-    const int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
-    if (I < J || K < L) return;
-    const int IJ = I * (I + 1) / 2 + J, KL = K * (K + 1) / 2 + L;
-    if (IJ < KL) return;
-    const int il = i & 7, jl = j & 7, kl = k & 7, ll = l & 7;
-    if ((I == J && il < jl) || (K == L && kl < ll)) return;
+// all images of the integral (ij|kl) = v into the packed tile store: the eight permutational images collapse to
+// ONE canonical location -- block pair (I >= J; inside a diagonal block pair the a >= b element), the same for the ket, bra
+// block pair >= ket block pair -- plus its transpose when both block pairs coincide ((ij|kl) and (kl|ij) live in the same tile).
+// Eight guarded stores per element (index arithmetic + the closed-form tile offset each time) were most of the instructions of
+// the shallow (cc-pVTZ-type, one primitive quartet) classes.
+DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l, double v) {
+    int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
+    int il = i & 7, jl = j & 7, kl = k & 7, ll = l & 7;
+    if (I < J || (I == J && il < jl)) { int t = I; I = J; J = t; t = il; il = jl; jl = t; }
+    if (K < L || (K == L && kl < ll)) { int t = K; K = L; L = t; t = kl; kl = ll; ll = t; }
+    int IJ = I * (I + 1) / 2 + J, KL = K * (K + 1) / 2 + L;
+    if (IJ < KL) {
+        int t = I; I = K; K = t; t = J; J = L; L = t; t = il; il = kl; kl = t; t = jl; jl = ll; ll = t; t = IJ; IJ = KL; KL = t;
+    }
     const int C = tile_dim(K == L);
-    tiles[tile_base(I, J, K, KL) + (long long)tile_pidx(I == J, il, jl) * C + tile_pidx(K == L, kl, ll)] = v;
+    const int r = tile_pidx(I == J, il, jl), c = tile_pidx(K == L, kl, ll);
+    double *tb = tiles + tile_base(I, J, K, KL);
+    tb[(long long)r * C + c] = v;
+    if (IJ == KL) tb[(long long)c * C + r] = v;
 }
 
 template <int LA, int LB, int LC, int LD>
@@ -650,14 +658,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
             } else
             if (MODE == ERI_OUT_TILES) {
-                tile_put(tiles, i, j, k, l, v);
-                tile_put(tiles, j, i, k, l, v);
-                tile_put(tiles, i, j, l, k, v);
-                tile_put(tiles, j, i, l, k, v);
-                tile_put(tiles, k, l, i, j, v);
-                tile_put(tiles, l, k, i, j, v);
-                tile_put(tiles, k, l, j, i, v);
-                tile_put(tiles, l, k, j, i, v);
+                tile_put_all(tiles, i, j, k, l, v);
             } else if (MODE == ERI_OUT_3C) {
                 const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                 tiles[(io * og.nao + jo) * og.naux + kx] = v;

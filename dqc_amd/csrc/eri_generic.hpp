@@ -440,14 +440,7 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
                         atomicAdd(&jk[ok4 + mb * sd + md], v * D[(size_t)i * n + k]);
                     }
                 } else if constexpr (MODE == ERI_OUT_TILES) {
-                    tile_put(tiles, i, j, k, l, v);
-                    tile_put(tiles, j, i, k, l, v);
-                    tile_put(tiles, i, j, l, k, v);
-                    tile_put(tiles, j, i, l, k, v);
-                    tile_put(tiles, k, l, i, j, v);
-                    tile_put(tiles, l, k, i, j, v);
-                    tile_put(tiles, k, l, j, i, v);
-                    tile_put(tiles, l, k, j, i, v);
+                    tile_put_all(tiles, i, j, k, l, v);
                 } else if constexpr (MODE == ERI_OUT_3C) {
                     const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                     tiles[(io * og.nao + jo) * og.naux + kx] = v;
