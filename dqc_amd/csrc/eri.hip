@@ -119,6 +119,7 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
         o2.pbin = sp->d_bins + (Cfg::TPQ == 1 ? cb : ck) * (SCREEN_NBIN + 1);  // bins of the PARTNER list the prefixes run over
         nblk = Cfg::TPQ == 1 ? (ntask + 3) / 4 : (ntask + Cfg::QPB - 1) / Cfg::QPB;
     }
+    nblk = (nblk + o2.nparts - 1) / o2.nparts;  // this rank's share of the blocks (dqc_direct_jk_part)
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_JK);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_JK, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
@@ -484,10 +485,15 @@ int dqc_direct_stats(void *ctx, long long *quartets_total, long long *quartets_l
 }
 
 int dqc_direct_jk(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, void *stream) {
+    return dqc_direct_jk_part(ctx, d_J, d_K, d_dm, tau, 0, 1, stream);
+}
+
+int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, int part, int nparts, void *stream) {
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     if (!ctx) { set_error("dqc_direct_jk: null context"); return DQC_EINVAL; }
     if (!(tau >= 0.0)) { set_error("dqc_direct_jk: tau must be >= 0"); return DQC_EINVAL; }
+    if (nparts < 1 || part < 0 || part >= nparts) { set_error("dqc_direct_jk_part: need 0 <= part < nparts"); return DQC_EINVAL; }
     DirectCtx &c = *static_cast<DirectCtx *>(ctx);
     const int nao = c.b.nao, nsh = (int)c.b.shells.size();
     hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, c.d_sym, c.d_a, d_K ? c.d_b : nullptr, d_dm, nao);
@@ -496,6 +502,8 @@ int dqc_direct_jk(void *ctx, double *d_J, double *d_K, const double *d_dm, doubl
     og.dmat = c.d_sym;
     og.jacc = c.d_a;
     og.kacc = d_K ? c.d_b : nullptr;
+    og.part = part;
+    og.nparts = nparts;
     ScreenPlan sp;
     const ScreenPlan *spp = nullptr;
     int rc;

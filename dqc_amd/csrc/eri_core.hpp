@@ -186,6 +186,8 @@ struct EriOut {
     const int *pbin = nullptr;
     double tau = 0.0;
     int nsh = 0;
+    // ---- one molecule sharded over GPUs (dqc_direct_jk_part): this launch is part `part` of `nparts` interleaved block sets
+    int part = 0, nparts = 1;
 };
 constexpr int SCREEN_NBIN = 8;
 // contraction-depth bin of a pair with npp surviving primitive pairs: 0 = deepest (> 64) ... 7 = one primitive pair (or none)
@@ -259,7 +261,9 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         __syncthreads();
     }
 
-    long long task = (long long)blockIdx.x * QPB + q;
+    // (one molecule over several GPUs: rank `part` of `nparts` takes the blocks part, part + nparts, ... of the launch)
+    const long long bidx = (long long)blockIdx.x * og.nparts + og.part;
+    long long task = bidx * QPB + q;
     bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         // screened map (direct SCF): the surviving tasks of every bra pair -- or, one lane per quartet, the surviving 64-bra-pair
         // chunks of every ket pair -- are a prefix of the Schwarz-sorted partner list; ntask counts tasks (waves)
         if constexpr (TPQ == 1) {
-            const long long wv = (long long)blockIdx.x * 4 + (tid >> 6);
+            const long long wv = bidx * 4 + (tid >> 6);
             const bool inr = wv < ntask;
             const long long w2 = inr ? wv : ntask - 1;
             const int e = screen_find(og.toff, nk * SCREEN_NBIN, w2);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         // with consecutive KET pairs per lane every primitive quartet was five uncoalesced loads served from L2) and the
         // ket primitive count is the same for all lanes; the pairs of a class are sorted by primitive count, so neighbouring
         // bra pairs are equally deep.  `same` classes keep ib >= ik (waves entirely below the diagonal retire at once).
-        const long long wv = (long long)blockIdx.x * 4 + (tid >> 6);
+        const long long wv = bidx * 4 + (tid >> 6);
         const int nchunk = (nb + 63) >> 6;
         int ikl = (int)(wv / nchunk);
         int ibl = (int)(wv - (long long)ikl * nchunk) * 64 + (tid & 63);

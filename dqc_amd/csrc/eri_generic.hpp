@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
         __syncthreads();
     }
 
-    long long task = (long long)blockIdx.x * QPB + q;
+    long long task = ((long long)blockIdx.x * og.nparts + og.part) * QPB + q;
     bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
@@ -535,7 +535,7 @@ static int launch_hl(double *tiles, const DevShells &ds, const DevPairs &db, con
     const long long ntask = ntask_screened >= 0 ? ntask_screened : (same == 2 ? (long long)nb : (same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk));
     if (ntask == 0) return 0;
     const int qpb = 256 / p.tpq;
-    const long long nblk = (ntask + qpb - 1) / qpb;
+    const long long nblk = ((ntask + qpb - 1) / qpb + og.nparts - 1) / og.nparts;
 #define DQC_HL(T)                                                                                                            \
     {                                                                                                                        \
         auto kern = eri_hl_kernel<T, MODE>;                                                                                   \

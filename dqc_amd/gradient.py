@@ -39,6 +39,9 @@ def nuclear_gradient(qc) -> torch.Tensor:
         # an all-zero field (the reference's property fixture attaches zeros so that autograd has a leaf) adds nothing
         raise NotImplementedError("nuclear gradients in a non-zero electric field are not implemented (derivative multipole "
                                   "integrals)")
+    if getattr(h, "sharded", False):
+        raise NotImplementedError("nuclear gradients of a Hamiltonian sharded over several GPUs (shard_over) are not implemented: "
+                                  "the grid terms need the whole grid")
     if h._vext is not None:
         raise NotImplementedError("nuclear gradients with an external potential are not implemented: the vext term "
                                   "(grid points and basis centres moving in vext) is missing from dqc_amd.gradient")

@@ -224,6 +224,10 @@ class HamiltonMI355(_Base):
         assert grid.coord_type == "cart"
         self.rgrid = grid.get_rgrid().to(self.device)
         self.dvolume = grid.get_dvolume().to(self.device).contiguous()
+        if self._pworld > 1:  # this rank's contiguous slab of the points (equal work per point: equal slabs)
+            g = self.rgrid.shape[0]
+            lo, hi = g * self._prank // self._pworld, g * (self._prank + 1) // self._pworld
+            self.rgrid, self.dvolume = self.rgrid[lo:hi].contiguous(), self.dvolume[lo:hi].contiguous()
         deriv = {1: 0, 2: 1, 4: 2}[self.xcfamily]
         self._ao = lib.eval_gto(self._tab, self.rgrid, deriv)  # (ngrid, ld), (4, ngrid, ld) or (5, ngrid, ld)
         self.is_grid_set = True
@@ -288,6 +292,49 @@ class HamiltonMI355(_Base):
         self._eri_mode = "direct" if on else "tiles"
         return self
 
+    # ------------------------------------------------------------------ one molecule over several GPUs
+    _pg, _prank, _pworld = None, 0, 1
+
+    def shard_over(self, group=None):
+        """before build() / setup_grid(), on EVERY rank of `group` (default: the world group): this one molecule is spread
+        over the ranks' GPUs -- rank r evaluates every world-th block of shell quartets of the screened direct J / K pass
+        (dqc_direct_jk_part) and the r-th contiguous slab of the grid (its AO matrix is 1 / world of the whole), and the
+        partial J, K, Vxc matrices and the E_xc quadrature are summed with ONE all_reduce each per Fock build (RCCL; n^2
+        doubles: latency-bound).  The SCF driver runs on every rank (SPMD); rank 0's convergence scalars are broadcast once
+        per iteration so that all ranks take the same decisions.  Tile store and density fitting are not sharded: the
+        Hamiltonian switches to direct SCF.  Nuclear gradients of a sharded Hamiltonian are not provided."""
+        import torch.distributed as dist
+        if self.is_built or self.is_grid_set:
+            raise RuntimeError("shard_over must be called before build() and setup_grid()")
+        if self._df is not None or self._vext is not None:
+            raise RuntimeError("a density-fitted Hamiltonian / one with an external potential on the grid cannot be sharded")
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("shard_over needs an initialised torch.distributed process group")
+        self._pg = group
+        self._prank, self._pworld = dist.get_rank(group), dist.get_world_size(group)
+        self._eri_mode = "direct"
+        return self
+
+    @property
+    def sharded(self):
+        return self._pworld > 1
+
+    def _allsum(self, t):
+        """sum of the ranks' partial results, in place (no-op for an unsharded Hamiltonian)"""
+        if self._pworld > 1 and t is not None:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._pg)
+        return t
+
+    def sync_scalars(self, t):
+        """rank 0's copy of a small device tensor on every rank (the SCF driver's per-iteration host read): all ranks decide alike"""
+        if self._pworld > 1:
+            import torch.distributed as dist
+            src = dist.get_global_rank(self._pg, 0) if self._pg is not None else 0
+            t = t.contiguous()
+            dist.broadcast(t, src=src, group=self._pg)
+        return t
+
     # direct SCF: shell quartets bounded by this much are skipped (DQC_AMD_DIRECT_TAU; 0 = none), and a build adds
     # G[D - D_prev] to the previous one for at most this many calls in a row before it is redone from D itself
     _DIRECT_TAU = float(os.environ.get("DQC_AMD_DIRECT_TAU", "1e-13"))
@@ -299,16 +346,19 @@ class HamiltonMI355(_Base):
         density-weighted screening sees max |D - D_prev|, which falls as the SCF converges; every _DIRECT_RESET-th build of a
         slot (or a change of shape / of the K request, or a difference that is no smaller than the density) starts again from D"""
         tau = self._DIRECT_TAU
+        part = (self._prank, self._pworld)
         st = self._dinc.get(slot)
         if tau > 0 and st is not None and st["n"] < self._DIRECT_RESET and st["k"] == with_k and st["d"].shape == dao.shape:
             dd = dao - st["d"]
-            J, K = self._dctx.jk(dd, with_k, tau)
+            J, K = self._dctx.jk(dd, with_k, tau, part)
+            self._allsum(J), self._allsum(K)
             J += st["J"]
             if with_k:
                 K += st["K"]
             n = st["n"] + 1
         else:
-            J, K = self._dctx.jk(dao, with_k, tau)
+            J, K = self._dctx.jk(dao, with_k, tau, part)
+            self._allsum(J), self._allsum(K)
             n = 0
         self._direct_stats = self._dctx.stats()
         if tau > 0:
@@ -507,7 +557,7 @@ class HamiltonMI355(_Base):
         assert self.xc is not None, "Please call .setup_grid with the xc object"
         if isinstance(dm, SpinParam):  # hcgto.py:320-328 with SpinParam densinfo
             densinfo = SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
-            return torch.sum(self.dvolume * self.xc.get_edensityxc(densinfo), dim=-1)
+            return self._allsum(torch.sum(self.dvolume * self.xc.get_edensityxc(densinfo), dim=-1))
 
         e = self._memo_energy(dm, 3)
         if e is not None:
@@ -515,7 +565,7 @@ class HamiltonMI355(_Base):
 
         def one(d):
             edens = self.xc.get_edensityxc(self._dm2densinfo(d))
-            return torch.sum(self.dvolume * edens, dim=-1)
+            return self._allsum(torch.sum(self.dvolume * edens, dim=-1))
 
         return self._batched(one, dm)
 
@@ -592,7 +642,7 @@ class HamiltonMI355(_Base):
             lk = ((2.0 * lapl if lapl is not None else 0.0) + 0.5 * kin).contiguous()
             for d in (1, 2, 3):
                 vm = vm + lib.grid_vxc_pair(self._ao[d], self._ao[d], self._nao_ao, self.dvolume, lk)
-        return vm
+        return self._allsum(vm)
 
     def get_elrep_plus_vxc(self, dm):
         """J[D] + Vxc[D] of ONE restricted density matrix as a plain tensor in the orthogonalised basis -- the sum
@@ -612,6 +662,7 @@ class HamiltonMI355(_Base):
         densinfo = self._dm2densinfo(dm)
         if hasattr(self.xc, "get_vxc_and_exc"):  # potentials and the E_xc quadrature from one pass over the grid
             potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
+            self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
         else:
             potinfo, exc = self.xc.get_vxc(densinfo), None
         # the two-electron energies of THIS density fall out of the build (tr D J = tr D_ao J_ao): remembered under the

@@ -57,6 +57,7 @@ def load():
     lib.dqc_jk_direct.argtypes = [c_dp, c_dp, c_dp] + tab + [c_vp]
     lib.dqc_direct_create.argtypes = [ctypes.POINTER(c_vp)] + tab + [c_vp]
     lib.dqc_direct_jk.argtypes = [c_vp, c_dp, c_dp, c_dp, ctypes.c_double, c_vp]
+    lib.dqc_direct_jk_part.argtypes = [c_vp, c_dp, c_dp, c_dp, ctypes.c_double, c_int, c_int, c_vp]
     lib.dqc_direct_stats.argtypes = [c_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), dp]
     lib.dqc_direct_npairs.argtypes = [c_vp]
     lib.dqc_direct_bounds.argtypes = [c_vp, dp, ip]
@@ -369,11 +370,14 @@ class DirectContext:
         with _on(self.device) as st_:
             _check(load().dqc_direct_create(ctypes.byref(self._h), *tab.args(), st_), "dqc_direct_create")
 
-    def jk(self, dm_ao, with_k=True, tau=0.0):
+    def jk(self, dm_ao, with_k=True, tau=0.0, part=(0, 1)):
+        """J, K (K = None if not with_k) of one AO density; part = (r, n): only every n-th block of shell quartets, starting
+        with the r-th -- the partial sums of rank r when one molecule is spread over n GPUs (the caller all_reduces)"""
         J = torch.empty((self.nao, self.nao), dtype=torch.float64, device=dm_ao.device)
         K = torch.empty_like(J) if with_k else None
         with _on(dm_ao.device) as st_:
-            _check(load().dqc_direct_jk(self._h, _ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), float(tau), st_), "dqc_direct_jk")
+            _check(load().dqc_direct_jk_part(self._h, _ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), float(tau), int(part[0]), int(part[1]),
+                                             st_), "dqc_direct_jk_part")
         return J, K
 
     def stats(self):

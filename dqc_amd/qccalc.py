@@ -153,10 +153,13 @@ class SCF_QCCalc:
         """the SCF loop, driven synchronously: every host read of the generator below is a blocking device -> host copy.
         dqc_amd.batch.run_concurrent drives many of these generators at once, one stream per molecule."""
         gen = self._run_gen(dm0, fwd_options)
+        # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
+        # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives
+        sync = getattr(self._engine.hamilton, "sync_scalars", lambda t: t)
         try:
             req = next(gen)
             while True:
-                req = gen.send(req.cpu().numpy())
+                req = gen.send(sync(req).cpu().numpy())
         except StopIteration:
             pass
         return self

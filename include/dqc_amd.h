@@ -277,6 +277,10 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
  *   dqc_direct_bounds  host copies of the bounds and the shell pairs they belong to (tests). */
 int dqc_direct_create(void **ctx, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);
 int dqc_direct_jk(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, void *stream);
+/* one molecule over several GPUs ("intra-molecule sharding"): rank `part` of `nparts` evaluates every nparts-th
+ * block of shell quartets of the (identically screened) pass and gets the PARTIAL sums d_J, d_K; the caller adds the parts up
+ * (all_reduce over RCCL: n^2 doubles per matrix -- latency-bound, 5 MB at nao 824).  Every rank holds its own context. */
+int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, double tau, int part, int nparts, void *stream);
 int dqc_direct_stats(void *ctx, long long *quartets_total, long long *quartets_launched, double *dmax);
 int dqc_direct_npairs(void *ctx);
 int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells);
