@@ -28,8 +28,9 @@
 //     24.7 ms, naphthalene / cc-pVTZ 157 -> 153 ms; a generic (flat) pointer to the copy made it 42.7 ms, the 14 KB table of
 //     the three-root classes costs more occupancy than it saves.  PMC (profiles/r02u_*): the kernels are VALU-dependency
 //     bound (48 % of the wave cycles in issue stalls: Clenshaw recurrences, fp64 divisions), ~35 % VALU utilisation.
-//   No integral screening (the reference passes prescreen = NULL); primitive pairs whose Gaussian
-//   product prefactor underflows (exp(-100)) are dropped when the pair tables are built.
+//   The stored fill screens no shell quartet (the reference passes prescreen = NULL); primitive pairs whose prefactor cannot
+//   reach 1e-20 are dropped when the pair tables are built (eri_core.hpp: prim_pair_negligible).  The DIRECT path (nothing
+//   stored, every build re-evaluates) does screen: Cauchy-Schwarz bounds, density-weighted, see the dqc_direct_* context below.
 #include <algorithm>
 #include <memory>
 

@@ -147,11 +147,11 @@ DQC_DEV D5 pw92_pol_eps(D5 rho, D5 zeta, const double *a3) {
     return g[0] + z4 * fz * (g[1] - g[0] + g[2] / c5(fz20)) - fz * g[2] / c5(fz20);
 }
 
-DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s) {
-    const double kappa = 0.8040, mu = 0.2195149727645171, c2 = 4.0 * 9.5707800006273038;
+DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s, double kappa = kPbeKappa, double mu = kPbeMu, bool rpbe = false) {
+    const double c2 = 4.0 * 9.5707800006273038;
     D5 r43 = r * cbrt5(r);
     D5 s2 = s / (c2 * (r43 * r43));
-    D5 F = (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2);
+    D5 F = rpbe ? (1.0 + kappa) - kappa * exp5(c5(0.0) - (mu / kappa) * s2) : (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2);
     return (-0.75 * 0.98474502184269641) * (r43 * F);
 }
 
@@ -186,15 +186,23 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                     const double a3[3] = {0.0310907, 0.01554535, 0.0168869};
                     f = rho * pw92_pol_eps(rho, zeta, a3);
                 } break;
-                case DQC_XC_GGA_X_PBE:
-                    f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu) + pbe_x_unpol5(2.0 * d, 4.0 * sdd));
-                    break;
+                case DQC_XC_LDA_C_PW_MOD: {
+                    const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
+                    f = rho * pw92_pol_eps(rho, zeta, a3);
+                } break;
+                case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_X_PBE_R: case DQC_XC_GGA_X_PBE_SOL: case DQC_XC_GGA_X_RPBE: {
+                    // exchange: exact spin scaling of the unpolarised form (kappa, mu by member of the family)
+                    const int id_ = terms.id[t];
+                    const double ka = id_ == DQC_XC_GGA_X_PBE_R ? 1.245 : kPbeKappa, mu_ = id_ == DQC_XC_GGA_X_PBE_SOL ? 10.0 / 81.0 : kPbeMu;
+                    const bool rp = id_ == DQC_XC_GGA_X_RPBE;
+                    f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu, ka, mu_, rp) + pbe_x_unpol5(2.0 * d, 4.0 * sdd, ka, mu_, rp));
+                } break;
                 case DQC_XC_LDA_C_VWN: f = rho * vwn_pol_eps(rho, zeta); break;
                 case DQC_XC_GGA_X_B88: f = b88_spin5(u, suu) + b88_spin5(d, sdd); break;
                 case DQC_XC_GGA_C_LYP: f = lyp_pol5(u, d, suu, sud, sdd); break;
                 default: {
                     const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
-                    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;
+                    const double beta = terms.id[t] == DQC_XC_GGA_C_PBE_SOL ? 0.046 : kPbeBeta, gamma = 0.031090690869654895;
                     D5 eps = pw92_pol_eps(rho, zeta, a3);
                     D5 phi = 0.5 * (p5(1.0 + zeta, 2.0 / 3.0) + p5(1.0 - zeta, 2.0 / 3.0));
                     D5 phi3 = phi * phi * phi;

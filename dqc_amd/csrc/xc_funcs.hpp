@@ -60,20 +60,24 @@ DQC_DEV Dual pw92_eps(Dual rho, double a) {
 }
 
 DQC_DEV Dual f_lda_c_pw(Dual rho) { return rho * pw92_eps(rho, 0.0310907); }
+DQC_DEV Dual f_lda_c_pw_mod(Dual rho) { return rho * pw92_eps(rho, 0.031090690869654895); }
 
-DQC_DEV Dual f_gga_x_pbe(Dual rho, Dual sigma) {
-    const double kappa = 0.8040, mu = 0.2195149727645171;
+// the PBE exchange family: enhancement factor F(s^2) = 1 + kappa - kappa / (1 + mu s^2 / kappa) with (kappa, mu) =
+// (0.804, 0.21951) PBE, (1.245, 0.21951) revPBE, (0.804, 10/81) PBEsol; RPBE: F = 1 + kappa (1 - exp(-mu s^2 / kappa))
+constexpr double kPbeKappa = 0.8040, kPbeMu = 0.2195149727645171, kPbeBeta = 0.06672455060314922;
+DQC_DEV Dual f_gga_x_pbe(Dual rho, Dual sigma, double kappa = kPbeKappa, double mu = kPbeMu, bool rpbe = false) {
     const double c2 = 4.0 * 9.5707800006273038;  // 4 (3 pi^2)^(2/3)
     Dual r13 = dcbrt(rho);
     Dual r43 = rho * r13;
     Dual s2 = sigma / (c2 * (r43 * r43));
-    Dual F = (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2);
+    Dual F = rpbe ? (1.0 + kappa) - kappa * dexp(mk(0.0) - (mu / kappa) * s2) : (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2);
     const double c = -0.75 * 0.98474502184269641;
     return c * (r43 * F);
 }
 
-DQC_DEV Dual f_gga_c_pbe(Dual rho, Dual sigma) {
-    const double beta = 0.06672455060314922, gamma = 0.031090690869654895;  // (1 - ln 2)/pi^2
+// PBE correlation; beta = 0.066725 (PBE) or 0.046 (PBEsol)
+DQC_DEV Dual f_gga_c_pbe(Dual rho, Dual sigma, double beta = kPbeBeta) {
+    const double gamma = 0.031090690869654895;  // (1 - ln 2)/pi^2
     Dual eps = pw92_eps(rho, gamma);
     Dual kf = dcbrt((3.0 * kPi * kPi) * rho);
     Dual ks2 = (4.0 / kPi) * kf;
@@ -127,10 +131,15 @@ DQC_DEV Dual f_gga_c_lyp(Dual rho, Dual sigma) {
     return mk(0.0) - a * (rho / den) - (a * b) * (omega * bracket);
 }
 
-DQC_DEV bool xc_id_is_lda(int id) { return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_VWN; }
-DQC_DEV bool xc_id_is_gga(int id) { return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP; }
-inline bool xc_host_is_lda(int id) { return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_VWN; }
-inline bool xc_host_is_gga(int id) { return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP; }
+__host__ __device__ inline bool xc_id_is_lda(int id) {
+    return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_PW_MOD || id == DQC_XC_LDA_C_VWN;
+}
+__host__ __device__ inline bool xc_id_is_gga(int id) {
+    return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP || id == DQC_XC_GGA_X_PBE_R ||
+           id == DQC_XC_GGA_X_PBE_SOL || id == DQC_XC_GGA_X_RPBE || id == DQC_XC_GGA_C_PBE_SOL;
+}
+inline bool xc_host_is_lda(int id) { return xc_id_is_lda(id); }
+inline bool xc_host_is_gga(int id) { return xc_id_is_gga(id); }
 
 // one LDA / GGA functional of the kernel set at (rho, sigma) with its first derivatives
 DQC_DEV Dual f_lda_gga(int id, Dual dr, Dual ds) {
@@ -138,7 +147,12 @@ DQC_DEV Dual f_lda_gga(int id, Dual dr, Dual ds) {
     case DQC_XC_LDA_X: return f_lda_x(dr);
     case DQC_XC_LDA_C_PW: return f_lda_c_pw(dr);
     case DQC_XC_LDA_C_VWN: return f_lda_c_vwn(dr);
+    case DQC_XC_LDA_C_PW_MOD: return f_lda_c_pw_mod(dr);
     case DQC_XC_GGA_X_PBE: return f_gga_x_pbe(dr, ds);
+    case DQC_XC_GGA_X_PBE_R: return f_gga_x_pbe(dr, ds, 1.245);
+    case DQC_XC_GGA_X_PBE_SOL: return f_gga_x_pbe(dr, ds, kPbeKappa, 10.0 / 81.0);
+    case DQC_XC_GGA_X_RPBE: return f_gga_x_pbe(dr, ds, kPbeKappa, kPbeMu, true);
+    case DQC_XC_GGA_C_PBE_SOL: return f_gga_c_pbe(dr, ds, 0.046);
     case DQC_XC_GGA_X_B88: return f_gga_x_b88(dr, ds);
     case DQC_XC_GGA_C_LYP: return f_gga_c_lyp(dr, ds);
     default: return f_gga_c_pbe(dr, ds);

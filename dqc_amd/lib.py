@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBPATH = os.environ.get("DQC_AMD_LIB") or os.path.join(_HERE, "libdqc_amd.so")  # override: perf-bisection variants
 _lib = None
 
-XC_IDS = {"lda_x": 1, "lda_c_vwn": 7, "lda_c_pw": 12, "gga_x_pbe": 101, "gga_x_b88": 106, "gga_c_pbe": 130, "gga_c_lyp": 131,
+XC_IDS = {"lda_x": 1, "lda_c_vwn": 7, "lda_c_pw": 12, "lda_c_pw_mod": 13, "gga_x_pbe": 101, "gga_x_pbe_r": 102, "gga_x_b88": 106,
+          "gga_x_pbe_sol": 116, "gga_x_rpbe": 117, "gga_c_pbe": 130, "gga_c_lyp": 131, "gga_c_pbe_sol": 133,
           "mgga_x_scan": 263, "mgga_c_scan": 267}
 
 

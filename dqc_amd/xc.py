@@ -11,8 +11,8 @@ import torch
 from . import lib
 from .utils.datastruct import ValGrad, SpinParam
 
-_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "lda_c_vwn": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "gga_x_b88": 2, "gga_c_lyp": 2,
-           "mgga_x_scan": 4, "mgga_c_scan": 4}
+_FAMILY = {"lda_x": 1, "lda_c_pw": 1, "lda_c_pw_mod": 1, "lda_c_vwn": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "gga_x_b88": 2, "gga_c_lyp": 2,
+           "gga_x_pbe_r": 2, "gga_x_pbe_sol": 2, "gga_x_rpbe": 2, "gga_c_pbe_sol": 2, "mgga_x_scan": 4, "mgga_c_scan": 4}
 
 
 class BaseXC:

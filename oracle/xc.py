@@ -77,25 +77,34 @@ def lda_c_pw(rho, sigma=None, a=_PW_A):
     return np.where(mask, e, 0.0), np.where(mask, v, 0.0), z
 
 
-def gga_x_pbe(rho, sigma):
+def gga_x_pbe(rho, sigma, kappa=_PBE_KAPPA, mu=_PBE_MU, rpbe=False):
+    """the PBE exchange family (libxc gga_x_pbe.c parameter sets): PBE (kappa 0.804, mu 0.21951), revPBE `gga_x_pbe_r`
+    (kappa = 1.245; Zhang, Yang, PRL 80, 890), PBEsol `gga_x_pbe_sol` (mu = 10/81; Perdew et al., PRL 100, 136406) and RPBE
+    `gga_x_rpbe` (F = 1 + kappa (1 - exp(-mu s^2 / kappa)); Hammer, Hansen, Norskov, PRB 59, 7413)"""
     mask, r = _safe(rho)
     A = -0.75 * (3.0 / np.pi) ** (1.0 / 3)
     c2 = 4.0 * (3.0 * np.pi ** 2) ** (2.0 / 3)
     r13 = r ** (1.0 / 3)
     r43 = r * r13
     s2 = sigma / (c2 * r43 * r43)
-    den = 1.0 + _PBE_MU * s2 / _PBE_KAPPA
-    F = 1.0 + _PBE_KAPPA - _PBE_KAPPA / den
-    Fp = _PBE_MU / (den * den)  # dF/d(s2)
+    if rpbe:
+        ex_ = np.exp(-mu * s2 / kappa)
+        F = 1.0 + kappa * (1.0 - ex_)
+        Fp = mu * ex_
+    else:
+        den = 1.0 + mu * s2 / kappa
+        F = 1.0 + kappa - kappa / den
+        Fp = mu / (den * den)  # dF/d(s2)
     e = A * r43 * F
     vrho = (4.0 / 3.0) * A * r13 * F + A * r43 * Fp * (-8.0 / 3.0) * s2 / r
     vsigma = A * r43 * Fp / (c2 * r43 * r43)
     return np.where(mask, e, 0.0), np.where(mask, vrho, 0.0), np.where(mask, vsigma, 0.0)
 
 
-def gga_c_pbe(rho, sigma):
+def gga_c_pbe(rho, sigma, beta=_PBE_BETA):
+    """PBE correlation; beta = 0.046: PBEsol `gga_c_pbe_sol` (Perdew et al., PRL 100, 136406)"""
     mask, r = _safe(rho)
-    g, b = _PBE_GAMMA, _PBE_BETA
+    g, b = _PBE_GAMMA, beta
     rs = (3.0 / (4.0 * np.pi * r)) ** (1.0 / 3)
     eps, deps = _pw92_eps(rs, _PW_A_MOD)
     deps_drho = deps * (-rs / (3.0 * r))
@@ -310,7 +319,7 @@ def lda_c_pw_pol(ru, rd, suu=None, sud=None, sdd=None):
     return _finish(rho * _pw92_pol_eps(rho, zeta, _PW_POL["a"]), mask)
 
 
-def gga_x_pbe_pol(ru, rd, suu, sud, sdd):
+def gga_x_pbe_pol(ru, rd, suu, sud, sdd, kappa=_PBE_KAPPA, mu=_PBE_MU, rpbe=False):
     mask, ru_, rd_ = _masked(ru, rd)
     u, d, suu_, sud_, sdd_ = _pol_inputs(ru_, rd_, suu, sud, sdd)
     A = -0.75 * (3.0 / np.pi) ** (1.0 / 3)
@@ -319,18 +328,21 @@ def gga_x_pbe_pol(ru, rd, suu, sud, sdd):
     def ex(r, s):  # unpolarised E_x[r, s]
         r43 = r.pow(4.0 / 3)
         s2 = s / (c2 * r43 * r43)
-        F = (1.0 + _PBE_KAPPA) - _PBE_KAPPA / (1.0 + (_PBE_MU / _PBE_KAPPA) * s2)
+        if rpbe:
+            F = (1.0 + kappa) - kappa * (((-mu / kappa) * s2).expm1() + 1.0)
+        else:
+            F = (1.0 + kappa) - kappa / (1.0 + (mu / kappa) * s2)
         return A * r43 * F
 
     e = 0.5 * (ex(2.0 * u, 4.0 * suu_) + ex(2.0 * d, 4.0 * sdd_))
     return _finish(e, mask)
 
 
-def gga_c_pbe_pol(ru, rd, suu, sud, sdd):
+def gga_c_pbe_pol(ru, rd, suu, sud, sdd, beta=_PBE_BETA):
     mask, ru_, rd_ = _masked(ru, rd)
     u, d, suu_, sud_, sdd_ = _pol_inputs(ru_, rd_, suu, sud, sdd)
     rho, zeta = _safe_zeta(u, d)
-    g_, b_ = _PBE_GAMMA, _PBE_BETA
+    g_, b_ = _PBE_GAMMA, beta
     eps = _pw92_pol_eps(rho, zeta, _PW_A_MOD3)
     phi = 0.5 * ((1.0 + zeta).pow(2.0 / 3) + (1.0 - zeta).pow(2.0 / 3))
     phi3 = phi * phi * phi
@@ -667,3 +679,25 @@ def gga_x_b88_pol(ru, rd, suu, sud, sdd):
 
 _FUNCS.update({"lda_c_vwn": (1, lda_c_vwn), "gga_x_b88": (2, gga_x_b88), "gga_c_lyp": (2, gga_c_lyp)})
 _FUNCS_POL.update({"lda_c_vwn": lda_c_vwn_pol, "gga_x_b88": gga_x_b88_pol, "gga_c_lyp": gga_c_lyp_pol})
+
+
+# ---- parameter variants of the PBE family and PW92 with full-precision constants (libxc ids 102, 116, 117, 133, 13)
+def _variant(f, **kw):
+    import functools
+    return functools.partial(f, **kw)
+
+
+def lda_c_pw_mod_pol(ru, rd, suu=None, sud=None, sdd=None):
+    mask, ru_, rd_ = _masked(ru, rd)
+    z0 = np.zeros_like(ru_)
+    u, d, _, _, _ = _pol_inputs(ru_, rd_, z0, z0, z0)
+    rho, zeta = _safe_zeta(u, d)
+    return _finish(rho * _pw92_pol_eps(rho, zeta, _PW_A_MOD3), mask)
+
+
+_FUNCS.update({"lda_c_pw_mod": (1, _variant(lda_c_pw, a=_PW_A_MOD)),
+               "gga_x_pbe_r": (2, _variant(gga_x_pbe, kappa=1.245)), "gga_x_pbe_sol": (2, _variant(gga_x_pbe, mu=10.0 / 81.0)),
+               "gga_x_rpbe": (2, _variant(gga_x_pbe, rpbe=True)), "gga_c_pbe_sol": (2, _variant(gga_c_pbe, beta=0.046))})
+_FUNCS_POL.update({"lda_c_pw_mod": lda_c_pw_mod_pol,
+                   "gga_x_pbe_r": _variant(gga_x_pbe_pol, kappa=1.245), "gga_x_pbe_sol": _variant(gga_x_pbe_pol, mu=10.0 / 81.0),
+                   "gga_x_rpbe": _variant(gga_x_pbe_pol, rpbe=True), "gga_c_pbe_sol": _variant(gga_c_pbe_pol, beta=0.046)})

@@ -108,7 +108,11 @@ def test_xc_closed_forms():
     assert np.allclose(oxc.gga_x_pbe(rho, sig)[0], -0.75 * (3 / np.pi) ** (1 / 3) * rho ** (4 / 3) * fx, rtol=2e-6)
 
 
-@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp"])
+_XC_NAMES = ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp",
+             "lda_c_pw_mod", "gga_x_pbe_r", "gga_x_pbe_sol", "gga_x_rpbe", "gga_c_pbe_sol"]
+
+
+@pytest.mark.parametrize("name", _XC_NAMES)
 def test_xc_derivatives_finite_difference(name):
     rng = np.random.default_rng(1)
     rho = rng.uniform(0.05, 1.5, 50)
@@ -150,6 +154,40 @@ def test_vwn_b88_lyp_external_pins():
     sig = (2 * zeta * rho2) ** 2
     assert abs(quad(oxc.gga_c_lyp(rho2, sig)[0]) + 0.0437) < 1e-3
     assert -1.06 < quad(oxc.gga_x_b88(rho2, sig)[0]) < -1.03  # exact exchange of this density: -5 zeta / 8 = -1.0547
+
+
+def test_pbe_family_variants_published_forms():
+    """gga_x_pbe_r / gga_x_pbe_sol / gga_x_rpbe / gga_c_pbe_sol / lda_c_pw_mod (getxc.py:12-36 takes any libxc name): the
+    enhancement factors written out from the papers (revPBE kappa = 1.245; PBEsol mu = 10/81, beta = 0.046; RPBE
+    F = 1 + kappa (1 - exp(-mu s^2 / kappa))), the limits every member shares (s -> 0: LDA exchange with the gradient
+    coefficient mu; s -> infinity: the bound 1 + kappa), PBE and RPBE agreeing to second order in s^2, and PBEsol correlation
+    = PBE correlation with beta rescaled; unpinned against an executed libxc like gga_c_pbe"""
+    rng = np.random.default_rng(5)
+    rho, sig = rng.uniform(0.05, 1.5, 40), rng.uniform(0.0, 2.0, 40)
+    kf = (3 * np.pi ** 2 * rho) ** (1 / 3)
+    s2 = sig / (2 * rho * kf) ** 2
+    ex0 = -0.75 * (3 / np.pi) ** (1 / 3) * rho ** (4 / 3)
+    mu, ka = 0.2195149727645171, 0.804
+    forms = {"gga_x_pbe": 1 + ka - ka / (1 + mu * s2 / ka), "gga_x_pbe_r": 1 + 1.245 - 1.245 / (1 + mu * s2 / 1.245),
+             "gga_x_pbe_sol": 1 + ka - ka / (1 + (10 / 81) * s2 / ka), "gga_x_rpbe": 1 + ka * (1 - np.exp(-mu * s2 / ka))}
+    for name, F in forms.items():
+        assert np.allclose(oxc._FUNCS[name][1](rho, sig)[0], ex0 * F, rtol=1e-13), name
+        e_small = oxc._FUNCS[name][1](rho, 1e-10 * rho ** (8 / 3))[0]
+        assert np.allclose(e_small, oxc.lda_x(rho)[0], rtol=1e-9), name
+        e_big = oxc._FUNCS[name][1](rho, 1e12 * rho ** (8 / 3))[0] / ex0
+        assert np.allclose(e_big, 1 + (1.245 if name == "gga_x_pbe_r" else ka), rtol=1e-6), name
+    small = 1e-3 * (2 * rho * kf) ** 2  # s^2 = 1e-3: F_PBE - F_RPBE = O(s^4 mu^2 / (2 kappa)) ... third order in s^2 apart
+    d = (oxc.gga_x_pbe(rho, small)[0] - oxc._FUNCS["gga_x_rpbe"][1](rho, small)[0]) / ex0
+    assert np.abs(d - (-(mu * 1e-3) ** 2 / (2 * ka))).max() < 1e-10
+    # correlation: H depends on beta only through beta / gamma and A; beta -> 0 kills the gradient correction
+    e_pw = oxc._FUNCS["lda_c_pw_mod"][1](rho)[0]
+    assert np.allclose(oxc.gga_c_pbe(rho, 0 * sig)[0], e_pw, rtol=1e-13) and np.allclose(oxc.gga_c_pbe(rho, sig, beta=1e-14)[0], e_pw, rtol=1e-10)
+    hs, hp = oxc._FUNCS["gga_c_pbe_sol"][1](rho, sig)[0] - e_pw, oxc.gga_c_pbe(rho, sig)[0] - e_pw
+    assert (hs > 0).all() and (hs < hp).all()  # a smaller beta gives a smaller (positive) gradient correction
+    t2 = 1e-8
+    sg = t2 * 4 * (4 * kf / np.pi) * rho ** 2
+    assert np.allclose((oxc._FUNCS["gga_c_pbe_sol"][1](rho, sg)[0] - e_pw) / (rho * t2), 0.046, rtol=1e-5)  # H -> beta t^2
+    assert np.abs(oxc.lda_c_pw(rho)[0] - e_pw).max() < 2e-7 * np.abs(e_pw).max()  # the two constant sets of PW92
 
 
 def test_overlap_normalisation_all_l():
@@ -269,7 +307,7 @@ def test_cart2sph_tables_agree(golden_dir):
 # ------------------------------------------------------------------------------------------------
 # spin-polarised path: functionals, UHF / UKS engines
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp"])
+@pytest.mark.parametrize("name", _XC_NAMES)
 def test_polarised_xc_derivatives_and_unpolarised_limit(name):
     rng = np.random.default_rng(0)
     n = 40
