@@ -155,7 +155,7 @@ class SCF_QCCalc:
         gen = self._run_gen(dm0, fwd_options)
         # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
         # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives
-        sync = getattr(self._engine.hamilton, "sync_scalars", lambda t: t)
+        sync = getattr(getattr(self._engine, "hamilton", None), "sync_scalars", lambda t: t)
         try:
             req = next(gen)
             while True:
