@@ -136,19 +136,28 @@ def main():
     from dqc_amd.batch import molecule_bytes, reserve_device_memory
     # the batch's device memory in one request (the driver clears fresh VRAM at ~35 GB/s: its own line of the breakdown)
     brk["device_memory_reserve"] = reserve_device_memory(len(mine) * molecule_bytes(208, 353400) + (4 << 30), dev)
+    from dqc_amd.batch import prepare_orthogonalisers
+    t = time.perf_counter()
+    mols = []
     for i in mine:
         zs, pos = M.c5_molecule(i)
-        t = time.perf_counter()
         mol = dqc_amd.Mol((zs, pos), basis="cc-pvdz", grid="sg3", device=dev)
         if args.df:
             mol.densityfit(method="coulomb", auxbasis=args.df)
-        t = lap("tables_overlap", t)
+        mol.get_hamiltonian()  # tables on the device, overlap matrix enqueued
+        mols.append(mol)
+    # the orthogonalisers of the whole batch from one batched eigh (one rocSOLVER call per molecule made the host wait 11 ms each)
+    prepare_orthogonalisers([m.get_hamiltonian() for m in mols])
+    t = lap("tables_overlap_orthogonalisers", t)
+    for mol in mols:
         qc = dqc_amd.KS(mol, xc=XC)
         qcs.append(qc)
         engines.append(qc._engine)
-        # (ERI tile fill on a side stream underneath the orthogonaliser, T, V, the Becke grid and the AO evaluation: stage
-        # clocks inside would serialise what the build overlaps -- tools/gpu_setup_breakdown.py has them one by one)
-        t = lap("integrals_grid_ao", t)
+    # (per molecule: ERI tile fill on a side stream underneath T, V, the Becke grid and the AO evaluation; no device
+    # synchronisation between molecules, so the next molecule's host work overlaps this one's fill -- stage clocks inside would
+    # serialise what the build overlaps: tools/gpu_setup_breakdown.py has them one by one)
+    t = lap("integrals_grid_ao", t)
+    del mols
     # density of the core-Hamiltonian guess ("1e", reference scf_qccalc.py:88-91) after one SCF update, for every molecule:
     # the occupied spaces come from the batched purification of the lockstep driver (no eigensolver)
     t = time.perf_counter()
