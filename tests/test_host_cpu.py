@@ -389,3 +389,31 @@ def test_xc_combinators_keep_every_valgrad_field_and_spin():
     s = ValGrad(value=d.value) + d
     assert torch.allclose(s.value, 2 * d.value) and s.grad is d.grad and s.kin is d.kin
     assert (3.0 * ValGrad(value=d.value)).grad is None
+
+
+def test_prepare_orthogonalisers_batched_eigh_on_cpu():
+    """batch.prepare_orthogonalisers on stand-in Hamiltonians (CPU tensors): one batched eigh per matrix size, X^T S X = 1,
+    eigenvalues below 1e-6 dropped per matrix (orbconverter.py:67-116), objects that already hold an X or are not
+    orthogonalised are left alone"""
+    from types import SimpleNamespace
+    from dqc_amd.batch import prepare_orthogonalisers
+    g = torch.Generator().manual_seed(0)
+
+    def ham(n, dup=False, **kw):
+        a = torch.randn((n, n), dtype=torch.float64, generator=g)
+        s = a @ a.T / n + torch.eye(n, dtype=torch.float64)
+        if dup:  # an overcomplete basis: the last function repeats the first
+            s[-1, :] = s[0, :]
+            s[:, -1] = s[:, 0]
+            s[-1, -1] = s[0, 0]
+        d = dict(_X=None, orthogonalized=True, _nao_ao=n, device=torch.device("cpu"), _ovlp_ao=s)
+        d.update(kw)
+        return SimpleNamespace(**d)
+
+    hs = [ham(12), ham(12), ham(12, dup=True), ham(7), ham(7), ham(9), ham(12, _X="kept"), ham(12, orthogonalized=False)]
+    assert prepare_orthogonalisers(hs) == 5  # three of size 12, two of size 7; the single 9 is left to the lazy property
+    for h in hs[:5]:
+        x = h._X
+        assert float((x.T @ h._ovlp_ao @ x - torch.eye(x.shape[1], dtype=torch.float64)).abs().max()) < 1e-10
+    assert hs[0]._X.shape == (12, 12) and hs[2]._X.shape == (12, 11)
+    assert hs[5]._X is None and hs[6]._X == "kept" and hs[7]._X is None
