@@ -287,7 +287,9 @@ static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vect
 // prefix offsets of the surviving tasks of every class pair for the coarse test Q_b Q_k >= tc: SCREEN_NBIN entries per pair,
 // one per contraction-depth bin of the partner class (inside a bin the partners are sorted by their bound, descending, so the
 // survivors are a prefix and a two-pointer sweep per (bin, bin) block finds them all)
-static void plan_screen(DirectCtx &c, double tc, ScreenPlan &sp) {
+// dl: nullptr (one threshold `tc` for every class pair) or the 5 x 5 table of density maxima by angular momentum -- then the
+// threshold of a class pair is tau / max(4 dl[la][lb], 4 dl[lc][ld], and with K: dl[la][lc], dl[la][ld], dl[lb][lc], dl[lb][ld])
+static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const double *dl = nullptr, double tau = 0.0, bool with_k = false) {
     c.h_toff.clear();
     c.stat_total = c.stat_launched = 0;
     std::vector<long long> cnt;
@@ -302,6 +304,13 @@ static void plan_screen(DirectCtx &c, double tc, ScreenPlan &sp) {
             class_l(ck, lc, ld);
             const bool same = cb == ck;
             c.stat_total += same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+            double tc = tc_all;
+            if (dl) {
+                auto d2 = [&](int x, int y) { return std::max(dl[5 * x + y], dl[5 * y + x]); };
+                double m = 4.0 * std::max(d2(la, lb), d2(lc, ld));
+                if (with_k) m = std::max(std::max(m, std::max(d2(la, lc), d2(la, ld))), std::max(d2(lb, lc), d2(lb, ld)));
+                tc = m > 0.0 ? tau / m : INFINITY;
+            }
             const bool tpq1 = !hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX && eri_tpq(ncart(la) * ncart(lb) * ncart(lc) * ncart(ld)) == 1;
             const double *qb = c.q.data() + c.hp.cls_start[cb], *qk = c.q.data() + c.hp.cls_start[ck];
             const int *bb = c.bins.data() + (size_t)cb * (SCREEN_NBIN + 1), *bk = c.bins.data() + (size_t)ck * (SCREEN_NBIN + 1);
@@ -360,6 +369,19 @@ __global__ void shell_dmax_kernel(double *__restrict__ dsh, double *__restrict__
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.0)
         atomicMax(reinterpret_cast<unsigned long long *>(dmax), (unsigned long long)__double_as_longlong(m));
+}
+
+// the same maxima per PAIR OF ANGULAR MOMENTA: dl[1 + 5 li + lj] = max |D| over the blocks of all shell pairs (l = li, l = lj).
+// The launch maps of a class pair are cut with the maxima of the blocks its quartets can touch -- the d and f blocks of a
+// density matrix are one to two orders below its s and p blocks, and the classes they belong to are the expensive ones
+__global__ void shell_dmax_by_l_kernel(double *__restrict__ dl, const double *__restrict__ dsh, const int *__restrict__ shl, int nsh) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)nsh * nsh) return;
+    const double m = dsh[e];
+    const int li = shl[e / nsh], lj = shl[e % nsh];
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(dl) + 1 + 5 * li + lj;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+    if (m > 0.0 && bits > *slot) atomicMax(slot, bits);  // (the plain read only saves atomics: a stale value is smaller)
 }
 }  // namespace dqc
 
@@ -447,7 +469,7 @@ int dqc_direct_create(void **ctx_out, const int *atm, int natm, const int *bas, 
     if ((rc = c->pool.upload(&d_sh, c->hp.sh, st)) || (rc = c->pool.upload(&d_off, c->hp.pp_off, st)) ||
         (rc = c->pool.upload(&d_pp, c->hp.pp, st)) || (rc = c->pool.upload(&c->d_q, c->q, st)) || (rc = c->pool.upload(&c->d_bins, c->bins, st)) || (rc = c->pool.alloc(&c->d_dsh, nsh * nsh)) ||
         (rc = c->pool.alloc(&c->d_sym, n2)) || (rc = c->pool.alloc(&c->d_a, n2)) || (rc = c->pool.alloc(&c->d_b, n2)) ||
-        (rc = c->pool.alloc(&c->d_dmax, 2)) || (rc = c->pool.alloc(&c->d_toff, ntoff))) {
+        (rc = c->pool.alloc(&c->d_dmax, 26)) || (rc = c->pool.alloc(&c->d_toff, ntoff))) {
         set_error("dqc_direct_create: device allocation failed");
         return rc;
     }
@@ -509,16 +531,18 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     const ScreenPlan *spp = nullptr;
     int rc;
     if (tau > 0.0) {
-        DQC_HIP(hipMemsetAsync(c.d_dmax, 0, sizeof(double) * 2, st));
+        DQC_HIP(hipMemsetAsync(c.d_dmax, 0, sizeof(double) * 26, st));
         const long long npr = (long long)nsh * nsh;
         hipLaunchKernelGGL(shell_dmax_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dsh, c.d_dmax, c.d_sym, c.ds.ao_off,
                            c.ds.l, nsh, nao);
         DQC_CHECK_LAUNCH();
-        double dmax = 0.0;
-        DQC_HIP(hipMemcpyAsync(&dmax, c.d_dmax, sizeof(double), hipMemcpyDeviceToHost, st));
-        DQC_HIP(hipStreamSynchronize(st));  // the launch sizes of this pass depend on max |D|
-        c.stat_dmax = dmax;
-        plan_screen(c, dmax > 0.0 ? tau / (4.0 * dmax) : INFINITY, sp);
+        hipLaunchKernelGGL(shell_dmax_by_l_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dmax, c.d_dsh, c.ds.l, nsh);
+        DQC_CHECK_LAUNCH();
+        double dmx[26];  // [0]: max |D|, [1 + 5 li + lj]: by angular momentum of the block
+        DQC_HIP(hipMemcpyAsync(dmx, c.d_dmax, sizeof(dmx), hipMemcpyDeviceToHost, st));
+        DQC_HIP(hipStreamSynchronize(st));  // the launch sizes of this pass depend on the density maxima
+        c.stat_dmax = dmx[0];
+        plan_screen(c, 0.0, sp, dmx + 1, tau, d_K != nullptr);
         if (!c.h_toff.empty())
             DQC_HIP(hipMemcpyAsync(c.d_toff, c.h_toff.data(), sizeof(long long) * c.h_toff.size(), hipMemcpyHostToDevice, st));
         sp.d_toff = c.d_toff;

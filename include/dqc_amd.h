@@ -272,7 +272,8 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
  *   dqc_direct_jk      J and K of one density as dqc_jk_direct, skipping every shell quartet whose contribution is bounded by
  *                      tau:  Q_ab Q_cd max(4 |D_ab|, 4 |D_cd|, |D_ac|, |D_ad|, |D_bc|, |D_bd|) < tau  (block maxima of D; the
  *                      exchange blocks only when d_K is given).  Quartets are dropped at launch (prefix of the Q-sorted partner
- *                      list, global max |D|) and per quartet inside the kernel.  tau = 0: every quartet (bit-for-bit the
+ *                      list, with the maxima of |D| over the blocks -- by angular momentum -- that a class of quartets can
+ *                      touch) and per quartet inside the kernel.  tau = 0: every quartet (bit-for-bit the
  *                      unscreened sums up to the order of the atomics).  One 8-byte device->host read per call (max |D| sets the
  *                      launch sizes).  J and K are linear in D: hand over density DIFFERENCES to let the screening bite as the
  *                      SCF converges (HamiltonMI355 does).  The error of an element of J / K is bounded by tau times the number
