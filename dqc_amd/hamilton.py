@@ -382,12 +382,19 @@ class HamiltonMI355(_Base):
             w = self._jkwork_multi = torch.empty(need, dtype=torch.float64, device=self.device)
         return w
 
-    def _jk_many(self, dms_j, dms_k):
+    def _jk_many(self, dms_j, dms_k, j_is_sum_of_k=False):
         """Coulomb matrices of the stacked (nj, nao, nao) `dms_j` and exchange matrices K of `dms_k`, all from ONE pass over
         the ERI tiles (dqc_jk_from_tiles_multi); orthogonalised basis in and out."""
         dj = None if dms_j is None else self._unconvert_dm(dms_j)
         dk = None if dms_k is None else self._unconvert_dm(dms_k)
         if self._direct:  # one pass over the shell quartets per density
+            if j_is_sum_of_k and dj is not None and dk is not None and dj.shape[0] == 1:
+                # unrestricted Hartree-Fock: J[D_u + D_d] = J[D_u] + J[D_d], and a J + K pass yields J of its density anyway:
+                # two passes over the shell quartets instead of three
+                jk = [self._jk_direct(d, True, ("k", i)) for i, d in enumerate(dk)]
+                J = sum(x[0] for x in jk).unsqueeze(0)
+                K = torch.stack([x[1] for x in jk])
+                return self._sym_orth(J), self._sym_orth(K)
             J = None if dj is None else torch.stack([self._jk_direct(d, False, ("j", i))[0] for i, d in enumerate(dj)])
             K = None if dk is None else torch.stack([self._jk_direct(d, True, ("k", i))[1] for i, d in enumerate(dk)])
             return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
@@ -432,7 +439,7 @@ class HamiltonMI355(_Base):
         c = getattr(self, "_jkpol_cache", None)
         if c is not None and c[0] is dm.u and c[1] is dm.d and c[2] == (dm.u._version, dm.d._version):
             return c[3], c[4]
-        J, K = self._jk_many((dm.u + dm.d).unsqueeze(0), torch.stack([dm.u, dm.d]))
+        J, K = self._jk_many((dm.u + dm.d).unsqueeze(0), torch.stack([dm.u, dm.d]), j_is_sum_of_k=True)
         # K[2 D] = 2 K[D] and the operator is -K/2: the two factors cancel
         out = (J[0], (-K[0], -K[1]))
         self._jkpol_cache = (dm.u, dm.d, (dm.u._version, dm.d._version), out[0], out[1])
