@@ -59,7 +59,8 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
 // class dispatch
 // ---------------------------------------------------------------------------------------------
 template <int LA, int LB, int LC, int LD>
-static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st) {
+static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st,
+                        const EriOut &og) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
@@ -69,7 +70,6 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)Cfg::LDS_BYTES);
-    EriOut og{0, 0, 0, 0};
     hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
                        dp, hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask, og);
     DQC_CHECK_LAUNCH();
@@ -79,13 +79,13 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
 // all classes with (LA>=LB), (LC>=LD), class(bra) >= class(ket)
 template <int CB, int CK>
 struct ClassLoop {
-    static int run(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st) {
+    static int run(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st, const EriOut &og) {
         constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
         constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
-        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, dp, hp, st);
+        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, dp, hp, st, og);
         if (rc) return rc;
-        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, dp, hp, st);
-        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, dp, hp, st);
+        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, dp, hp, st, og);
+        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, dp, hp, st, og);
         else return 0;
     }
 };
@@ -566,13 +566,26 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
 
 int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas, int nbas, const double *env,
                        int nenv, void *stream) {
+    return dqc_eri_fill_tiles_part(d_tiles, atm, natm, bas, nbas, env, nenv, 0, -1, stream);
+}
+
+int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
+                            long long tile_begin, long long tile_end, void *stream) {
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     Basis b;
     int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
     if (rc) return rc;
     if (nbas == 0 || b.nao == 0) return DQC_OK;
-    DQC_HIP(hipMemsetAsync(d_tiles, 0, sizeof(double) * (size_t)eri_store_data_doubles(b.nao), st));  // packed store (common.hpp)
+    const long long nt_all = (long long)dqc_eri_tile_count(b.nao);
+    if (tile_end < 0) tile_end = nt_all;
+    if (tile_begin < 0 || tile_end > nt_all || tile_begin > tile_end) { set_error("dqc_eri_fill_tiles_part: tile range outside the store"); return DQC_EINVAL; }
+    // a slice [tile_begin, tile_end) of the store (one rank's share when the store is spread over several GPUs): every shell
+    // quartet is still evaluated -- the integrals of a quartet scatter over several tiles -- but only the slice is written
+    const long long lo = dqc_eri_tile_offset(b.nao, tile_begin), hi = dqc_eri_tile_offset(b.nao, tile_end);
+    if (hi == lo) return DQC_OK;
+    double *d_tiles = d_tiles_part - lo;  // virtual origin: the kernels address by offsets in the whole store
+    DQC_HIP(hipMemsetAsync(d_tiles_part, 0, sizeof(double) * (size_t)(hi - lo), st));  // packed store (common.hpp)
     if ((rc = boys_table_ensure())) return rc;
     HostPairs hp;
     build_pairs(b, hp);
@@ -588,9 +601,12 @@ int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas
     }
     DevPairs dp{d_sh, d_off, d_pp};
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
-    rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st);
+    EriOut og{0, 0, 0, 0};
+    og.st_lo = lo;
+    og.st_hi = hi;
+    rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og);
     if (rc) return rc;
-    if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, EriOut{0, 0, 0, 0}, st))) return rc;
+    if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;
     return DQC_OK;
 }
 

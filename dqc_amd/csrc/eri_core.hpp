@@ -68,7 +68,9 @@ __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2;
 // block pair >= ket block pair -- plus its transpose when both block pairs coincide ((ij|kl) and (kl|ij) live in the same tile).
 // Eight guarded stores per element (index arithmetic + the closed-form tile offset each time) were most of the instructions of
 // the shallow (cc-pVTZ-type, one primitive quartet) classes.
-DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l, double v) {
+// [lo, hi): the double offsets of the slice of the store this launch fills (a rank's share of a store sharded over several
+// GPUs: `tiles` is then the slice's virtual origin, slice - lo); whole store: 0 ... LLONG_MAX
+DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l, double v, long long lo, long long hi) {
     int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
     int il = i & 7, jl = j & 7, kl = k & 7, ll = l & 7;
     if (I < J || (I == J && il < jl)) { int t = I; I = J; J = t; t = il; il = jl; jl = t; }
@@ -79,7 +81,9 @@ DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l
     }
     const int C = tile_dim(K == L);
     const int r = tile_pidx(I == J, il, jl), c = tile_pidx(K == L, kl, ll);
-    double *tb = tiles + tile_base(I, J, K, KL);
+    const long long base = tile_base(I, J, K, KL);
+    if (base < lo || base >= hi) return;
+    double *tb = tiles + base;
     tb[(long long)r * C + c] = v;
     if (IJ == KL) tb[(long long)c * C + r] = v;
 }
@@ -188,6 +192,8 @@ struct EriOut {
     int nsh = 0;
     // ---- one molecule sharded over GPUs (dqc_direct_jk_part): this launch is part `part` of `nparts` interleaved block sets
     int part = 0, nparts = 1;
+    // ---- TILES mode: slice [st_lo, st_hi) (double offsets) of the store this launch fills (dqc_eri_fill_tiles_part)
+    long long st_lo = 0, st_hi = 0x7fffffffffffffffLL;
 };
 constexpr int SCREEN_NBIN = 8;
 // contraction-depth bin of a pair with npp surviving primitive pairs: 0 = deepest (> 64) ... 7 = one primitive pair (or none)
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
             } else
             if (MODE == ERI_OUT_TILES) {
-                tile_put_all(tiles, i, j, k, l, v);
+                tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi);
             } else if (MODE == ERI_OUT_3C) {
                 const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                 tiles[(io * og.nao + jo) * og.naux + kx] = v;

@@ -457,7 +457,9 @@ __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *_
 // keep the 2-shuffle + 4-wave LDS combine of jk_tiles_kernel.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
-                                                         double *__restrict__ work, int npad, long long ntiles, long long per_block) {
+                                                         double *__restrict__ work, int npad, long long ntiles, long long per_block,
+                                                         long long tbeg) {
+    // (tiles [tbeg, ntiles): the whole store, or one rank's slice of it -- dqc_jk_from_tiles_part)
     const double dsc = dscp ? *dscp : 0.0;
     __shared__ double s_col[2][4][64];
     const size_t n2 = (size_t)npad * npad;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
     const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
-    const long long T0 = (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
+    const long long T0 = tbeg + (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
     if (T0 >= T1) return;
     int IJ, KL, I, J, K, L;
     decode_tri(T0, IJ, KL);
@@ -545,7 +547,8 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
 // atomics cost 12 % of its time, the K atomics 6 %, the LDS contraction 16 %).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
-                                                          double *__restrict__ work, int npad, long long ntiles, long long per_block) {
+                                                          double *__restrict__ work, int npad, long long ntiles, long long per_block,
+                                                          long long tbeg) {
     const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     __shared__ double s_col[4][64];  // (single buffer: two barriers per tile separate its writers and readers anyway)
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restr
     const int r0 = 4 * (t >> 4), c0 = 4 * (t & 15);
     const int kk = c0 >> 3, l0 = c0 & 7, ii = r0 >> 3, j0 = r0 & 7;
     const int o = t >> 2, pg = t & 3, x = o >> 3, y = o & 7, yh = y >> 2;  // exchange part: output (x, y), partial group pg
-    const long long T0 = (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
+    const long long T0 = tbeg + (long long)blockIdx.x * per_block, T1 = min(T0 + per_block, ntiles);
     if (T0 >= T1) return;
     int IJ, KL, I, J, K, L;
     decode_tri(T0, IJ, KL);
@@ -852,13 +855,48 @@ size_t dqc_jk_work_doubles(int nao) {
     return 3 * npad * npad + 8;  // D, J, K accumulators + the fixed-point scale of the deterministic mode
 }
 
+long long dqc_eri_tile_offset(int nao, long long tile) {
+    // doubles in front of tile `tile` (0 ... tile count) of the packed store of a basis with nao functions: tiles follow each
+    // other in the order (IJ, KL <= IJ), tile = IJ (IJ + 1) / 2 + KL
+    using namespace dqc;
+    const long long nt = (long long)dqc_eri_tile_count(nao);
+    if (nao <= 0 || tile <= 0) return 0;
+    if (tile >= nt) return eri_store_data_doubles(nao);
+    auto tri = [](long long t, long long &a, long long &b) {
+        long long r = (long long)((std::sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > t) r--;
+        while ((r + 1) * (r + 2) / 2 <= t) r++;
+        a = r;
+        b = t - r * (r + 1) / 2;
+    };
+    long long IJ, KL, I, J, K, L;
+    tri(tile, IJ, KL);
+    tri(IJ, I, J);
+    tri(KL, K, L);
+    return tile_base((int)I, (int)J, (int)K, (int)KL);
+}
+
 int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm, int nao,
                       double *d_work, void *stream) {
+    return dqc_jk_from_tiles_part(d_J, d_K, d_tiles, d_dm, nao, d_work, 0, (long long)dqc_eri_tile_count(nao), stream);
+}
+
+int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part, const double *d_dm, int nao, double *d_work,
+                           long long tile_begin, long long tile_end, void *stream) {
     using namespace dqc;
     if (nao <= 0) return DQC_OK;
     hipStream_t st = (hipStream_t)stream;
     const int npad = (nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
-    const long long ntiles = (long long)dqc_eri_tile_count(nao);
+    const long long nt_all = (long long)dqc_eri_tile_count(nao);
+    if (tile_begin < 0 || tile_end > nt_all || tile_begin > tile_end) { set_error("dqc_jk_from_tiles_part: tile range outside the store"); return DQC_EINVAL; }
+    const bool whole = tile_begin == 0 && tile_end == nt_all;
+    if (!whole && deterministic_mode()) {
+        set_error("dqc_jk_from_tiles_part: the deterministic mode needs the whole store (its scale reads the diagonal tiles)");
+        return DQC_EINVAL;
+    }
+    // the kernels address tiles by their offset in the WHOLE store: a slice is handed over with its virtual origin
+    const double *d_tiles = d_tiles_part - dqc_eri_tile_offset(nao, tile_begin);
+    const long long ntiles = tile_end, tbeg = tile_begin, nrun = tile_end - tile_begin;
     const int with_k = d_K != nullptr;
     hipLaunchKernelGGL(jk_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dm, nao, npad, with_k);
     DQC_CHECK_LAUNCH();
@@ -870,12 +908,18 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     }
     const unsigned grid = (unsigned)std::min<long long>(ntiles, 256 * 16);
     static const char *jimpl = getenv("DQC_J_IMPL");  // "stride": the grid-stride kernel of round 1 (A/B runs)
+    if (nrun == 0) {
+        // (an empty slice: nothing to add)
+    } else if (!whole && jimpl && jimpl[0] == 's') {
+        set_error("dqc_jk_from_tiles_part: DQC_J_IMPL=stride streams the whole store only");
+        return DQC_EINVAL;
+    } else
     if (with_k && !(jimpl && jimpl[0] == 's')) {
         // contiguous tile ranges of >= 8 tiles, 1024 ... 6144 blocks (4 resident per CU; sweep 1024 ... 8192 on benzene, 20-atom
         // cc-pVDZ and naphthalene / cc-pVTZ: flat within 3 % inside this window)
-        const long long nblk = std::min<long long>(ntiles, std::max<long long>(1024, std::min<long long>(6144, ntiles / 8)));
-        const long long per = (ntiles + nblk - 1) / nblk;
-        hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per);
+        const long long nblk = std::min<long long>(nrun, std::max<long long>(1024, std::min<long long>(6144, nrun / 8)));
+        const long long per = (nrun + nblk - 1) / nblk;
+        hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg);
     } else if (with_k) {
         hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
     } else if (jimpl && jimpl[0] == 's') {
@@ -883,9 +927,9 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     } else {
         // contiguous tile ranges, ~6 resident blocks per CU x 2 rounds.  (Tried: 8 x 4 tile rectangles with the column sums in
         // LDS, 24 atomics per tile and no barrier -- 0.396 ms against 0.37 ms for this form: shorter contiguous runs.)
-        const long long nblk = std::min<long long>(ntiles, 256 * 12);
-        const long long per = (ntiles + nblk - 1) / nblk;
-        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((ntiles + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per);
+        const long long nblk = std::min<long long>(nrun, 256 * 12);
+        const long long per = (nrun + nblk - 1) / nblk;
+        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg);
     }
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad, dscp);

@@ -163,6 +163,9 @@ class HamiltonMI355(_Base):
             # exact J/K keeps the 8-fold-unique 8^4 tiles resident: ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, > 288 GB
             # near nao 740).  Fail with a message instead of an allocator OOM deep inside the fill.
             need = lib.eri_store_doubles(tab.nao) * 8
+            if self._pworld > 1 and self._eri_mode == "tiles":  # this rank's slice of the store
+                self._tile_slice = lib.tile_slice(tab.nao, self._prank, self._pworld)
+                need = self._tile_slice[2] * 8
             free, _total = torch.cuda.mem_get_info(dev)
             free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)  # blocks cached by the allocator are reusable
             mode = self._eri_mode
@@ -187,7 +190,10 @@ class HamiltonMI355(_Base):
             side = _side_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._tiles_store = lib.eri_tiles(tab, dev)
+                if self._tile_slice is not None:
+                    self._tiles_store = lib.eri_tiles_part(tab, dev, self._tile_slice[0], self._tile_slice[1])
+                else:
+                    self._tiles_store = lib.eri_tiles(tab, dev)
                 fill_done = torch.cuda.Event()
                 fill_done.record(side)
             self._tiles_store.record_stream(main)
@@ -294,15 +300,19 @@ class HamiltonMI355(_Base):
 
     # ------------------------------------------------------------------ one molecule over several GPUs
     _pg, _prank, _pworld = None, 0, 1
+    _tile_slice = None  # (tile_begin, tile_end, doubles) when the tile store is spread over the ranks
 
-    def shard_over(self, group=None):
+    def shard_over(self, group=None, eri="direct"):
         """before build() / setup_grid(), on EVERY rank of `group` (default: the world group): this one molecule is spread
         over the ranks' GPUs -- rank r evaluates every world-th block of shell quartets of the screened direct J / K pass
         (dqc_direct_jk_part) and the r-th contiguous slab of the grid (its AO matrix is 1 / world of the whole), and the
         partial J, K, Vxc matrices and the E_xc quadrature are summed with ONE all_reduce each per Fock build (RCCL; n^2
         doubles: latency-bound).  The SCF driver runs on every rank (SPMD); rank 0's convergence scalars are broadcast once
         per iteration so that all ranks take the same decisions.  Tile store and density fitting are not sharded: the
-        Hamiltonian switches to direct SCF.  Nuclear gradients of a sharded Hamiltonian are not provided."""
+        Hamiltonian switches to direct SCF.  Nuclear gradients of a sharded Hamiltonian are not provided.
+        eri="tiles": the STORED path instead -- the packed tile store itself is spread over the ranks' memories (rank r keeps
+        and streams the r-th contiguous slice of the tiles: 8 x 288 GB hold the store of ~1200 basis functions;
+        dqc_eri_fill_tiles_part / dqc_jk_from_tiles_part), same all_reduce of the partial J / K."""
         import torch.distributed as dist
         if self.is_built or self.is_grid_set:
             raise RuntimeError("shard_over must be called before build() and setup_grid()")
@@ -312,19 +322,40 @@ class HamiltonMI355(_Base):
             raise RuntimeError("shard_over needs an initialised torch.distributed process group")
         self._pg = group
         self._prank, self._pworld = dist.get_rank(group), dist.get_world_size(group)
-        self._eri_mode = "direct"
+        if eri not in ("direct", "tiles"):
+            raise RuntimeError("shard_over: eri must be 'direct' or 'tiles'")
+        self._eri_mode = eri
+        self._tile_slice = None
         return self
 
     @property
     def sharded(self):
         return self._pworld > 1
 
+    _deferred = None  # a list while a build collects its partial results for ONE all_reduce (_allsum_deferred)
+
     def _allsum(self, t):
         """sum of the ranks' partial results, in place (no-op for an unsharded Hamiltonian)"""
         if self._pworld > 1 and t is not None:
+            if self._deferred is not None:
+                self._deferred.append(t)
+                return t
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._pg)
         return t
+
+    def _allsum_flush(self):
+        """the partial results collected since `_deferred = []` summed over the ranks with one all_reduce of their concatenation
+        (J, Vxc and the E_xc quadrature of a Fock build are each latency-bound on their own)"""
+        ts, self._deferred = self._deferred, None
+        if ts:
+            import torch.distributed as dist
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._pg)
+            o = 0
+            for t in ts:
+                t.copy_(flat[o:o + t.numel()].reshape(t.shape))
+                o += t.numel()
 
     def sync_scalars(self, t):
         """rank 0's copy of a small device tensor on every rank (the SCF driver's per-iteration host read): all ranks decide alike"""
@@ -369,6 +400,9 @@ class HamiltonMI355(_Base):
         """(J, K or None) of one AO-basis density: from the resident tiles, or directly from the shell quartets"""
         if self._direct:
             return self._jk_direct(dao, with_k, slot)
+        if self._tile_slice is not None:  # the store is spread over the ranks: stream this rank's slice, add the parts up
+            J, K = lib.jk_part(self._tiles, dao, self._jkwork, with_k, self._tile_slice[0], self._tile_slice[1])
+            return self._allsum(J), self._allsum(K)
         return lib.jk(self._tiles, dao, self._jkwork, with_k)
 
     def _sym_orth(self, m_ao):
@@ -397,6 +431,13 @@ class HamiltonMI355(_Base):
                 return self._sym_orth(J), self._sym_orth(K)
             J = None if dj is None else torch.stack([self._jk_direct(d, False, ("j", i))[0] for i, d in enumerate(dj)])
             K = None if dk is None else torch.stack([self._jk_direct(d, True, ("k", i))[1] for i, d in enumerate(dk)])
+            return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
+        if self._tile_slice is not None:  # (the several-densities-per-pass kernel streams the whole store only)
+            if j_is_sum_of_k and dj is not None and dk is not None and dj.shape[0] == 1:
+                jk = [self._jk_ao(d, True) for d in dk]
+                return self._sym_orth(sum(x[0] for x in jk).unsqueeze(0)), self._sym_orth(torch.stack([x[1] for x in jk]))
+            J = None if dj is None else torch.stack([self._jk_ao(d, False)[0] for d in dj])
+            K = None if dk is None else torch.stack([self._jk_ao(d, True)[1] for d in dk])
             return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
         J, K = lib.jk_multi(self._tiles, dj, dk, self._multi_work(0 if dj is None else dj.shape[0], 0 if dk is None else dk.shape[0]))
         return (None if J is None else self._sym_orth(J)), (None if K is None else self._sym_orth(K))
@@ -662,6 +703,8 @@ class HamiltonMI355(_Base):
             dao = (fac[0][0] @ fac[0][1])[:n, :n].contiguous()
         else:
             dao = self._unconvert_dm(dm)
+        if self._tile_slice is not None:  # tile store spread over the ranks: J, Vxc and E_xc parts travel in one all_reduce
+            self._deferred = []
         if self._df is not None:
             jao = self._df.coulomb_ao(dao)
         else:
@@ -672,11 +715,13 @@ class HamiltonMI355(_Base):
             self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
         else:
             potinfo, exc = self.xc.get_vxc(densinfo), None
+        vm = self._vxc_ao_from_potinfo(potinfo)
+        if self._deferred is not None:
+            self._allsum_flush()
         # the two-electron energies of THIS density fall out of the build (tr D J = tr D_ao J_ao): remembered under the
         # identity + version of `dm`, so that dm2energy(dm) right after dm2scp(dm) streams neither the tiles nor the grid again
         e_j = 0.5 * (dao * jao).sum()
         self._energy_memo = (dm, dm._version, e_j, None if exc is None else exc[0])
-        vm = self._vxc_ao_from_potinfo(potinfo)
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
 

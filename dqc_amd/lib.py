@@ -50,6 +50,10 @@ def load():
     if hasattr(lib, "dqc_eri_store_doubles"):  # (absent from the pre-packing A/B build tools/gpu_jk_ab.py loads)
         lib.dqc_eri_store_doubles.argtypes = [c_int]
         lib.dqc_eri_store_doubles.restype = c_sz
+    lib.dqc_eri_tile_offset.argtypes = [c_int, ctypes.c_longlong]
+    lib.dqc_eri_tile_offset.restype = ctypes.c_longlong
+    lib.dqc_eri_fill_tiles_part.argtypes = [c_dp, ip, c_int, ip, c_int, dp, c_int, ctypes.c_longlong, ctypes.c_longlong, c_vp]
+    lib.dqc_jk_from_tiles_part.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, ctypes.c_longlong, ctypes.c_longlong, c_vp]
     lib.dqc_jk_work_doubles.argtypes = [c_int]
     lib.dqc_jk_work_doubles.restype = c_sz
     tab = [ip, c_int, ip, c_int, dp, c_int]
@@ -406,6 +410,35 @@ class DirectContext:
             self.close()
         except Exception:
             pass
+
+
+def tile_slice(nao, part, nparts):
+    """(tile_begin, tile_end, doubles) of the `part`-th of `nparts` contiguous slices of the packed tile store, equal in tiles"""
+    nt = int(load().dqc_eri_tile_count(int(nao)))
+    t0, t1 = nt * part // nparts, nt * (part + 1) // nparts
+    L = load()
+    return t0, t1, int(L.dqc_eri_tile_offset(int(nao), t1) - L.dqc_eri_tile_offset(int(nao), t0))
+
+
+def eri_tiles_part(tab, device, t0, t1):
+    """the tiles [t0, t1) of the packed store (one rank's slice when the store is spread over several GPUs)"""
+    L = load()
+    n = int(L.dqc_eri_tile_offset(tab.nao, t1) - L.dqc_eri_tile_offset(tab.nao, t0))
+    tiles = torch.empty(max(n, 1), dtype=torch.float64, device=device)
+    with _on(device) as st_:
+        _check(L.dqc_eri_fill_tiles_part(_ptr(tiles), *tab.args(), int(t0), int(t1), st_), "dqc_eri_fill_tiles_part")
+    return tiles
+
+
+def jk_part(tiles_part, dm_ao, work, with_k, t0, t1):
+    """PARTIAL J, K (the contributions of the tiles [t0, t1) held in `tiles_part`): the caller sums the ranks' parts"""
+    nao = dm_ao.shape[-1]
+    J = torch.empty((nao, nao), dtype=torch.float64, device=dm_ao.device)
+    K = torch.empty_like(J) if with_k else None
+    with _on(dm_ao.device) as st_:
+        _check(load().dqc_jk_from_tiles_part(_ptr(J), _ptr(K), _ptr(tiles_part), _ptr(dm_ao.contiguous()), nao, _ptr(work),
+                                             int(t0), int(t1), st_), "dqc_jk_from_tiles_part")
+    return J, K
 
 
 def jk_multi(tiles, dms_j, dms_k, work=None):

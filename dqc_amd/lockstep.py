@@ -117,7 +117,7 @@ class LockstepSCF:
         # 0.1-0.4 ms of kernels); a 20-atom build (1.4 ms of kernels) is issued eagerly -- capturing 32 graphs would cost
         # more than the launches they save
         self.use_graph = ((self.n <= 160) if graph == "auto" else bool(graph)) and not self.pol  # (GraphedFock is restricted-only)
-        if any(getattr(e.hamilton, "_direct", False) for e in self.engines):
+        if any(getattr(e.hamilton, "_direct", False) or getattr(e.hamilton, "sharded", False) for e in self.engines):
             self.use_graph = False  # direct SCF builds are not capturable (per-call scratch and table uploads)
         gen = torch.Generator().manual_seed(20240229)
         self.omega = [torch.randn((self.n, r), dtype=self.dtype, generator=gen).to(self.device) if r else None for r, _ in self.channels]

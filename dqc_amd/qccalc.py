@@ -191,7 +191,9 @@ class SCF_QCCalc:
         # (dqc_amd/purify.py); "eigh" keeps the reference's diagonalise-and-occupy step (hf.py:105-113)
         graphed, purified = None, None
         # (direct SCF builds allocate stream-ordered scratch and upload pair tables per call: not captured)
-        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "_direct", False):
+        # (nor the builds of a Hamiltonian sharded over several GPUs: they hold collectives)
+        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "_direct", False) \
+                and not getattr(eng.hamilton, "sharded", False):
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)

@@ -254,6 +254,18 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
                       const double *d_w, const double *d_v, void *stream);
 
+/* ---- the tile store spread over several GPUs (one molecule on N ranks: 8 x 288 GB hold the tiles of ~1200 basis functions) ----
+ * Tiles follow each other in the order (IJ, KL <= IJ); a rank keeps the tiles [tile_begin, tile_end) in a buffer of
+ * dqc_eri_tile_offset(nao, tile_end) - dqc_eri_tile_offset(nao, tile_begin) doubles.  dqc_eri_fill_tiles_part evaluates every
+ * shell quartet (a quartet's integrals scatter over several tiles) and writes only the slice; dqc_jk_from_tiles_part streams the
+ * slice and returns the PARTIAL d_J / d_K of its tiles -- the caller adds the ranks' parts (all_reduce).  tile_end = -1 in the
+ * fill: to the end of the store.  The deterministic mode needs the whole store. */
+long long dqc_eri_tile_offset(int nao, long long tile);
+int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv,
+                            long long tile_begin, long long tile_end, void *stream);
+int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part, const double *d_dm, int nao, double *d_work,
+                           long long tile_begin, long long tile_end, void *stream);
+
 /* ---- direct SCF: J and K straight from the shell quartets, nothing stored  ("direct / recompute above") ----
  * The stored tile form needs ~nao^4 bytes (2 GB at nao 208, 31 GB at 412, beyond one GPU near nao 740); this entry point
  * re-evaluates every unique shell quartet (the Rys kernel of dqc_eri_fill_tiles) and contracts it with the density on the fly:
