@@ -58,6 +58,8 @@ def main():
                     help="HIP streams the batch's Fock builds are dealt to (molecule k -> stream k %% S): independent molecules, so "
                          "the tail of one molecule's kernels overlaps the head of the next one's (SURVEY 8e: each rank, own streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-molecule-leg", action="store_true",
+                    help="N > 1: skip the leg that spreads ONE C4 molecule over the ranks (HamiltonMI355.shard_over)")
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--profile-mode", action="store_true",
                     help="only setup + warmup + the timed steps (for rocprofv3 passes: no extra legs, no CPU work)")
@@ -385,6 +387,14 @@ def main():
         out_extra["small_batch"] = small_batch_leg(dev)
         out_extra["direct_scf"] = direct_scf_leg(dev)
 
+    # N > 1 only, after everything that is timed for the headline: ONE molecule (C4) spread over the N ranks -- the path with a
+    # data-path collective (last row).  Run under a watchdog: a wedged collective must not cost the line above.
+    one_mol = None
+    if world > 1 and extras and not args.no_one_molecule_leg:
+        one_mol = one_molecule_sharded_leg(dev, rank, world, timeout_s=150.0)
+        if one_mol is not None:
+            out_extra["one_molecule_sharded"] = one_mol
+
     if rank == 0:
         c = 4  # GGA: phi + 3 gradient components
         norb_pad = 0 if dense else lib.padded_norb(orbs[0].shape[1])
@@ -477,8 +487,78 @@ def main():
             out["cpu_baseline_reference_shape"] = cpu_baseline_dense_benzene(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
+        if one_mol is not None and (one_mol.get("hung") or one_mol.get("error")):
+            # a collective of the one-molecule leg did not return on some rank (or a rank left the leg early): the line is out;
+            # leave without touching the process group again -- a rank stuck in its watchdog follows when that expires
+            sys.stdout.flush()
+            os._exit(0)
+        if one_mol is not None:  # (the closing barrier under the same kind of watchdog)
+            import threading
+            th = threading.Thread(target=lambda: (dist.barrier(), dist.destroy_process_group()), daemon=True)
+            th.start()
+            th.join(120.0)
+            if th.is_alive():
+                sys.stdout.flush()
+                os._exit(0)
+            return
         dist.barrier()
         dist.destroy_process_group()
+
+
+def one_molecule_sharded_leg(dev, rank, world, timeout_s):
+    """ONE C4 molecule (naphthalene / cc-pVTZ, RKS PBE, sg3) spread over the ranks of this run: HamiltonMI355.shard_over(eri="tiles")
+    -- every rank fills and streams its slice of the 30 GB tile store and its slab of the grid; the partial J + Vxc + E_xc of a
+    Fock build travel in one all_reduce (RCCL over xGMI).  Timed: Fock builds of the core-guess density, barrier-bracketed.  The
+    work runs in a watchdog thread: on a timeout (a wedged collective) the leg reports `hung` and the caller leaves without
+    touching the process group again.  `fock_build_ms_one_gpu_unsharded` is in the N = 1 line (direct_scf leg) for comparison."""
+    import threading
+    import torch.distributed as dist
+    res = {}
+
+    def work():
+        try:
+            import dqc_amd
+            from tests import molecules as M
+            torch.cuda.set_device(dev)
+            t0 = time.perf_counter()
+            mol = dqc_amd.Mol(M.naphthalene(), basis="cc-pvtz", grid="sg3", device=dev)
+            h = mol.get_hamiltonian().shard_over(eri="tiles")
+            eng = dqc_amd.KS(mol, xc=XC)._engine
+            n = eng.shape[-1]
+            dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64, device=dev)))
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            res["setup_s"] = time.perf_counter() - t0
+            for _ in range(3):
+                eng.dm2scp(dm)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            k = 40
+            t1 = time.perf_counter()
+            for _ in range(k):
+                f = eng.dm2scp(dm)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            res["fock_build_ms"] = 1e3 * (time.perf_counter() - t1) / k
+            chk = torch.stack([f.abs().sum(), -f.abs().sum()])
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)  # max and -min of the ranks' Fock checksums
+            res["fock_checksum"] = float(chk[0])
+            res["fock_checksum_spread_over_ranks"] = float(chk[0] + chk[1])
+            res.update({"ranks": world, "nao": int(h._nao_ao), "tile_store_gb_per_rank": h._tiles.numel() * 8 / 1e9,
+                        "grid_points_per_rank": int(h.rgrid.shape[0]), "collectives_per_build": 1,
+                        "all_reduce_bytes_per_build": int(8 * (h._nao_ao ** 2 + h._ld ** 2 + 1025)),
+                        "note": "C4 naphthalene RKS PBE / cc-pVTZ sg3, one molecule on all ranks: tile store and grid sliced over "
+                                "the ranks, partial J + Vxc + E_xc summed with one all_reduce per Fock build"})
+            del eng, mol, h
+        except Exception as e:  # noqa: BLE001
+            res["error"] = repr(e)[:400]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"error": "timed out after %.0f s (a collective did not return)" % timeout_s, "hung": True, "ranks": world}
+    return res
 
 
 def direct_scf_leg(dev):
@@ -504,6 +584,19 @@ def direct_scf_leg(dev):
             h = mol.get_hamiltonian()
             out[mode] = {"setup_s": t1 - t0, "scf_s": t2 - t1, "iterations": int(qc.niter), "energy_ha": float(qc.energy()),
                          "converged": bool(qc.converged)}
+            if mode == "tiles":  # one Fock build of this molecule on one GPU: the reference point of the N > 1 one-molecule leg
+                eng = qc._engine
+                n = eng.shape[-1]
+                dm = eng.scp2dm(eng.dm2scp(torch.zeros((n, n), dtype=torch.float64, device=dev)))
+                for _ in range(3):
+                    eng.dm2scp(dm)
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+                for _ in range(20):
+                    eng.dm2scp(dm)
+                torch.cuda.synchronize(dev)
+                out["fock_build_ms_one_gpu_unsharded"] = 1e3 * (time.perf_counter() - t3) / 20
+                del eng, dm
             if mode == "direct":
                 tot, lau, dmax = h._direct_stats
                 out[mode].update({"unique_shell_quartets": int(tot), "launched_share_last_build": lau / max(tot, 1),
