@@ -417,3 +417,25 @@ def test_prepare_orthogonalisers_batched_eigh_on_cpu():
         assert float((x.T @ h._ovlp_ao @ x - torch.eye(x.shape[1], dtype=torch.float64)).abs().max()) < 1e-10
     assert hs[0]._X.shape == (12, 12) and hs[2]._X.shape == (12, 11)
     assert hs[5]._X is None and hs[6]._X == "kept" and hs[7]._X is None
+
+
+def test_tile_store_slices_partition_the_store_host_arithmetic():
+    """dqc_eri_tile_offset / lib.tile_slice (host arithmetic of the packed tile store, no GPU needed): offsets grow tile by tile
+    by 36 x 36, 36 x 64, 64 x 36 or 64 x 64 doubles (diagonal block pairs keep their i >= j elements), the last offset is the
+    store size, and the N slices of lib.tile_slice partition the tiles and the doubles for every N"""
+    from dqc_amd import lib
+    L = lib.load()
+    for nao in (1, 7, 8, 9, 24, 86, 114, 208):
+        nt = int(L.dqc_eri_tile_count(nao))
+        nb = (nao + 7) // 8
+        npair = nb * (nb + 1) // 2
+        assert nt == npair * (npair + 1) // 2
+        offs = [int(L.dqc_eri_tile_offset(nao, t)) for t in range(nt + 1)]
+        assert offs[0] == 0 and offs[-1] == lib.eri_store_doubles(nao)
+        sizes = {b - a for a, b in zip(offs[:-1], offs[1:])}
+        assert sizes <= {36 * 36, 36 * 64, 64 * 36, 64 * 64} and min(sizes) > 0
+        assert int(L.dqc_eri_tile_offset(nao, nt + 5)) == offs[-1] and int(L.dqc_eri_tile_offset(nao, -3)) == 0
+        for nparts in (1, 2, 3, 8, 50):
+            sl = [lib.tile_slice(nao, r, nparts) for r in range(nparts)]
+            assert sl[0][0] == 0 and sl[-1][1] == nt and all(a[1] == b[0] for a, b in zip(sl[:-1], sl[1:]))
+            assert sum(x[2] for x in sl) == offs[-1] and all(x[2] == offs[x[1]] - offs[x[0]] for x in sl)
