@@ -461,7 +461,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
 // Vxc for larger bases: the wave-specialised kernel with RECTANGULAR output ownership.  vxc_ws_kernel splits the
 // T x T output tiles linearly over `nsplit` blocks that each stage ALL columns of a slab; beyond two blocks per
 // slab that re-reads the slab nsplit times (nsplit = 18 at nao = 624).  Here block (slab, i, j) owns the tile
-// rectangle  rows [i T / NR, (i+1) T / NR)  x  cols [j T / NC, (j+1) T / NC)  (<= 8 x 11 tiles) and its producers
+// rectangle  rows [i T / NR, (i+1) T / NR)  x  cols [j T / NC, (j+1) T / NC)  (<= 9 x 12 tiles, <= 88 of them) and its producers
 // stage only the Phi columns of those rows (A operand) and the four AO components of those columns (-> Psi, B
 // operand): per-block loads are what vxc_ws_kernel loads at nao = 208, and a slab is re-read NC + 4 NR times in
 // total instead of 5 nsplit.  Chunks are always 16 points (39 KB per LDS buffer).
@@ -1087,6 +1087,7 @@ static int launch_vxc_ws2(int maxt, int nla, int nlb, dim3 grid, size_t shmem, h
         return 0;                                                                                                     \
     }
     DQC_VW2_CASE(8, 4, 4) DQC_VW2_CASE(8, 4, 6) DQC_VW2_CASE(11, 4, 4) DQC_VW2_CASE(11, 4, 6)
+    DQC_VW2_CASE(8, 5, 4) DQC_VW2_CASE(8, 5, 6) DQC_VW2_CASE(11, 5, 4) DQC_VW2_CASE(11, 5, 6)  // 9-row rectangles (NLA = 5)
 #undef DQC_VW2_CASE
     set_error("vxc_ws2: internal dispatch error");
     return DQC_EINVAL;
@@ -1135,13 +1136,26 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         const int ttot_w = sym ? T * (T + 1) / 2 : ttot;
         if (ttot_w > 2 * 11 * VXC_WAVES && !(impl_env && impl_env[0] == 'r')) {
             // larger bases: rectangular ownership (vxc_ws2_kernel), rectangles of at most 8 x 11 tiles
-            const int NR = (T + 7) / 8, NC = (T + 10) / 11;
+            // rectangle shape: a block stages nr Phi tile columns (one component) and 4 nc AO-component tile columns for its
+            // nr x nc tiles -- (nr + 4 nc) / (nr nc) operand tile columns per MFMA: rows are cheap, columns dear.  The tallest
+            // rectangle the layout allows (9 rows: LSA <= 144), then the widest that keeps <= 11 accumulator tiles per wave:
+            // T = 27 (naphthalene / cc-pVTZ): 9 x 9 tiles, 9 blocks per slab (round 2: 7 x 9, 12 blocks); T = 17: 9 x 9 (6 x 9).
+            // DQC_WS2_NR / DQC_WS2_NC override the block counts (A/B runs).
+            int NR = (T + 8) / 9, NC = 1;
+            {
+                const int nrm = (T + NR - 1) / NR;
+                while ((T + NC - 1) / NC > 12 || nrm * ((T + NC - 1) / NC) > 11 * VXC_WAVES) NC++;
+                const char *e1 = getenv("DQC_WS2_NR"), *e2 = getenv("DQC_WS2_NC");
+                if (e1 && atoi(e1) > 0) NR = atoi(e1);
+                if (e2 && atoi(e2) > 0) NC = atoi(e2);
+            }
             const int nrmax = (T + NR - 1) / NR, ncmax = (T + NC - 1) / NC;
+            if (nrmax > 9 || ncmax > 12 || nrmax * ncmax > 11 * VXC_WAVES) { set_error("vxc_ws2: rectangle outside the kernel's limits"); return DQC_EINVAL; }
             const int need2 = (nrmax * ncmax + VXC_WAVES - 1) / VXC_WAVES;
             const int maxt2 = need2 <= 8 ? 8 : 11;
             auto pad16 = [](int w_) { return (w_ & 31) == 16 ? w_ : w_ + 16; };  // == 16 (mod 32): conflict-free fragments
             const int LSA = pad16(nrmax * 16), LSB = pad16(ncmax * 16);
-            const int nla = 4, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;
+            const int nla = nrmax <= 8 ? 4 : 5, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;  // b128 loads per producer thread and row
             const int nsplit2 = NR * NC;
             int nslab = std::max(8, (512 / nsplit2) / 8 * 8);
             int slab = (ngrid + nslab - 1) / nslab;
