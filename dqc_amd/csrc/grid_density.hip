@@ -113,8 +113,11 @@ template <int NCT, bool GGA>
 __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
                                                          const double *__restrict__ dm, int ntile,
-                                                         const double *__restrict__ aoe) {
+                                                         const double *__restrict__ aoe, int lda) {
     // aoe: array the row dots are taken with (== ao except for the "pair" form rowdot(ao . D, aoe), LDA mode only)
+    // lda: row stride of the AO arrays in HBM (dqc_ao_stride); ld = 16 ntile: rows / columns of the zero-padded D.  The K loop and
+    // the epilogue run over 16 ntile columns of an AO row: columns lda .. ld - 1 are the first doubles of the next row (the
+    // arrays carry ld - lda doubles of slack at their end), finite values that meet zero rows / columns of D
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int LSB = NCT * 16;                 // width of the staged D column panel
     constexpr int LSBP = lr_panel_stride(NCT);    // odd: the B fragments are read with permuted columns (rowdot_epilogue_paired)
@@ -125,14 +128,14 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int g0 = blockIdx.x * DEN_BM;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;
     // all global addresses are (uniform 64-bit base) + (small 32-bit lane offset)
-    const double *aoblk = ao + (size_t)g0 * ld;    // this block's 64 rows of Phi
-    const double *aoeblk = aoe + (size_t)g0 * ld;
+    const double *aoblk = ao + (size_t)g0 * lda;   // this block's 64 rows of Phi
+    const double *aoeblk = aoe + (size_t)g0 * lda;
     const int rmax = ngrid - 1 - g0;               // last valid block-local row
     // staging roles: A chunk = 64 rows x 16 doubles -> thread (row = tid/4, 4 doubles at seg = tid%4)
     const int arow = tid >> 2, aseg = (tid & 3) * 4;
-    const int aoff = min(arow, rmax) * ld + aseg;
+    const int aoff = min(arow, rmax) * lda + aseg;
 
     double p[4][GGA ? 4 : 1];
 #pragma unroll
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
         for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
     int roff[4];  // block-local element offsets of this lane's four accumulator rows
 #pragma unroll
-    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + (DEN_PAIRED ? 2 : 1) * lr;
+    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * lda + (DEN_PAIRED ? 2 : 1) * lr;
 
     const int nk = ld / DEN_KC;
     // every panel is a full one: the last panel is shifted back to end at ntile and the tiles it shares with its
@@ -265,14 +268,14 @@ static constexpr size_t density_lds_bytes() {
 
 template <bool GGA>
 static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
-                          int ngrid, int ld, const double *dm, int ntile, const double *aoe) {
+                          int ngrid, int ld, const double *dm, int ntile, const double *aoe, int lda) {
 #define DQC_DENS_CASE(N)                                                                                           \
     case N:                                                                                                        \
         if constexpr (!GGA || N <= 14) { /* GGA panels of 15 / 16 tiles would spill: never instantiated */          \
             (void)hipFuncSetAttribute((const void *)density_kernel<N, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)density_lds_bytes<N>());                                                \
             hipLaunchKernelGGL((density_kernel<N, GGA>), grid, dim3(DEN_NT), density_lds_bytes<N>(), st, rho, grho, ao, \
-                               ngrid, ld, dm, ntile, aoe);                                                          \
+                               ngrid, ld, dm, ntile, aoe, lda);                                                     \
             return 0;                                                                                              \
         }                                                                                                          \
         break;
@@ -328,7 +331,7 @@ template <int NRT, int NCT, bool GGA>
 __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                             const double *__restrict__ ao, int ngrid, int ld,
                                                             const double *__restrict__ orb,
-                                                            const double *__restrict__ orbt, int ntile) {
+                                                            const double *__restrict__ orbt, int ntile, int lda) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int RP = LrGeom<NRT>::RP, RPS = LrGeom<NRT>::RPS;
     constexpr int LSB = NCT * 16;
@@ -341,12 +344,12 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int g0 = blockIdx.x * DEN_BM;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;       // lda: row stride of the AO arrays; ld = 16 ntile (see density_kernel)
     // all global addresses are (uniform 64-bit base) + (small 32-bit lane offset): one VGPR per address
-    const double *aoblk = ao + (size_t)g0 * ld;  // this block's 64 rows of Phi
+    const double *aoblk = ao + (size_t)g0 * lda; // this block's 64 rows of Phi
     const int rmax = ngrid - 1 - g0;             // last valid block-local row
     const int arow = tid >> 2, aseg = (tid & 3) * 4;
-    const int aoff = min(arow, rmax) * ld + aseg;
+    const int aoff = min(arow, rmax) * lda + aseg;
 
     DEN_TRACE_POINT(0);
     // ---- phase 1: a1[ct][reg] = A'[pt = lr][r = 16 ct + 4 reg + lk]
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
         for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
     int roff[4];  // block-local element offsets of this lane's four accumulator rows
 #pragma unroll
-    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * ld + (DEN_PAIRED ? 2 : 1) * lr;
+    for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * lda + (DEN_PAIRED ? 2 : 1) * lr;
 
     // ---- phase 2 + epilogue, one column panel of NCT tiles at a time.  Every panel is a full one: the last panel
     // is shifted back to end at ntile and the tiles it shares with its predecessor (tile index < jnew) get zero L^T
@@ -562,20 +565,21 @@ constexpr int lr_max_nct(int nrt) { return nrt <= 3 ? 14 : (nrt <= 4 ? 12 : 10);
 
 template <int NRT, bool GGA>
 static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao, int ngrid,
-                               int ld, const double *orb, const double *orbt, int ntile) {
+                               int ld, const double *orb, const double *orbt, int ntile, int lda) {
 #define DQC_DLR_CASE(N)                                                                                          \
     case N:                                                                                                      \
         if constexpr (!GGA || N <= lr_max_nct(NRT)) { /* wider panels would spill: never instantiated */         \
             constexpr size_t shm = density_lr_lds_bytes<NRT, N>();                                               \
             auto kern = density_lr_kernel<NRT, N, GGA>;                                                          \
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-            hipLaunchKernelGGL(kern, grid, dim3(DEN_NT), shm, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);   \
+            hipLaunchKernelGGL(kern, grid, dim3(DEN_NT), shm, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda); \
             return 0;                                                                                            \
         }                                                                                                        \
         break;
-    switch (nct) {  // ld / 16 is odd; panels of a split matrix may be even
-        DQC_DLR_CASE(1) DQC_DLR_CASE(3) DQC_DLR_CASE(5) DQC_DLR_CASE(7) DQC_DLR_CASE(9) DQC_DLR_CASE(10)
-        DQC_DLR_CASE(11) DQC_DLR_CASE(12) DQC_DLR_CASE(13) DQC_DLR_CASE(14) DQC_DLR_CASE(15) DQC_DLR_CASE(16)
+    switch (nct) {
+        DQC_DLR_CASE(1) DQC_DLR_CASE(2) DQC_DLR_CASE(3) DQC_DLR_CASE(4) DQC_DLR_CASE(5) DQC_DLR_CASE(6) DQC_DLR_CASE(7)
+        DQC_DLR_CASE(8) DQC_DLR_CASE(9) DQC_DLR_CASE(10) DQC_DLR_CASE(11) DQC_DLR_CASE(12) DQC_DLR_CASE(13) DQC_DLR_CASE(14)
+        DQC_DLR_CASE(15) DQC_DLR_CASE(16)
     default:
         break;
     }
@@ -586,14 +590,14 @@ static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, 
 
 template <bool GGA>
 static int launch_density_lr(int nrt, int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
-                             int ngrid, int ld, const double *orb, const double *orbt, int ntile) {
+                             int ngrid, int ld, const double *orb, const double *orbt, int ntile, int lda) {
     switch (nrt) {
-    case 1: return launch_density_lr_n<1, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
-    case 2: return launch_density_lr_n<2, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
-    case 3: return launch_density_lr_n<3, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
-    case 4: return launch_density_lr_n<4, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
-    case 6: return launch_density_lr_n<6, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
-    case 8: return launch_density_lr_n<8, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile);
+    case 1: return launch_density_lr_n<1, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
+    case 2: return launch_density_lr_n<2, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
+    case 3: return launch_density_lr_n<3, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
+    case 4: return launch_density_lr_n<4, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
+    case 6: return launch_density_lr_n<6, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
+    case 8: return launch_density_lr_n<8, GGA>(nct, grid, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda);
     default:
         set_error("density_lr: internal factor-width dispatch error");
         return DQC_EINVAL;
@@ -611,13 +615,13 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
     if (ngrid <= 0) return DQC_OK;
     const bool gga = d_grho != nullptr;
     if (gga && ncomp < 4) { set_error("dqc_grid_density: gradient requested but ao has < 4 components"); return DQC_EINVAL; }
-    const int ld = dqc_padded_nao(nao), ntile = ld / 16;
+    const int ld = dqc_padded_nao(nao), ntile = ld / 16, lda = dqc_ao_stride(nao);
     // column panels: <= 16 tiles (LDA) / <= 14 (GGA: 15 and 16 tiles of accumulators + the epilogue's load batches spill)
     const int nchunk = (ntile + (gga ? 13 : 15)) / (gga ? 14 : 16);
     const int nct = (ntile + nchunk - 1) / nchunk;
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
-    int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao)
-                 : launch_density<false>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao);
+    int rc = gga ? launch_density<true>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao, lda)
+                 : launch_density<false>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_dm, ntile, d_ao, lda);
     if (rc) return rc;
     DQC_CHECK_LAUNCH();
     return DQC_OK;
@@ -641,15 +645,14 @@ int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int n
         set_error("dqc_grid_density_lr: norb_pad must be a value returned by dqc_padded_norb");
         return DQC_EINVAL;
     }
-    const int ld = dqc_padded_nao(nao), ntile = ld / 16;
+    const int ld = dqc_padded_nao(nao), ntile = ld / 16, lda = dqc_ao_stride(nao);
     // (narrower panels -- fewer registers and less LDS, 3 blocks per CU instead of 2 -- change nothing: 0.57 ms for 5, 7, 9 or 13 tiles)
     const int lim = gga ? dqc::lr_max_nct(norb_pad / 16) : 16;
     const int nchunk = (ntile + lim - 1) / lim;
-    int nct = (ntile + nchunk - 1) / nchunk;
-    if (nct < 9 && (nct & 1) == 0) nct++;  // instantiated panel widths
+    const int nct = (ntile + nchunk - 1) / nchunk;
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
-    int rc = gga ? launch_density_lr<true>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile)
-                 : launch_density_lr<false>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile);
+    int rc = gga ? launch_density_lr<true>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda)
+                 : launch_density_lr<false>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda);
     if (rc) return rc;
     DQC_CHECK_LAUNCH();
     return DQC_OK;
@@ -660,11 +663,11 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     if (ngrid <= 0) return DQC_OK;
-    const int ld = dqc_padded_nao(nao), ntile = ld / 16;
+    const int ld = dqc_padded_nao(nao), ntile = ld / 16, lda = dqc_ao_stride(nao);
     const int nchunk = (ntile + 15) / 16;
     const int nct = (ntile + nchunk - 1) / nchunk;
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
-    int rc = launch_density<false>(nct, grid, st, d_out, nullptr, d_ao_a, ngrid, ld, d_dm, ntile, d_ao_b);
+    int rc = launch_density<false>(nct, grid, st, d_out, nullptr, d_ao_a, ngrid, ld, d_dm, ntile, d_ao_b, lda);
     if (rc) return rc;
     DQC_CHECK_LAUNCH();
     return DQC_OK;

@@ -38,15 +38,17 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
                                                      int ngrid, int ld, const double *__restrict__ w,
                                                      const double *__restrict__ vrho, const double *__restrict__ vgrad,
                                                      int slab, int nsplit, int tiles_per_split,
-                                                     const double *__restrict__ aob) {
+                                                     const double *__restrict__ aob, int lda, int LS) {
     // aob: LDA mode only -- array the Psi operand is built from (== ao except for the "pair" form ao^T diag(w v) aob)
+    // lda: row stride of the AO arrays in HBM (dqc_ao_stride); ld = 16 T: the tile-padded width that is staged (columns
+    // lda .. ld - 1 of a row are the first doubles of the next row: finite values that only reach discarded rows / columns
+    // of M); LS: LDS row stride, == 16 (mod 32) so that the fragment reads are conflict-free
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int LS = ld;  // ld == 16 (mod 32): conflict-free fragment reads without extra padding
     const int BUF = 2 * KCH * LS;  // phi + psi
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lr = lane & 15, lk = lane >> 4;
     const int T = ld >> 4, ttot = T * T;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;
 
     // XCD-aware decode: the nsplit blocks that share a slab get ids 8 apart -> same XCD, dispatched together
     const int id = blockIdx.x;
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(512, 2) void vxc_kernel(double *__restrict__ vmat, 
 #pragma unroll
             for (int d = 0; d < 3; d++) cf[d + 1] = vgrad[(size_t)d * ngrid + gg];
         }
-        src = ao + (size_t)gg * ld;
-        srcb = aob + (size_t)gg * ld;
+        src = ao + (size_t)gg * lda;
+        srcb = aob + (size_t)gg * lda;
     };
     auto prefetch_cols = [&](int part) {
 #pragma unroll
@@ -232,50 +234,105 @@ constexpr int WS2_BUF = WS2_XS + 4 * WS2_GSB;             // doubles per buffer 
 #ifndef WS_D
 #define WS_D 2
 #endif
-template <int MAXT, int KCH, int D = WS_D, int GSA = VWS_GS, int GSB = VWS_GS>
+template <int MAXT, int KCH, int D = WS_D, int GSA = VWS_GS, int GSB = VWS_GS, int NTL = MAXT>
 __device__ __forceinline__ void ws_chunk(const unsigned (&pa)[MAXT], const unsigned (&pb)[MAXT], v4d (&acc)[MAXT]) {
-    constexpr int NS = (KCH / 4) * MAXT;
-    double fa[D + 1], fb[D + 1];
+    // NTL <= MAXT: the tiles this wave really owns (no dummy MFMAs: the deal below gives the waves of a block tile counts
+    // that differ by at most one, and every count has its own straight-line body)
+    constexpr int NS = (KCH / 4) * NTL;
+    if constexpr (NTL > 0) {
+        double fa[D + 1], fb[D + 1];
 #pragma unroll
-    for (int s = 0; s < D && s < NS; s++) {
-        fa[s % (D + 1)] = *(lds_cdouble_t *)(pa[s % MAXT] + (s / MAXT) * GSA * 8);
-        fb[s % (D + 1)] = *(lds_cdouble_t *)(pb[s % MAXT] + (s / MAXT) * GSB * 8);
-    }
-#pragma unroll
-    for (int s = 0; s < NS; s++) {  // tiles past the wave's count are clamped duplicates, discarded later
-        if (s + D < NS) {
-            const int s2 = s + D;
-            fa[s2 % (D + 1)] = *(lds_cdouble_t *)(pa[s2 % MAXT] + (s2 / MAXT) * GSA * 8);
-            fb[s2 % (D + 1)] = *(lds_cdouble_t *)(pb[s2 % MAXT] + (s2 / MAXT) * GSB * 8);
+        for (int s = 0; s < D && s < NS; s++) {
+            fa[s % (D + 1)] = *(lds_cdouble_t *)(pa[s % NTL] + (s / NTL) * GSA * 8);
+            fb[s % (D + 1)] = *(lds_cdouble_t *)(pb[s % NTL] + (s / NTL) * GSB * 8);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[s % MAXT] = mfma_f64(fa[s % (D + 1)], fb[s % (D + 1)], acc[s % MAXT]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-#ifdef ABL_VWS_NO_LDSREAD
-template <int MAXT, int KCH>
-__device__ __forceinline__ void ws_chunk_nolds(double a, double b, v4d (&acc)[MAXT]) {
 #pragma unroll
-    for (int s = 0; s < (KCH / 4) * MAXT; s++) {
-        acc[s % MAXT] = mfma_f64(a, b, acc[s % MAXT]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < NS; s++) {
+            if (s + D < NS) {
+                const int s2 = s + D;
+                fa[s2 % (D + 1)] = *(lds_cdouble_t *)(pa[s2 % NTL] + (s2 / NTL) * GSA * 8);
+                fb[s2 % (D + 1)] = *(lds_cdouble_t *)(pb[s2 % NTL] + (s2 / NTL) * GSB * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[s % NTL] = mfma_f64(fa[s % (D + 1)], fb[s % (D + 1)], acc[s % NTL]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
-#endif
+// A consumer wave of vxc_ws_kernel / vxc_ws2_kernel with NTL tiles (compile time: the accumulators, the fragment addresses and
+// the straight-line MFMA stream are sized for exactly the tiles the wave owns).  Tile u = t0 + t of the block's list maps to
+// local tile coordinates (li, lj) -- LDS columns 16 li of the A part, 16 lj of the B part -- and to the output tile
+// (r0 + li, c0 + lj):  nc > 0: rectangle, (u / nc, u % nc);  nc == 0, sym == 0: (u / T, u % T);  sym: upper triangle of T rows.
+struct WsTiles { int sym, T, nc, r0, c0, t0; };
+__device__ __forceinline__ void ws_tile(const WsTiles &m, int u, int &li, int &lj) {
+    if (m.nc) { li = u / m.nc; lj = u - li * m.nc; return; }
+    if (!m.sym) { li = u / m.T; lj = u - li * m.T; return; }
+    int i = 0, rem = u;
+    while (rem >= m.T - i) { rem -= m.T - i; i++; }  // row i of the upper triangle holds T - i tiles
+    li = i;
+    lj = i + rem;
+}
+template <int NTL, int KCH, int D, int GSA, int GSB, int XS, int BUF>
+__device__ __forceinline__ void ws_consumer(double *lds, double *__restrict__ vmat, int ld, int nchunk, const WsTiles m, int LSA, int LSB) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    constexpr int NA = NTL > 0 ? NTL : 1;
+    v4d acc[NA];
+    unsigned pa[NA], pb[NA];  // LDS byte addresses of the A / B fragments (k-group 0, current buffer)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
+#pragma unroll
+    for (int t = 0; t < NTL; t++) {
+        acc[t] = v4d{0, 0, 0, 0};
+        int li, lj;
+        ws_tile(m, m.t0 + t, li, lj);
+        pa[t] = lds0 + 8u * (unsigned)(lk * LSA + li * 16 + lr);
+        pb[t] = lds0 + 8u * (unsigned)(XS + lk * LSB + lj * 16 + lr);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
+        __syncthreads();  // ... and closes
+        if constexpr (NTL > 0) {
+            ws_chunk<NA, KCH, D, GSA, GSB, NTL>(pa, pb, acc);
+            const unsigned delta = (c & 1) ? (unsigned)(-BUF * 8) : (unsigned)(BUF * 8);  // on to the other buffer
+#pragma unroll
+            for (int t = 0; t < NTL; t++) { pa[t] += delta; pb[t] += delta; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTL; t++) {
+        int li, lj;
+        ws_tile(m, m.t0 + t, li, lj);
+        const int ia = (m.r0 + li) * 16 + lk, ib = (m.c0 + lj) * 16 + lr;
+        const double sc = (m.sym && li != lj) ? 2.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r], g_vxc_det_scale);
+    }
+}
+// dispatch on the (wave-uniform) tile count nt in [0, MAXT]
+template <int MAXT, int KCH, int D, int GSA, int GSB, int XS, int BUF, int N = MAXT>
+__device__ __forceinline__ void ws_consumer_n(int nt, double *lds, double *__restrict__ vmat, int ld, int nchunk, const WsTiles m,
+                                              int LSA, int LSB) {
+    if (nt == N) ws_consumer<N, KCH, D, GSA, GSB, XS, BUF>(lds, vmat, ld, nchunk, m, LSA, LSB);
+    else if constexpr (N > 0) ws_consumer_n<MAXT, KCH, D, GSA, GSB, XS, BUF, N - 1>(nt, lds, vmat, ld, nchunk, m, LSA, LSB);
+}
+// balanced deal of `n` tiles to the 8 consumer waves: counts differ by at most one (waves w and w + 4 share a SIMD)
+__device__ __forceinline__ void ws_deal(int n, int wave, int &t0, int &nt) {
+    const int tbase = n / VXC_WAVES, trem = n % VXC_WAVES;
+    nt = tbase + (wave < trem ? 1 : 0);
+    t0 = wave * tbase + min(wave, trem);
+}
 
 template <int MAXT, int NLP, int KCH, bool GGA>
 __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__restrict__ vmat, const double *__restrict__ ao,
                                                           int ngrid, int ld, const double *__restrict__ w,
                                                           const double *__restrict__ vrho,
                                                           const double *__restrict__ vgrad, int slab, int nsplit,
-                                                          int tiles_per_split, const double *__restrict__ aob, int sym) {
+                                                          int tiles_per_split, const double *__restrict__ aob, int sym, int lda, int LS) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     static_assert(KCH == 16, "the fixed-stride chunk layout is laid out for 16-point chunks");
-    const int LS = ld;
-    constexpr int BUF = VWS_BUF;
+    constexpr int BUF = VWS_BUF;  // (lda / ld / LS: see vxc_kernel)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;
     const int id = blockIdx.x;
     const int grp = id / (8 * nsplit), rem = id - grp * 8 * nsplit;
     const int split = rem / 8, sl = grp * 8 + (rem & 7);
@@ -297,7 +354,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
         constexpr int TPR = VWS_PROD / KCH;  // threads per chunk row
         const int pt = tid - 512;
         const int prow = pt / TPR, pcol = pt % TPR;
-        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);  // bytes from the chunk's first row
+        const unsigned voff0 = 8u * (unsigned)(prow * lda + pcol * 2);  // bytes from the chunk's first row
         unsigned wlds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds +
                         8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);  // Phi slot in buffer 0
         typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -326,16 +383,16 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
                     cf[d + 1] = as_d(xg[0], xg[1]);
                 }
             }
-            const size_t nb = (size_t)rows * ld * 8;     // < 2^31: a slab is a few MB
+            const size_t nb = (size_t)rows * lda * 8;    // < 2^31: a slab is a few MB
 #pragma unroll
             for (int d = 0; d < (GGA ? 4 : 1); d++) {
-                const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
+                const auto r = rsrc(ao + d * cs + (size_t)g0 * lda, nb);
 #pragma unroll
                 for (int i = 0; i < NLP; i++)
                     if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
             }
             if (!GGA && !sym) {  // (sym: the second operand is the first)
-                const auto r = rsrc(aob + (size_t)g0 * ld, nb);
+                const auto r = rsrc(aob + (size_t)g0 * lda, nb);
 #pragma unroll
                 for (int i = 0; i < NLP; i++)
                     if ((pcol + i * TPR) * 2 < ld) raw[i][1] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
@@ -371,90 +428,25 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
         if (wave == VXC_WAVES) VXC_TRACE_POINT(1, 0);
         for (int c = 0; c < nchunk; c++) {
             wlds += (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // buffer (c + 1) & 1
-#ifndef VWS_ONE_BARRIER
             __syncthreads();  // the consumers have finished chunk c - 1 and wait: the vector ALUs are free for the combine
-#endif
-#ifndef ABL_VWS_NO_PROD
             if (c + 1 < nchunk) stage();              // chunk c + 1: its loads were issued a whole period ago
-#endif
-#ifndef VWS_ONE_BARRIER
             if (wave == VXC_WAVES) VXC_TRACE_POINT(1, c + 1);  // combine done
             __syncthreads();  // the consumers start the MFMAs of chunk c
-#endif
-#ifndef ABL_VWS_NO_PROD
             if (c + 2 < nchunk) prefetch(c + 2);      // VALU-free issue, in flight during the MFMAs
-#endif
-#ifdef VWS_ONE_BARRIER
-            if (wave == VXC_WAVES) VXC_TRACE_POINT(1, c + 1);
-            __syncthreads();
-#endif
         }
         return;
     }
 
     // ---------------------------------------------------------------------- consumers
-    const int lr = lane & 15, lk = lane >> 4;
     // sym: A^T diag(w v) A with ONE operand (LDA Vxc, the tau terms of a meta-GGA) is symmetric -- only the tiles (i <= j) are
     // computed, off-diagonal ones doubled so that the final (M + M^T) / 2 restores both halves
     const int T = ld >> 4, ttot = sym ? T * (T + 1) / 2 : T * T;
-    auto tile_ij = [&](int u, int &ti, int &tj) {
-        if (!sym) { ti = u / T; tj = u - ti * T; return; }
-        int i = 0, rem = u;
-        while (rem >= T - i) { rem -= T - i; i++; }  // row i of the upper triangle holds T - i tiles
-        ti = i;
-        tj = i + rem;
-    };
     const int tc0 = split * tiles_per_split;
     const int tc1 = min(tc0 + tiles_per_split, ttot);
-    const int per_wave = (tc1 - tc0 + VXC_WAVES - 1) / VXC_WAVES;
-    const int t0 = tc0 + wave * per_wave;
-    const int nt = max(0, min(per_wave, tc1 - t0));
-    v4d acc[MAXT];
-    unsigned pa[MAXT], pb[MAXT];  // LDS byte addresses of the A / B fragments (k-group 0, current buffer)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds;
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        acc[t] = v4d{0, 0, 0, 0};
-        int ti, tj;
-        tile_ij(min(t0 + t, ttot - 1), ti, tj);
-        pa[t] = lds0 + 8u * (unsigned)(lk * LS + ti * 16 + lr);
-        pb[t] = lds0 + 8u * (unsigned)(VWS_XS + lk * LS + tj * 16 + lr);
-    }
-    __syncthreads();
-    if (wave == 0) VXC_TRACE_POINT(0, 0);
-    for (int c = 0; c < nchunk; c++) {
-#ifndef VWS_ONE_BARRIER
-        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
-        __syncthreads();  // ... and closes
-#endif
-#ifdef ABL_VWS_NO_LDSREAD
-        ws_chunk_nolds<MAXT, KCH>(1e-3 * lane, 2e-3 * lr, acc);
-#elif !defined(ABL_VWS_NO_MFMA)
-        ws_chunk<MAXT, KCH>(pa, pb, acc);
-#endif
-        const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);  // on to the other buffer
-#pragma unroll
-        for (int t = 0; t < MAXT; t++) { pa[t] += delta; pb[t] += delta; }
-        if (wave == 0) VXC_TRACE_POINT(0, c + 1);  // MFMAs of this chunk issued
-#ifdef VWS_ONE_BARRIER
-        __syncthreads();
-#endif
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        if (t < nt) {
-            int ti, tj;
-            tile_ij(t0 + t, ti, tj);
-            const int ia = ti * 16 + lk, ib = tj * 16 + lr;
-            const double sc = (sym && ti != tj) ? 2.0 : 1.0;
-#pragma unroll
-#ifndef ABL_VWS_NO_EPI
-            for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], sc * acc[t][r], g_vxc_det_scale);
-#else
-            for (int r = 0; r < 4; r++) if (acc[t][r] == 1.2345) vmat[0] = 1.0;
-#endif
-        }
-    }
+    int t0, nt;
+    ws_deal(tc1 - tc0, wave, t0, nt);
+    const WsTiles m{sym, T, 0, 0, 0, tc0 + t0};
+    ws_consumer_n<MAXT, KCH, WS_D, VWS_GS, VWS_GS, VWS_XS, VWS_BUF>(nt, lds, vmat, ld, nchunk, m, LS, LS);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,14 +463,14 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
                                                            int ngrid, int ld, const double *__restrict__ w,
                                                            const double *__restrict__ vrho,
                                                            const double *__restrict__ vgrad, int slab, int NR, int NC,
-                                                           int LSA, int LSB, const double *__restrict__ aob) {
+                                                           int LSA, int LSB, const double *__restrict__ aob, int lda) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int KCH = 16;
     // chunk layout as in vxc_ws_kernel: fixed strides between the 4-point k-groups (Phi part: WS2_GSA, Psi part: WS2_GSB), so that
     // the consumers' fragment reads are  address register + immediate;  rows inside a k-group at the run-time strides LSA / LSB
     constexpr int BUF = WS2_BUF;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;
     const int T = ld >> 4, nsplit = NR * NC;
     const int id = blockIdx.x;
     const int grp = id / (8 * nsplit), rem = id - grp * 8 * nsplit;
@@ -499,7 +491,7 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
         const int pt = tid - 512;
         const int prow = pt / TPR, pcol = pt % TPR;
         const int wa = nr * 16, wb = nc * 16;  // staged widths (doubles)
-        const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+        const unsigned voff0 = 8u * (unsigned)(prow * lda + pcol * 2);
         unsigned wla = lds0 + 8u * (unsigned)((prow >> 2) * WS2_GSA + (prow & 3) * LSA + pcol * 2);
         unsigned wlb = lds0 + 8u * (unsigned)(WS2_XS + (prow >> 2) * WS2_GSB + (prow & 3) * LSB + pcol * 2);
         typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -527,16 +519,16 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
                 }
             }
             // bytes from the rectangle's first column of row g0 to the end of the slab (the loads of a row stop at its staged width)
-            const size_t nba = (size_t)rows * ld * 8 - (size_t)r0 * 128, nbb = (size_t)rows * ld * 8 - (size_t)c0 * 128;
+            const size_t nba = (size_t)rows * lda * 8 - (size_t)r0 * 128, nbb = (size_t)rows * lda * 8 - (size_t)c0 * 128;
             {
-                const auto r = rsrc(ao + (size_t)g0 * ld + r0 * 16, nba);
+                const auto r = rsrc(ao + (size_t)g0 * lda + r0 * 16, nba);
 #pragma unroll
                 for (int i = 0; i < NLA; i++)
                     if ((pcol + i * TPR) * 2 < wa) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
             }
 #pragma unroll
             for (int d = 0; d < (GGA ? 4 : 1); d++) {
-                const auto r = rsrc((GGA ? ao : aob) + d * cs + (size_t)g0 * ld + c0 * 16, nbb);
+                const auto r = rsrc((GGA ? ao : aob) + d * cs + (size_t)g0 * lda + c0 * 16, nbb);
 #pragma unroll
                 for (int i = 0; i < NLB; i++)
                     if ((pcol + i * TPR) * 2 < wb) rb[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
@@ -583,38 +575,10 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     }
 
     // ---------------------------------------------------------------------- consumers
-    const int lr = lane & 15, lk = lane >> 4;
-    const int ttot = nr * nc;
-    const int per_wave = (ttot + VXC_WAVES - 1) / VXC_WAVES;
-    const int t0 = wave * per_wave;
-    const int nt = max(0, min(per_wave, ttot - t0));
-    v4d acc[MAXT];
-    unsigned pa[MAXT], pb[MAXT];  // LDS byte addresses of the A / B fragments (k-group 0, current buffer)
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        acc[t] = v4d{0, 0, 0, 0};
-        const int tl = min(t0 + t, ttot - 1);
-        pa[t] = lds0 + 8u * (unsigned)(lk * LSA + (tl / nc) * 16 + lr);
-        pb[t] = lds0 + 8u * (unsigned)(WS2_XS + lk * LSB + (tl % nc) * 16 + lr);
-    }
-    __syncthreads();
-    for (int c = 0; c < nchunk; c++) {
-        __syncthreads();  // chunk c - 1 done: the producers' combine window opens ...
-        __syncthreads();  // ... and closes
-        ws_chunk<MAXT, KCH, 4, WS2_GSA, WS2_GSB>(pa, pb, acc);
-        const unsigned delta = (c & 1) ? (unsigned)(-BUF * 8) : (unsigned)(BUF * 8);
-#pragma unroll
-        for (int t = 0; t < MAXT; t++) { pa[t] += delta; pb[t] += delta; }
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; t++) {
-        if (t < nt) {
-            const int tl = t0 + t;
-            const int ia = (r0 + tl / nc) * 16 + lk, ib = (c0 + tl % nc) * 16 + lr;
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * ld + ib], acc[t][r], g_vxc_det_scale);
-        }
-    }
+    int t0, nt;
+    ws_deal(nr * nc, wave, t0, nt);
+    const WsTiles m{0, T, nc, r0, c0, t0};
+    ws_consumer_n<MAXT, KCH, 4, WS2_GSA, WS2_GSB, WS2_XS, WS2_BUF>(nt, lds, vmat, ld, nchunk, m, LSA, LSB);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,22 +628,31 @@ __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsi
     }
 }
 
+// the same with a (wave-uniform) run-time tile count in [0, MAXT]: one straight-line body per count, no dummy MFMAs
+template <int MAXT, bool TWO, int N = MAXT>
+__device__ __forceinline__ void wsu_chunk_n(int nt, const unsigned (&pi)[MAXT], const unsigned (&pj)[MAXT], v4d (&acc)[MAXT]) {
+    if constexpr (N == 0) return;
+    else if (nt == N) wsu_chunk<MAXT, N, TWO>(pi, pj, acc);
+    else wsu_chunk_n<MAXT, TWO, N - 1>(nt, pi, pj, acc);
+}
+
 // the 4 producer waves of vxc_wsu_kernel / vxc_wsb_kernel (threads 512 .. 767): chunk c + 2 travels HBM -> registers while the
 // consumers run the MFMAs of chunk c; chunk c + 1 is combined into (Phi, Psi) and written to LDS in the window between chunks
 template <int NLP, bool GGA>
 DQC_DEV void vwu_producer(double *lds, const double *__restrict__ ao, int ngrid, int ld, const double *__restrict__ w,
-                          const double *__restrict__ vrho, const double *__restrict__ vgrad, int gs, int ge, int nchunk) {
+                          const double *__restrict__ vrho, const double *__restrict__ vgrad, int gs, int ge, int nchunk,
+                          int lda, int LS) {
+    // lda: row stride of the AO arrays in HBM; ld = 16 T: staged width; LS: LDS row stride (see vxc_kernel)
     constexpr int KCH = 16;
-    const int LS = ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     (void)wave; (void)lane;
-    const size_t cs = (size_t)ngrid * ld;
+    const size_t cs = (size_t)ngrid * lda;
     // ------------------------------------------------------------------ producers (see vxc_ws_kernel)
     __builtin_amdgcn_s_setprio(3);
     constexpr int TPR = VWU_PROD / KCH;  // 16 threads per chunk row
     const int pt = tid - 512;
     const int prow = pt / TPR, pcol = pt % TPR;
-    const unsigned voff0 = 8u * (unsigned)(prow * ld + pcol * 2);
+    const unsigned voff0 = 8u * (unsigned)(prow * lda + pcol * 2);
     unsigned wlds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)lds +
                     8u * (unsigned)((prow >> 2) * VWS_GS + (prow & 3) * LS + pcol * 2);
     typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -706,10 +679,10 @@ DQC_DEV void vwu_producer(double *lds, const double *__restrict__ ao, int ngrid,
                 cf[d + 1] = as_d(xg[0], xg[1]);
             }
         }
-        const size_t nb = (size_t)rows * ld * 8;
+        const size_t nb = (size_t)rows * lda * 8;
 #pragma unroll
         for (int d = 0; d < (GGA ? 4 : 1); d++) {
-            const auto r = rsrc(ao + d * cs + (size_t)g0 * ld, nb);
+            const auto r = rsrc(ao + d * cs + (size_t)g0 * lda, nb);
 #pragma unroll
             for (int i = 0; i < NLP; i++)
                 if ((pcol + i * TPR) * 2 < ld) raw[i][d] = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + i * TPR * 16, 0, 0);
@@ -769,18 +742,16 @@ DQC_DEV void vwu_producer(double *lds, const double *__restrict__ ao, int ngrid,
 template <int MAXT, int NLP, bool GGA>
 __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
                                                            int ld, const double *__restrict__ w, const double *__restrict__ vrho,
-                                                           const double *__restrict__ vgrad, int slab) {
+                                                           const double *__restrict__ vgrad, int slab, int lda, int LS) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int KCH = 16;
-    const int LS = ld;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const size_t cs = (size_t)ngrid * ld;
     const int gs = blockIdx.x * slab, ge = min(gs + slab, ngrid);
     if (gs >= ngrid) return;
     const int nchunk = (ge - gs + KCH - 1) / KCH;
 
     if (wave >= VXC_WAVES) {
-        vwu_producer<NLP, GGA>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk);
+        vwu_producer<NLP, GGA>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk, lda, LS);
         return;
     }
 
@@ -820,8 +791,7 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
         VWU_STAMP(0, 4 * c + 1);
 #endif
 #ifndef VWU_EXP_NOMFMA
-        if (nt == MAXT) wsu_chunk<MAXT, MAXT, GGA>(pi, pj, acc);
-        else wsu_chunk<MAXT, MAXT - 1, GGA>(pi, pj, acc);
+        wsu_chunk_n<MAXT, GGA>(nt, pi, pj, acc);
 #endif
         const unsigned delta = (c & 1) ? (unsigned)(-VWS_BUF * 8) : (unsigned)(VWS_BUF * 8);
 #pragma unroll
@@ -857,6 +827,8 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsu_kernel(double *__restrict__
 // Measured (C5 shape, random data): 0.691 ms against 0.725 ms.  Not pursued: sharing fragment reads between the tiles of a
 // row -- a build that issues a quarter of the ds_read_b64 (wrong results, timing only) is just 3-5 % faster.
 // ---------------------------------------------------------------------------------------------
+constexpr int wsd_ls(int T) { return ((16 * T) & 31) == 16 ? 16 * T : 16 * T + 16; }
+
 template <int T>
 struct WsdDeal {
     int no[VXC_WAVES], nd[VXC_WAVES], o0[VXC_WAVES], d0[VXC_WAVES];
@@ -913,7 +885,7 @@ DQC_DEV void wsd_chunk(const unsigned (&pi)[NO + ND], const unsigned (&pj)[NO + 
 
 template <int T, int NO, int ND>
 DQC_DEV void wsd_consumer(double *lds, double *__restrict__ vmat, int nchunk, int o0, int d0) {
-    constexpr int NT = NO + ND, LS = 16 * T;
+    constexpr int NT = NO + ND, LS = wsd_ls(T);  // rows of the output matrix: 16 T; LDS rows: == 16 (mod 32)
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     auto tile_ij = [&](int t, int &ti, int &tj) {
         if (t >= NO) { ti = tj = d0 + (t - NO); return; }
@@ -949,14 +921,14 @@ DQC_DEV void wsd_consumer(double *lds, double *__restrict__ vmat, int nchunk, in
         tile_ij(t, ti, tj);
         const int ia = ti * 16 + lk, ib = tj * 16 + lr;
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * LS + ib], acc[t][r], g_vxc_det_scale);
+        for (int r = 0; r < 4; r++) acc_add(&vmat[(size_t)(ia + 4 * r) * (16 * T) + ib], acc[t][r], g_vxc_det_scale);
     }
 }
 
 template <int T, int NLP>
 __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__ vmat, const double *__restrict__ ao, int ngrid,
                                                            const double *__restrict__ w, const double *__restrict__ vrho,
-                                                           const double *__restrict__ vgrad, int slab) {
+                                                           const double *__restrict__ vgrad, int slab, int lda) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int KCH = 16, ld = 16 * T;
     constexpr WsdDeal<T> DL{};
@@ -966,7 +938,7 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__
     if (gs >= ngrid) return;
     const int nchunk = (ge - gs + KCH - 1) / KCH;
     if (wave >= VXC_WAVES) {
-        vwu_producer<NLP, true>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk);
+        vwu_producer<NLP, true>(lds, ao, ngrid, ld, w, vrho, vgrad, gs, ge, nchunk, lda, wsd_ls(T));
         return;
     }
 #define DQC_WSD_CASE(W) case W: wsd_consumer<T, DL.no[W], DL.nd[W]>(lds, vmat, nchunk, DL.o0[W], DL.d0[W]); break;
@@ -981,16 +953,20 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__
 #include "grid_fused.inc"
 #endif
 
-// V = (M + M^T) / 2 on the zero-padded (ld, ld) matrix (deterministic mode: M arrives as fixed-point integers)
-__global__ void symmetrize_kernel(double *m, int ld) {
+// V = (M + M^T) / 2 on the (ld, ld) matrix (deterministic mode: M arrives as fixed-point integers).  Rows / columns nao .. ld - 1
+// are ZEROED: the kernels stage 16 T columns per AO row, and where the row stride of the AO arrays is below that
+// (dqc_ao_stride) the last tile's extra columns hold the first values of the next row -- finite numbers that only reach
+// these padding rows / columns
+__global__ void symmetrize_kernel(double *m, int ld, int nao) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
     const double sc = g_vxc_det_scale;
     if (i < ld && j < i) {
-        const double v = 0.5 * (det_value(m[(size_t)i * ld + j], sc) + det_value(m[(size_t)j * ld + i], sc));
+        const double v = i < nao ? 0.5 * (det_value(m[(size_t)i * ld + j], sc) + det_value(m[(size_t)j * ld + i], sc)) : 0.0;
         m[(size_t)i * ld + j] = v;
         m[(size_t)j * ld + i] = v;
-    } else if (i < ld && j == i && sc != 0.0) {
-        m[(size_t)i * ld + i] = det_value(m[(size_t)i * ld + i], sc);
+    } else if (i < ld && j == i) {
+        if (i >= nao) m[(size_t)i * ld + i] = 0.0;
+        else if (sc != 0.0) m[(size_t)i * ld + i] = det_value(m[(size_t)i * ld + i], sc);
     }
 }
 
@@ -1011,29 +987,29 @@ static int sync_vxc_det_scale() {
 template <int MAXT, int NL, int KCH, bool GGA>
 static void launch_vxc_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                             const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps,
-                            const double *aob) {
+                            const double *aob, int lda, int LS) {
     (void)hipFuncSetAttribute((const void *)vxc_kernel<MAXT, NL, KCH, GGA>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)shmem);
     hipLaunchKernelGGL((vxc_kernel<MAXT, NL, KCH, GGA>), grid, dim3(512), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab,
-                       nsplit, tps, aob);
+                       nsplit, tps, aob, lda, LS);
 }
 
 template <int MAXT, int NLP, int KCH, bool GGA>
 static void launch_vxc_ws_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                                const double *w, const double *vrho, const double *vgrad, int slab, int nsplit, int tps,
-                               const double *aob, int sym) {
+                               const double *aob, int sym, int lda, int LS) {
     auto kern = vxc_ws_kernel<MAXT, NLP, KCH, GGA>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym);
+    hipLaunchKernelGGL(kern, grid, dim3(VWS_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym, lda, LS);
 }
 
 template <bool GGA>
 static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat,
                          const double *ao, int ngrid, int ld, const double *w, const double *vrho, const double *vgrad,
-                         int slab, int nsplit, int tps, const double *aob, int sym) {
+                         int slab, int nsplit, int tps, const double *aob, int sym, int lda, int LS) {
 #define DQC_VWS_CASE(N, L)                                                                                          \
     if (maxt == N && nlp == L && kch == 16) {                                                                       \
-        launch_vxc_ws_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym); \
+        launch_vxc_ws_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, sym, lda, LS); \
         return 0;                                                                                                   \
     }
     DQC_VWS_CASE(2, 1) DQC_VWS_CASE(4, 1) DQC_VWS_CASE(6, 1) DQC_VWS_CASE(8, 1) DQC_VWS_CASE(11, 1)
@@ -1046,44 +1022,44 @@ static int launch_vxc_ws(int maxt, int nlp, int kch, dim3 grid, size_t shmem, hi
 
 template <int MAXT, int NLP, bool GGA>
 static void launch_vxc_wsu_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
-                                const double *w, const double *vrho, const double *vgrad, int slab) {
+                                const double *w, const double *vrho, const double *vgrad, int slab, int lda, int LS) {
     auto kern = vxc_wsu_kernel<MAXT, NLP, GGA>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
+    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, lda, LS);
 }
 
 template <int T>
 static void launch_vxc_wsd(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, const double *w,
-                           const double *vrho, const double *vgrad, int slab) {
+                           const double *vrho, const double *vgrad, int slab, int lda) {
     auto kern = vxc_wsd_kernel<T, 7>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, w, vrho, vgrad, slab);
+    hipLaunchKernelGGL(kern, grid, dim3(VWU_NT), shmem, st, vmat, ao, ngrid, w, vrho, vgrad, slab, lda);
 }
 
 template <bool GGA>
 static int launch_vxc_wsu(int maxt, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
-                          const double *w, const double *vrho, const double *vgrad, int slab) {
-    if (maxt <= 9) launch_vxc_wsu_inst<9, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
-    else launch_vxc_wsu_inst<12, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab);
+                          const double *w, const double *vrho, const double *vgrad, int slab, int lda, int LS) {
+    if (maxt <= 9) launch_vxc_wsu_inst<9, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, lda, LS);
+    else launch_vxc_wsu_inst<12, 7, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, lda, LS);
     return 0;
 }
 
 template <int MAXT, int NLA, int NLB, bool GGA>
 static void launch_vxc_ws2_inst(dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao, int ngrid, int ld,
                                 const double *w, const double *vrho, const double *vgrad, int slab, int NR, int NC, int LSA,
-                                int LSB, const double *aob) {
+                                int LSB, const double *aob, int lda) {
     auto kern = vxc_ws2_kernel<MAXT, NLA, NLB, GGA>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    hipLaunchKernelGGL(kern, grid, dim3(VWS2_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob);
+    hipLaunchKernelGGL(kern, grid, dim3(VWS2_NT), shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob, lda);
 }
 
 template <bool GGA>
 static int launch_vxc_ws2(int maxt, int nla, int nlb, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                           int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int NR,
-                          int NC, int LSA, int LSB, const double *aob) {
+                          int NC, int LSA, int LSB, const double *aob, int lda) {
 #define DQC_VW2_CASE(N, A, B)                                                                                        \
     if (maxt == N && nla == A && nlb == B) {                                                                          \
-        launch_vxc_ws2_inst<N, A, B, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob); \
+        launch_vxc_ws2_inst<N, A, B, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, NR, NC, LSA, LSB, aob, lda); \
         return 0;                                                                                                     \
     }
     DQC_VW2_CASE(8, 4, 4) DQC_VW2_CASE(8, 4, 6) DQC_VW2_CASE(11, 4, 4) DQC_VW2_CASE(11, 4, 6)
@@ -1096,20 +1072,20 @@ static int launch_vxc_ws2(int maxt, int nla, int nlb, dim3 grid, size_t shmem, h
 template <bool GGA>
 static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStream_t st, double *vmat, const double *ao,
                       int ngrid, int ld, const double *w, const double *vrho, const double *vgrad, int slab, int nsplit,
-                      int tps, const double *aob) {
+                      int tps, const double *aob, int lda, int LS) {
 #define DQC_VXC_CASE(N, L)                                                                                        \
     if (maxt == N && nl == L && kch == 16) {                                                                      \
-        launch_vxc_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);  \
+        launch_vxc_inst<N, L, 16, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, lda, LS);  \
         return 0;                                                                                                 \
     }                                                                                                             \
     if (maxt == N && nl == L && kch == 8) {                                                                       \
-        launch_vxc_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob);   \
+        launch_vxc_inst<N, L, 8, GGA>(grid, shmem, st, vmat, ao, ngrid, ld, w, vrho, vgrad, slab, nsplit, tps, aob, lda, LS);   \
         return 0;                                                                                                 \
     }
     DQC_VXC_CASE(2, 1) DQC_VXC_CASE(4, 1) DQC_VXC_CASE(8, 1) DQC_VXC_CASE(11, 1)
     DQC_VXC_CASE(2, 2) DQC_VXC_CASE(4, 2) DQC_VXC_CASE(8, 2) DQC_VXC_CASE(11, 2)
     DQC_VXC_CASE(2, 4) DQC_VXC_CASE(4, 4) DQC_VXC_CASE(8, 4) DQC_VXC_CASE(11, 4)
-#undef DQC_VXC_CASE  // (this kernel only sees ld <= 208: wider bases take vxc_ws2_kernel)
+#undef DQC_VXC_CASE  // (this kernel only sees ld <= 256: wider bases take vxc_ws2_kernel)
     set_error("vxc: internal dispatch error");
     return DQC_EINVAL;
 }
@@ -1124,22 +1100,26 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
     hipStream_t st = (hipStream_t)stream;
     const bool gga = d_vgrad != nullptr;
     if (gga && ncomp < 4) { set_error("dqc_grid_vxc: vgrad given but ao has < 4 components"); return DQC_EINVAL; }
-    const int ld = dqc_padded_nao(nao), T = ld / 16, ttot = T * T;
+    // ld = 16 T: rows / columns of the output matrix and the width the kernels stage; lda: row stride of the AO arrays;
+    // LS: LDS row stride of a staged chunk, == 16 (mod 32) so that the ds_read_b64 fragment reads are conflict-free
+    const int ld = dqc_padded_nao(nao), lda = dqc_ao_stride(nao), T = ld / 16, ttot = T * T;
+    auto pad16 = [](int w_) { return (w_ & 31) == 16 ? w_ : w_ + 16; };
+    const int LS = pad16(ld);
     if (sync_vxc_det_scale()) return DQC_EHIP;
     DQC_HIP(hipMemsetAsync(d_vmat, 0, sizeof(double) * (size_t)ld * ld, st));
     if (ngrid > 0) {
         static const char *impl_env = getenv("DQC_VXC_IMPL");  // "reg": the unspecialised vxc_kernel (A/B runs)
         // one-operand forms without a gradient term (LDA Vxc, the tau terms of a meta-GGA) are symmetric matrices: the
         // wave-specialised kernel then computes the upper-triangular tiles only
-        const bool ws_shape = ld <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r');
+        const bool ws_shape = LS <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r');
         const bool sym = ws_shape && !gga && d_aob == d_ao;
         const int ttot_w = sym ? T * (T + 1) / 2 : ttot;
         if (ttot_w > 2 * 11 * VXC_WAVES && !(impl_env && impl_env[0] == 'r')) {
-            // larger bases: rectangular ownership (vxc_ws2_kernel), rectangles of at most 8 x 11 tiles
+            // larger bases: rectangular ownership (vxc_ws2_kernel), rectangles of at most 9 x 12 tiles
             // rectangle shape: a block stages nr Phi tile columns (one component) and 4 nc AO-component tile columns for its
             // nr x nc tiles -- (nr + 4 nc) / (nr nc) operand tile columns per MFMA: rows are cheap, columns dear.  The tallest
             // rectangle the layout allows (9 rows: LSA <= 144), then the widest that keeps <= 11 accumulator tiles per wave:
-            // T = 27 (naphthalene / cc-pVTZ): 9 x 9 tiles, 9 blocks per slab (round 2: 7 x 9, 12 blocks); T = 17: 9 x 9 (6 x 9).
+            // T = 26 (naphthalene / cc-pVTZ): 9 x 9 tiles, 9 blocks per slab (round 2: 7 x 9, 12 blocks); T = 17: 9 x 9 (6 x 9).
             // DQC_WS2_NR / DQC_WS2_NC override the block counts (A/B runs).
             int NR = (T + 8) / 9, NC = 1;
             {
@@ -1153,7 +1133,6 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             if (nrmax > 9 || ncmax > 12 || nrmax * ncmax > 11 * VXC_WAVES) { set_error("vxc_ws2: rectangle outside the kernel's limits"); return DQC_EINVAL; }
             const int need2 = (nrmax * ncmax + VXC_WAVES - 1) / VXC_WAVES;
             const int maxt2 = need2 <= 8 ? 8 : 11;
-            auto pad16 = [](int w_) { return (w_ & 31) == 16 ? w_ : w_ + 16; };  // == 16 (mod 32): conflict-free fragments
             const int LSA = pad16(nrmax * 16), LSB = pad16(ncmax * 16);
             const int nla = nrmax <= 8 ? 4 : 5, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;  // b128 loads per producer thread and row
             const int nsplit2 = NR * NC;
@@ -1164,11 +1143,11 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             const size_t shmem2 = sizeof(double) * 2 * WS2_BUF;  // fixed-stride chunk layout, two buffers
             if (LSA > 144 || LSB > 208) { set_error("vxc_ws2: internal layout error"); return DQC_EINVAL; }
             dim3 grid2(nslab * nsplit2);
-            int rc = gga ? launch_vxc_ws2<true>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob)
-                         : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob);
+            int rc = gga ? launch_vxc_ws2<true>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob, lda)
+                         : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob, lda);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
@@ -1184,16 +1163,18 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             const size_t shmem_u = sizeof(double) * 2 * VWS_BUF;
             int rc = 0;
             // GGA: one MFMA on the diagonal tiles (vxc_wsd_kernel); DQC_VXC_IMPL=upper keeps two on every tile (A/B runs)
-            if (gga && (T == 13 || T == 11) && !(impl_env && impl_env[0] == 'u')) {
-                if (T == 13) launch_vxc_wsd<13>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab);
-                else launch_vxc_wsd<11>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab);
+            if (gga && !(impl_env && impl_env[0] == 'u')) {
+                if (T == 13) launch_vxc_wsd<13>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab, lda);
+                else if (T == 12) launch_vxc_wsd<12>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab, lda);
+                else if (T == 11) launch_vxc_wsd<11>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab, lda);
+                else launch_vxc_wsd<10>(dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, d_w, d_vrho, d_vgrad, slab, lda);
             } else {
-                rc = gga ? launch_vxc_wsu<true>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab)
-                         : launch_vxc_wsu<false>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab);
+                rc = gga ? launch_vxc_wsu<true>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, lda, LS)
+                         : launch_vxc_wsu<false>(need, dim3(nslab), shmem_u, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, lda, LS);
             }
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
@@ -1208,7 +1189,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         for (int q = 0; q < 5; q++)
             if (sizes_p[q] >= need) { maxt = sizes_p[q]; break; }
         // chunk depth: 16 points while the double-buffered (phi, psi) chunk fits LDS, else 8
-        const int kch = (sizeof(double) * 2 * 2 * 16 * (size_t)ld <= 150 * 1024) ? 16 : 8;
+        const int kch = (sizeof(double) * 2 * 2 * 16 * (size_t)LS <= 150 * 1024) ? 16 : 8;
         const int tpr = 512 / kch;  // threads per chunk row
         const int nlneed = (ld / 2 + tpr - 1) / tpr;  // double2 columns per thread
         const int nl = nlneed <= 1 ? 1 : (nlneed <= 2 ? 2 : (nlneed <= 4 ? 4 : 8));
@@ -1218,28 +1199,28 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         int slab = (ngrid + nslab - 1) / nslab;
         slab = (slab + kch - 1) / kch * kch;
         nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;
-        const size_t shmem = sizeof(double) * 2 * 2 * kch * ld;
+        const size_t shmem = sizeof(double) * 2 * 2 * kch * LS;
         dim3 grid(nslab * nsplit);
-        // default: wave-specialised kernel (8 MFMA waves + 4 producer waves); the producers hold a whole chunk in
+        // default: wave-specialised kernel (8 MFMA waves + 8 producer waves); the producers hold a whole chunk in
         // registers, which bounds ld; DQC_VXC_IMPL=reg selects the unspecialised kernel
         const int tprp = VWS_PROD / kch;
         const int nlpneed = (ld / 2 + tprp - 1) / tprp;
         const int nlp = nlpneed <= 1 ? 1 : (nlpneed <= 2 ? 2 : (nlpneed <= 4 ? 4 : (nlpneed <= 7 ? 7 : 8)));
-        if (nlpneed <= 7 && kch == 16 && ld <= VWS_LSMAX && !(impl_env && impl_env[0] == 'r')) {
+        if (nlpneed <= 4 && kch == 16 && ws_shape) {
             const size_t shmem_ws = sizeof(double) * 2 * VWS_BUF;  // fixed-stride chunk layout, two buffers
-            int rc = gga ? launch_vxc_ws<true>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, 0)
-                         : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, sym ? 1 : 0);
+            int rc = gga ? launch_vxc_ws<true>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, 0, lda, LS)
+                         : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, sym ? 1 : 0, lda, LS);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
-        int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob)
-                     : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob);
+        int rc = gga ? launch_vxc<true>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, lda, LS)
+                     : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, lda, LS);
         if (rc) return rc;
         DQC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld);
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
         DQC_CHECK_LAUNCH();
     }
     return DQC_OK;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
             }
         }
     }
-    // zero padding columns nao..ld-1 (ld - nao < 16)
+    // zero padding columns nao..ld-1 (ld = the arrays' row stride, dqc_ao_stride: ld - nao < 16)
     while (col0 + nfill < ld) {
         for (int c = 0; c < NC; c++) tile[wave][c][lane][nfill] = 0.0;
         nfill++;
@@ -149,7 +149,11 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
     if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_eval_gto: device upload failed"); return rc; }
     if (ngrid > 0) {
         int nblk = (ngrid + 63) / 64;
-        int ld = dqc_padded_nao(b.nao);
+        const int ld = dqc_ao_stride(b.nao);
+        const int ncomp = deriv == 0 ? 1 : (deriv == 1 ? 4 : (deriv == 2 ? 5 : 10));
+        // the slack the grid kernels may read past the last row (dqc_ao_doubles): zeros
+        const size_t body = (size_t)ncomp * (size_t)ngrid * ld, slack = dqc_ao_doubles(ncomp, ngrid, b.nao) - body;
+        if (slack) DQC_HIP(hipMemsetAsync(d_out + body, 0, slack * sizeof(double), st));
         if (deriv == 0)
             hipLaunchKernelGGL(eval_gto_kernel<0>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
         else if (deriv == 1)

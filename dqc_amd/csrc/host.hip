@@ -174,11 +174,31 @@ int dqc_nao(const int *bas, int nbas) {
 }
 
 int dqc_padded_nao(int nao) {
-    int ld = (nao + 15) / 16 * 16;  // multiple of 16 (MFMA tiles) ...
-    // (round 3: plain multiples of 16 -- benzene 144 -> 128 -- are not worth having: the LDA build gets 4 % faster, the
-    // naphthalene / cc-pVTZ one not at all, and the one-block Vxc kernels rely on an odd tile count)
-    if ((ld & 31) != 16) ld += 16;  // ... and == 16 (mod 32): LDS fragment reads are bank-conflict-free
-    return ld;
+    // rows / columns of the zero-padded AO-indexed SQUARE matrices (D, V, L): whole 16 x 16 MFMA tiles.  (Until round 4 this was
+    // also the row stride of the AO-on-grid arrays and had to be == 16 (mod 32) for the LDS fragment reads: benzene / cc-pVDZ,
+    // nao 114, lived in 144 columns -- 1.26 x the traffic and 9 tile columns of MFMA work instead of 8.  The kernels now keep
+    // their own LDS strides and the arrays their own row stride, dqc_ao_stride.)
+    return (nao + 15) / 16 * 16;
+}
+
+int dqc_ao_stride(int nao) {
+    // row stride (doubles) of the AO-on-grid arrays: nao rounded up to 8 doubles -- 64-byte aligned rows.  Measured on the
+    // benzene / naphthalene grids (profiles/r04a_grid_ab.txt): rows at the kernels' minimum alignment (2 doubles = their 16-byte
+    // loads) cost the factor-form density kernel 3-5 % although they are 5 % fewer bytes than 8-aligned rows (a 128-byte row
+    // segment then straddles cache lines); 8- and 16-aligned rows time the same, and 8 keeps benzene / cc-pVDZ (nao 114) at
+    // 1.05 x the algorithmic bytes instead of 1.12 x.  DQC_AO_ALIGN = 2 | 4 | 8 | 16 overrides (A/B runs).
+    static const int align = [] {
+        const char *e = getenv("DQC_AO_ALIGN");
+        const int a = e ? atoi(e) : 8;
+        return (a == 2 || a == 4 || a == 8 || a == 16) ? a : 8;
+    }();
+    return (nao + align - 1) / align * align;
+}
+
+size_t dqc_ao_doubles(int ncomp, int ngrid, int nao) {
+    // what an AO-on-grid array of ncomp components must hold: the kernels read whole 16-column tiles, i.e. up to
+    // dqc_padded_nao - dqc_ao_stride doubles past the end of the last row
+    return (size_t)ncomp * (size_t)ngrid * (size_t)dqc_ao_stride(nao) + (size_t)(dqc_padded_nao(nao) - dqc_ao_stride(nao));
 }
 
 size_t dqc_eri_store_doubles(int nao) {

@@ -126,11 +126,13 @@ def _xc_gradient(eng, d_aos):
     gga = fam >= 2
     ao = lib.eval_gto(h._tab, h.rgrid, 3 if gga else 1)                        # (10 | 4, ngrid, ld)
     dpads = [lib.pad_matrix(d, ld) for d in d_aos]
+    lda = ao.shape[-1]  # row stride of the AO arrays (>= nao, zero padding columns)
     bs, cs_, infos = [], [], []
     for dp in dpads:
         rho_s, grho_s = lib.grid_density(ao[:4], nao, dp, True)
-        b = ao[0] @ dp                                                         # (ngrid, ld)
-        c = [ao[1 + i] @ dp for i in range(3)] if gga else None
+        dq = dp[:lda, :lda]
+        b = ao[0] @ dq                                                         # (ngrid, lda)
+        c = [ao[1 + i] @ dq for i in range(3)] if gga else None
         tau = 0.5 * sum((c[i] * ao[1 + i]).sum(1) for i in range(3)) if fam == 4 else None
         bs.append(b)
         cs_.append(c)

@@ -73,7 +73,8 @@ class HamiltonMI355(_Base):
         self._tab = lib.Tables(atm, bas, env)
         self._zs = zs
         self._nao_ao = self._tab.nao
-        self._ld = lib.padded_nao(self._nao_ao)
+        self._ld = lib.padded_nao(self._nao_ao)    # rows / columns of the zero-padded square matrices the kernels take
+        self._lda = lib.ao_stride(self._nao_ao)   # row stride of the AO-on-grid arrays
 
         self._ovlp_ao = lib.int1e("ovlp", self._tab, self.device)
         # the orthogonaliser (eigh of S: 5 ms of small rocSOLVER kernels with the host waiting) is formed at first use, so that
@@ -657,7 +658,7 @@ class HamiltonMI355(_Base):
             # sum_r (Phi L)_r (lapl Phi L)_r = 1/4 [ |(Phi + lapl Phi) L|^2 - |(Phi - lapl Phi) L|^2 ]: two more phase-1 passes of the
             # factor kernel on the arrays Phi +- lapl Phi (formed on first use: 2 x ngrid x ld doubles)
             if getattr(self, "_ao_lapl_pm", None) is None:
-                self._ao_lapl_pm = ((self._ao[0] + self._ao[4]).contiguous(), (self._ao[0] - self._ao[4]).contiguous())
+                self._ao_lapl_pm = (lib.ao_from(self._ao[0] + self._ao[4], self._nao_ao), lib.ao_from(self._ao[0] - self._ao[4], self._nao_ao))
             pl = sum(lib.grid_density_lr(self._ao_lapl_pm[0], self._nao_ao, f, False)[0] for f in fac)
             mi = sum(lib.grid_density_lr(self._ao_lapl_pm[1], self._nao_ao, f, False)[0] for f in fac)
             return ValGrad(value=rho, grad=grho, lapl=2.0 * (0.25 * (pl - mi) + gg), kin=gg * 0.5)

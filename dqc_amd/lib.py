@@ -45,6 +45,9 @@ def load():
     lib.dqc_version.restype = c_int
     lib.dqc_nao.argtypes = [ip, c_int]
     lib.dqc_padded_nao.argtypes = [c_int]
+    lib.dqc_ao_stride.argtypes = [c_int]
+    lib.dqc_ao_doubles.argtypes = [c_int, c_int, c_int]
+    lib.dqc_ao_doubles.restype = c_sz
     lib.dqc_eri_tile_count.argtypes = [c_int]
     lib.dqc_eri_tile_count.restype = c_sz
     if hasattr(lib, "dqc_eri_store_doubles"):  # (absent from the pre-packing A/B build tools/gpu_jk_ab.py loads)
@@ -171,7 +174,37 @@ class Tables:
 
 
 def padded_nao(nao):
+    """rows / columns of the zero-padded AO-indexed square matrices (D, V, the factor pair): whole 16 x 16 tiles"""
     return int(load().dqc_padded_nao(int(nao)))
+
+
+def ao_stride(nao):
+    """row stride of the AO-on-grid arrays (nao rounded up to 8 doubles: 64-byte rows, no tile padding in HBM)"""
+    return int(load().dqc_ao_stride(int(nao)))
+
+
+def ao_empty(ncomp, ngrid, nao, device, zero=False):
+    """an AO-on-grid array for the grid kernels: (ngrid, lda) for ncomp = 0, else (ncomp, ngrid, lda), a view of a flat buffer
+    of dqc_ao_doubles doubles -- the kernels read whole 16-column tiles, up to ld - lda doubles past the end of the last row
+    (that slack is zeroed here)"""
+    nc = max(int(ncomp), 1)
+    lda = ao_stride(nao)
+    tot = int(load().dqc_ao_doubles(nc, int(ngrid), int(nao)))
+    flat = (torch.zeros if zero else torch.empty)(tot, dtype=torch.float64, device=device)
+    body = nc * int(ngrid) * lda
+    if not zero and tot > body:
+        flat[body:].zero_()
+    out = flat[:body].view(nc, int(ngrid), lda)
+    return out[0] if ncomp == 0 else out
+
+
+def ao_from(values, nao=None):
+    """values (ngrid, n) or (ncomp, ngrid, n) with n >= nao (any device tensor / view, e.g. the sum of two AO arrays) -> a
+    fresh array in the kernels' layout (row stride lda, zero padding columns, zeroed slack) holding values[..., :nao]"""
+    nao = values.shape[-1] if nao is None else nao
+    out = ao_empty(0 if values.dim() == 2 else values.shape[0], values.shape[-2], nao, values.device, zero=True)
+    out[..., :nao] = values[..., :nao]
+    return out
 
 
 def int1e(which, tab, device, zs=None):
@@ -461,12 +494,15 @@ def jk_multi(tiles, dms_j, dms_k, work=None):
 
 
 def eval_gto(tab, rgrid, deriv):
-    """rgrid (ngrid,3) device -> (ngrid, ld) [deriv 0], (4, ngrid, ld) [deriv 1], (5, ngrid, ld) [deriv 2: + laplacian]
-    or (10, ngrid, ld) [deriv 3: + xx xy xz yy yz zz]"""
+    """rgrid (ngrid,3) device -> (ngrid, lda) [deriv 0], (4, ngrid, lda) [deriv 1], (5, ngrid, lda) [deriv 2: + laplacian]
+    or (10, ngrid, lda) [deriv 3: + xx xy xz yy yz zz]; lda = ao_stride(nao) (the array carries the kernels' slack, see ao_empty)"""
     ngrid = rgrid.shape[0]
-    ld = padded_nao(tab.nao)
-    shape = (ngrid, ld) if deriv == 0 else ({1: 4, 2: 5, 3: 10}[deriv], ngrid, ld)
-    out = torch.empty(shape, dtype=torch.float64, device=rgrid.device)
+    ncomp = {0: 0, 1: 4, 2: 5, 3: 10}[deriv]
+    nc = max(ncomp, 1)
+    lda = ao_stride(tab.nao)
+    flat = torch.empty(int(load().dqc_ao_doubles(nc, int(ngrid), int(tab.nao))), dtype=torch.float64, device=rgrid.device)
+    out = flat[:nc * ngrid * lda].view(nc, ngrid, lda)
+    out = out[0] if ncomp == 0 else out
     with _on(rgrid.device) as st_:
         _check(load().dqc_eval_gto(deriv, _ptr(out), _ptr(rgrid.contiguous()), ngrid, *tab.args(), st_),
                "dqc_eval_gto")
@@ -612,7 +648,7 @@ def grid_density_pair(ao_a, ao_b, nao, dm_pad):
 
 def grid_vxc_pair(ao_a, ao_b, nao, w, v):
     """sym( sum_g w_g v_g a_ga b_gb ) -> (ld, ld)"""
-    ngrid, ld = ao_a.shape
+    ngrid, ld = ao_a.shape[0], padded_nao(nao)
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao_a.device)
     with _on(ao_a.device) as st_:
         _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), st_),
@@ -624,7 +660,7 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
     """-> (ld, ld) symmetric AO-basis Vxc matrix (zero padded)"""
     ncomp = 1 if ao.dim() == 2 else ao.shape[0]
     ngrid = ao.shape[-2]
-    ld = ao.shape[-1]
+    ld = padded_nao(nao)
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
     with _on(ao.device) as st_:
         _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), st_),
@@ -661,7 +697,7 @@ def grid_fused(ao, nao, w, factor, terms, want_dens=False, want_exc=False):
     """(variant library) density -> XC -> Vxc from one read of the AO matrix (4, ngrid, ld); factor = pad_factor(...) pair; terms:
     LDA / GGA list.  -> (vmat (ld, ld), rho or None, grho (3, ngrid) or None, exc (1,) or None)"""
     orb, orbt = factor
-    ngrid, ld = ao.shape[-2], ao.shape[-1]
+    ngrid, ld = ao.shape[-2], padded_nao(nao)
     ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
     cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)

@@ -14,8 +14,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work and
  *     return; they synchronise only where stated.
  *   - return value: 0 on success, negative DQC_E* on error; dqc_last_error() gives the text.
- *   - `ld` ("leading dimension") of AO-indexed device matrices is dqc_padded_nao(nao)
- *     (the smallest multiple of 16 >= nao that is 16 mod 32); padding columns/rows are zero.
+ *   - `ld` ("leading dimension") of the AO-indexed SQUARE device matrices (D, V, the factor pair) is
+ *     dqc_padded_nao(nao), the smallest multiple of 16 >= nao; padding columns/rows are zero.
+ *   - the AO-on-grid arrays (dqc_eval_gto output, the d_ao arguments) have their own row stride
+ *     `lda` = dqc_ao_stride(nao) (nao rounded up to 8 doubles: 64-byte rows, no tile padding in HBM) and must be
+ *     allocated with dqc_ao_doubles(ncomp, ngrid, nao) doubles: the kernels read whole 16-column tiles,
+ *     i.e. up to ld - lda doubles past the end of the last row (dqc_eval_gto zeroes that slack).
  */
 #ifndef DQC_AMD_H
 #define DQC_AMD_H
@@ -35,8 +39,11 @@ const char *dqc_last_error(void);
 int dqc_version(void);
 /* number of spherical AOs described by bas  (CINTcgto_spheric summed; lcintwrap.py:376-383) */
 int dqc_nao(const int *bas, int nbas);
-/* leading dimension used for all AO-indexed device matrices */
+/* leading dimension of the AO-indexed square device matrices */
 int dqc_padded_nao(int nao);
+/* row stride of the AO-on-grid arrays, and the doubles an array of ncomp components must hold */
+int dqc_ao_stride(int nao);
+size_t dqc_ao_doubles(int ncomp, int ngrid, int nao);
 
 /* ---- one-electron integrals --------------------------------------------------------------
  * Replaces GTOint2c(int1e_{ovlp,kin,nuc}_sph, ...)  (dqc/hamilton/intor/molintor.py:624-644,
@@ -87,16 +94,17 @@ int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_
 /* ---- AO values on the grid -----------------------------------------------------------------
  * Replaces GTOval_sph / GTOval_ip_sph (dqc/hamilton/intor/gtoeval.py:196-239) with the
  * to_transpose=True layout of HamiltonCGTO.setup_grid (hcgto.py:168, :179).
- * deriv 0: d_out (ngrid, ld) = phi;  deriv 1: d_out (4, ngrid, ld) = phi, d/dx, d/dy, d/dz;
- * deriv 2: d_out (5, ngrid, ld) = the same plus the laplacian (GTOval_lapl_sph, hcgto.py:183-186).
- * deriv 3: d_out (10, ngrid, ld) = phi, gradient, then d2/dxx, dxy, dxz, dyy, dyz, dzz (GTOval_sph_deriv2 order without
+ * deriv 0: d_out (ngrid, lda) = phi;  deriv 1: d_out (4, ngrid, lda) = phi, d/dx, d/dy, d/dz;
+ * deriv 2: d_out (5, ngrid, lda) = the same plus the laplacian (GTOval_lapl_sph, hcgto.py:183-186).
+ * deriv 3: d_out (10, ngrid, lda) = phi, gradient, then d2/dxx, dxy, dxz, dyy, dyz, dzz (GTOval_sph_deriv2 order without
  *          the duplicates; used by the GGA nuclear gradient).
- * d_coords: (ngrid, 3).  ld = dqc_padded_nao(nao); padding columns are written as zero. */
+ * d_coords: (ngrid, 3).  lda = dqc_ao_stride(nao); d_out holds dqc_ao_doubles(ncomp, ngrid, nao) doubles; padding columns and
+ * the slack are written as zero. */
 int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, int ngrid, const int *atm,
                  int natm, const int *bas, int nbas, const double *env, int nenv, void *stream);
 
 /* ---- density on the grid  (HamiltonCGTO._dm2densinfo, hcgto.py:371-443) ---------------------
- * d_ao: (ncomp, ngrid, ld) from dqc_eval_gto, ncomp = 1 (LDA) or 4 (GGA).  d_dm: (ld, ld)
+ * d_ao: (ncomp, ngrid, lda) from dqc_eval_gto, ncomp = 1 (LDA) or 4 (GGA).  d_dm: (ld, ld)
  * symmetric AO density (zero padded).  d_rho: (ngrid).  d_grho: (3, ngrid) or NULL. */
 int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid,
                      int nao, const double *d_dm, void *stream);
@@ -247,7 +255,7 @@ int dqc_padded_norb(int norb);
 int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
                         const double *d_orb, const double *d_orbt, int norb_pad, void *stream);
 
-/* "pair" forms used by the meta-GGA branches (hcgto.py:420-438, 473-489), both on single-component (ngrid, ld)
+/* "pair" forms used by the meta-GGA branches (hcgto.py:420-438, 473-489), both on single-component (ngrid, lda)
  * arrays:  d_out_g = sum_ij a_gi D_ij b_gj   and   d_vmat = sym( sum_g w_g v_g a_ga b_gb ). */
 int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
                           const double *d_dm, void *stream);

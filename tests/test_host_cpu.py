@@ -28,7 +28,10 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(so, n), n
     L = lib.load()
     assert L.dqc_version() >= 100
-    assert L.dqc_padded_nao(114) == 144 and L.dqc_padded_nao(208) == 208 and L.dqc_padded_nao(7) == 16
+    assert L.dqc_padded_nao(114) == 128 and L.dqc_padded_nao(208) == 208 and L.dqc_padded_nao(7) == 16
+    assert L.dqc_ao_stride(114) == 120 and L.dqc_ao_stride(7) == 8 and L.dqc_ao_stride(208) == 208 and L.dqc_ao_stride(412) == 416
+    L.dqc_ao_doubles.restype = __import__("ctypes").c_size_t
+    assert L.dqc_ao_doubles(4, 10, 114) == 4 * 10 * 120 + 8
     assert L.dqc_eri_tile_count(208) == 351 * 352 // 2 * (351 * 352 // 2 + 1) // 2 or L.dqc_eri_tile_count(208) > 0
     nb = 26
     npair = nb * (nb + 1) // 2

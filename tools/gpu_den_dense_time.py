@@ -6,7 +6,7 @@ from dqc_amd import lib
 ngrid, nao = 353400, 208
 ld = lib.padded_nao(nao)
 g = torch.Generator(device="cuda").manual_seed(1)
-ao = torch.randn((4, ngrid, ld), dtype=torch.float64, device="cuda", generator=g) * 0.1
+ao = lib.ao_from(torch.randn((4, ngrid, nao), dtype=torch.float64, device="cuda", generator=g) * 0.1)
 d = torch.randn((nao, nao), dtype=torch.float64, device="cuda", generator=g); d = d + d.T
 dp = lib.pad_matrix(d, ld)
 f = lambda: lib.grid_density(ao, nao, dp, True)

@@ -8,9 +8,8 @@ terms = [(1.0, "gga_x_pbe"), (1.0, "gga_c_pbe")]
 for nao, ngrid, nocc in ((208, 353400, 46), (170, 30011, 20), (200, 5000, 64), (208, 17, 5), (208, 4099, 33)):
     ld = lib.padded_nao(nao)
     g = torch.Generator().manual_seed(nao + ngrid)
-    ao = torch.zeros((4, ngrid, ld), dtype=torch.float64)
-    ao[:, :, :nao] = torch.randn((4, ngrid, nao), dtype=torch.float64, generator=g) * torch.exp(-3 * torch.rand((4, ngrid, nao), dtype=torch.float64, generator=g))
-    ao = ao.to(dev)
+    ao = torch.randn((4, ngrid, nao), dtype=torch.float64, generator=g) * torch.exp(-3 * torch.rand((4, ngrid, nao), dtype=torch.float64, generator=g))
+    ao = lib.ao_from(ao.to(dev))
     w = torch.rand(ngrid, dtype=torch.float64, generator=g).to(dev)
     c = (torch.randn((nao, nocc), dtype=torch.float64, generator=g) * 0.3).to(dev)
     fac = lib.pad_factor(c, ld)

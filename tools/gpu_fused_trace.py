@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 nao, ngrid, nocc = 208, 353400, 46
 ld = lib.padded_nao(nao)
 g = torch.Generator().manual_seed(1)
-ao = (torch.randn((4, ngrid, ld), dtype=torch.float64, generator=g) * torch.exp(-3 * torch.rand((4, ngrid, ld), dtype=torch.float64, generator=g))).to(dev)
+ao = lib.ao_from((torch.randn((4, ngrid, nao), dtype=torch.float64, generator=g) * torch.exp(-3 * torch.rand((4, ngrid, nao), dtype=torch.float64, generator=g))).to(dev))
 w = torch.rand(ngrid, dtype=torch.float64, generator=g).to(dev)
 fac = lib.pad_factor((torch.randn((nao, nocc), dtype=torch.float64, generator=g) * 0.3).to(dev), ld)
 terms = [(1.0, "gga_x_pbe"), (1.0, "gga_c_pbe")]

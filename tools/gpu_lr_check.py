@@ -31,7 +31,7 @@ for name, mol, basis, gridn, nocc in [("h2o", M.H2O, "cc-pvdz", "sg2", 5), ("ch4
     if name == "h2o":
         rg = rg[:-7]
     ao = lib.eval_gto(tab, torch.as_tensor(rg, device=dev), 1)
-    nao, ld = tab.nao, ao.shape[-1]
+    nao, ld = tab.nao, lib.padded_nao(tab.nao)
     rng = np.random.default_rng(5)
     L = rng.standard_normal((nao, nocc)) / np.sqrt(nao)
     D = L @ L.T

@@ -10,11 +10,11 @@ nao, ngrid = 208, 353400
 ld = lib.padded_nao(nao)
 torch.manual_seed(0)
 if kind == "zeros":
-    ao = torch.zeros((4, ngrid, ld), dtype=torch.float64, device=dev)
+    ao = lib.ao_from(torch.zeros((4, ngrid, nao), dtype=torch.float64, device=dev))
 elif kind == "ones":
-    ao = torch.ones((4, ngrid, ld), dtype=torch.float64, device=dev)
+    ao = lib.ao_from(torch.ones((4, ngrid, nao), dtype=torch.float64, device=dev))
 else:
-    ao = torch.randn((4, ngrid, ld), dtype=torch.float64, device=dev)
+    ao = lib.ao_from(torch.randn((4, ngrid, nao), dtype=torch.float64, device=dev))
     if kind == "small":
         ao = ao * 1e-3 * (torch.rand_like(ao) > 0.9)
 w = torch.rand(ngrid, dtype=torch.float64, device=dev)

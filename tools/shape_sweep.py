@@ -32,7 +32,7 @@ def main():
     for nao, ngrid in SHAPES:
         ld = lib.padded_nao(nao)
         g = torch.Generator(device="cpu").manual_seed(nao)
-        ao = torch.zeros((4, ngrid, ld), dtype=torch.float64, device=dev)
+        ao = lib.ao_empty(4, ngrid, nao, dev, zero=True)
         # AO-like magnitudes (many small values): exp(-|N(0, 4)|^2) * N(0, 1)
         blk = 65536
         for c in range(4):
