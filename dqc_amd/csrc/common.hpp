@@ -23,7 +23,7 @@ namespace dqc {
 // (index 8 a + b).  Tiles follow each other in the order (IJ, KL <= IJ); tile (IJ, KL) starts at
 //     tile_row_off(I, J) + R(IJ) * (64 KL - 28 K),
 //     tile_row_off(I, J) = sum_{P < IJ} R(P) * (64 (P + 1) - 28 (A_P + [A_P == B_P])) = 8 I (64 I^3 + 16 I^2 + 129 I - 47) + 256 J (8 I^2 + I + 8 J + 8)
-// (a closed form: a table lookup in front of every tile's loads cost the J + K kernels 6-9 %).  For nao = 208 the store is
+// (a closed form: a table lookup in front of every tile's loads cost the J + K kernels 6-9 %; the last block row: tile_base below).  For nao = 208 the store is
 // 1.895 GB instead of the 2.024 GB of full 8^4 tiles (ideal nao^4 / 8 doubles: 1.872 GB).
 // ---------------------------------------------------------------------------------------
 __host__ __device__ inline int tile_dim(bool diag) { return diag ? 36 : 64; }
@@ -35,10 +35,34 @@ __host__ __device__ inline int tile_pidx(bool diag, int a, int b) {  // local pa
 __host__ __device__ inline long long tile_row_off(long long I, long long J) {
     return 8 * I * (64 * I * I * I + 16 * I * I + 129 * I - 47) + 256 * J * (8 * I * I + I + 8 * J + 8);
 }
-__host__ __device__ inline long long tile_base(int I, int J, int K, int KL) {  // first double of tile ((I, J), KL = (K, .))
-    return tile_row_off(I, J) + (long long)tile_dim(I == J) * (64LL * KL - 28LL * K);
+// Round 4: the LAST AO block is stored at its true width.  nao = 8 last + wl (1 <= wl <= 8): a block pair (last, J) has only
+// 8 wl (J < last) or wl (wl + 1) / 2 (J == last) rows that belong to AOs -- a PREFIX of its 64 / 36 rows in the pair's own
+// element order (8 a + b resp. a (a + 1) / 2 + b with a < wl) -- and only those are stored (benzene / cc-pVDZ, nao 114 = 14 x 8 + 2:
+// 0.213 -> 0.172 GB, 1.26 -> 1.02 x nao^4 bytes; naphthalene / cc-pVTZ 30.1 -> 29.1 GB).  The pairs (last, .) are the last ones in
+// the order of the store, so every tile in front of them keeps its closed-form offset; COLUMNS are left alone (a padded column
+// needs K == last, which only the last block row itself has: 0.1 % of the store).
+struct TileLay {
+    int last, wl;
+    __host__ __device__ TileLay(int nao) : last((nao - 1) >> 3), wl(nao - 8 * ((nao - 1) >> 3)) {}
+};
+__host__ __device__ inline int tile_rows(int I, int J, const TileLay &ly) {  // stored rows of the tiles of block pair (I, J)
+    if (I == ly.last && ly.wl < 8) return I == J ? ly.wl * (ly.wl + 1) / 2 : 8 * ly.wl;
+    return tile_dim(I == J);
 }
-inline long long eri_store_data_doubles(int nao) { return tile_row_off((nao + DQC_TILE_B - 1) / DQC_TILE_B, 0); }
+__host__ __device__ inline long long tile_base(int I, int J, int K, int KL, const TileLay &ly) {  // first double of tile ((I, J), KL = (K, .))
+    const long long colpre = 64LL * KL - 28LL * K;  // columns of the pairs in front of KL
+    if (I < ly.last || ly.wl == 8) return tile_row_off(I, J) + (long long)tile_dim(I == J) * colpre;
+    // row (last, J): everything up to (last, 0), then the J truncated pairs (last, J' < J) of 64 (P0 + J' + 1) - 28 last columns each
+    const long long L = ly.last, P0 = L * (L + 1) / 2;
+    const long long pre = tile_row_off(L, 0) + 8LL * ly.wl * ((64 * (P0 + 1) - 28 * L) * J + 32LL * J * (J - 1));
+    return pre + (long long)tile_rows(I, J, ly) * colpre;
+}
+inline long long eri_store_data_doubles(int nao) {
+    if (nao <= 0) return 0;
+    const TileLay ly(nao);
+    const long long L = ly.last, PL = L * (L + 1) / 2 + L;
+    return tile_base(ly.last, ly.last, 0, 0, ly) + (long long)tile_rows(ly.last, ly.last, ly) * (64 * (PL + 1) - 28 * (L + 1));
+}
 
 void set_error(const std::string &msg);
 bool deterministic_mode();  // dqc_set_deterministic (host.hip)

@@ -51,7 +51,7 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
         int IJ = (a >> 3) * ((a >> 3) + 1) / 2 + (b >> 3), KL = (c >> 3) * ((c >> 3) + 1) / 2 + (d >> 3);
         if (IJ < KL) { int t = a; a = c; c = t; t = b; b = d; d = t; t = IJ; IJ = KL; KL = t; }
         const int A = a >> 3, B = b >> 3, Cb = c >> 3, Db = d >> 3;
-        dense[e] = tiles[tile_base(A, B, Cb, KL) + (long long)tile_pidx(A == B, a & 7, b & 7) * tile_dim(Cb == Db) + tile_pidx(Cb == Db, c & 7, d & 7)];
+        dense[e] = tiles[tile_base(A, B, Cb, KL, TileLay(nao)) + (long long)tile_pidx(A == B, a & 7, b & 7) * tile_dim(Cb == Db) + tile_pidx(Cb == Db, c & 7, d & 7)];
     }
 }
 
@@ -604,6 +604,7 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     EriOut og{0, 0, 0, 0};
     og.st_lo = lo;
     og.st_hi = hi;
+    og.st_nao = b.nao;
     rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og);
     if (rc) return rc;
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;

@@ -70,7 +70,7 @@ __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2;
 // the shallow (cc-pVTZ-type, one primitive quartet) classes.
 // [lo, hi): the double offsets of the slice of the store this launch fills (a rank's share of a store sharded over several
 // GPUs: `tiles` is then the slice's virtual origin, slice - lo); whole store: 0 ... LLONG_MAX
-DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l, double v, long long lo, long long hi) {
+DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l, double v, long long lo, long long hi, int nao) {
     int I = i >> 3, J = j >> 3, K = k >> 3, L = l >> 3;
     int il = i & 7, jl = j & 7, kl = k & 7, ll = l & 7;
     if (I < J || (I == J && il < jl)) { int t = I; I = J; J = t; t = il; il = jl; jl = t; }
@@ -81,7 +81,7 @@ DQC_DEV void tile_put_all(double *__restrict__ tiles, int i, int j, int k, int l
     }
     const int C = tile_dim(K == L);
     const int r = tile_pidx(I == J, il, jl), c = tile_pidx(K == L, kl, ll);
-    const long long base = tile_base(I, J, K, KL);
+    const long long base = tile_base(I, J, K, KL, TileLay(nao));  // (rows of valid AOs are a prefix of every pair: r < tile_rows)
     if (base < lo || base >= hi) return;
     double *tb = tiles + base;
     tb[(long long)r * C + c] = v;
@@ -194,6 +194,7 @@ struct EriOut {
     int part = 0, nparts = 1;
     // ---- TILES mode: slice [st_lo, st_hi) (double offsets) of the store this launch fills (dqc_eri_fill_tiles_part)
     long long st_lo = 0, st_hi = 0x7fffffffffffffffLL;
+    int st_nao = 0;  // basis size (the last block row of the store is kept at its true width: common.hpp TileLay)
 };
 constexpr int SCREEN_NBIN = 8;
 // contraction-depth bin of a pair with npp surviving primitive pairs: 0 = deepest (> 64) ... 7 = one primitive pair (or none)
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
             } else
             if (MODE == ERI_OUT_TILES) {
-                tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi);
+                tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
             } else if (MODE == ERI_OUT_3C) {
                 const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                 tiles[(io * og.nao + jo) * og.naux + kx] = v;

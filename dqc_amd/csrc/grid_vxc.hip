@@ -604,7 +604,7 @@ __device__ long long g_vwu_trace[2 * VWU_TRACE_N];
 #define VWU_STAMP(role, slot)
 #endif
 
-template <int MAXT, int NTL, bool TWO, int D = 2, int KG0 = 0, int NKG = 4>
+template <int MAXT, int NTL, bool TWO, int D = 2, int KG0 = 0, int NKG = 4, int GS = VWS_GS, int XS = VWS_XS>
 __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsigned (&pj)[MAXT], v4d (&acc)[MAXT]) {
     // NTL <= MAXT: tiles actually looped over (waves that own one tile fewer skip the dummy MFMAs);
     // k-groups KG0 .. KG0 + NKG - 1 of the 16-point chunk (the fused kernel runs a chunk in two halves)
@@ -613,8 +613,8 @@ __device__ __forceinline__ void wsu_chunk(const unsigned (&pi)[MAXT], const unsi
     auto rd = [&](int s) {
         const int kk = KG0 + s / (NTL * H), t = (s % (NTL * H)) / H, h = s % H;
         // h = 0: A = Phi_i, B = Psi_j;   h = 1: A = Psi_i, B = Phi_j
-        fa[s % (D + 1)] = *(lds_cdouble_t *)(pi[t] + (kk * VWS_GS + (h ? VWS_XS : 0)) * 8);
-        fb[s % (D + 1)] = *(lds_cdouble_t *)(pj[t] + (kk * VWS_GS + (h ? 0 : VWS_XS)) * 8);
+        fa[s % (D + 1)] = *(lds_cdouble_t *)(pi[t] + (kk * GS + (h ? XS : 0)) * 8);
+        fb[s % (D + 1)] = *(lds_cdouble_t *)(pj[t] + (kk * GS + (h ? 0 : XS)) * 8);
     };
 #pragma unroll
     for (int s = 0; s < D && s < NS; s++) rd(s);
@@ -949,6 +949,7 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__
 #undef DQC_WSD_CASE
 }
 
+
 #ifdef DQC_WITH_FUSED  // the measured-negative fused grid pass: variant library only (libdqc_amd_fused.so, its own test)
 #include "grid_fused.inc"
 #endif
@@ -1136,7 +1137,12 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             const int LSA = pad16(nrmax * 16), LSB = pad16(ncmax * 16);
             const int nla = nrmax <= 8 ? 4 : 5, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;  // b128 loads per producer thread and row
             const int nsplit2 = NR * NC;
-            int nslab = std::max(8, (512 / nsplit2) / 8 * 8);
+            // the blocks of a slab carry different work (T = 26: 64 ... 81 tiles) and the hardware deals blocks to the CUs in index
+            // order: ~12 blocks per CU even the loads out (naphthalene / cc-pVTZ: 2.34 ms with 2 per CU, 2.17 with 12), as long
+            // as a block keeps >= 64 chunks (its prologue / atomic epilogue: nao 264 on 206 k points 0.73 -> 0.91 ms with 17-chunk
+            // blocks).  DQC_VXC_BLOCKS overrides the target (A/B runs).
+            static const int target_blocks2 = [] { const char *e = getenv("DQC_VXC_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 3072; }();
+            int nslab = std::max(8, std::min(target_blocks2 / nsplit2, std::max(ngrid / 1024, 512 / nsplit2)) / 8 * 8);
             int slab = (ngrid + nslab - 1) / nslab;
             slab = (slab + 15) / 16 * 16;
             nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;

@@ -35,10 +35,17 @@ DQC_DEV void decode_tri(long long t, int &a, int &b) {  // t = a(a+1)/2 + b, b <
 // a > b twins -- the same cache lines, so HBM delivers the packed size -- and the arithmetic downstream (the 1/2 weights of
 // the diagonal pairs) is that of the full view, unchanged.
 DQC_DEV void tile_load_patch(const double *__restrict__ tiles, int IJ, int KL, int I, int J, int K, int L, int r0, int c0, double2 &a0, double2 &b0, double2 &a1, double2 &b1, double2 &a2,
-                             double2 &b2, double2 &a3, double2 &b3) {
+                             double2 &b2, double2 &a3, double2 &b3, const TileLay &ly) {
     const bool dr = I == J, dc = K == L;
-    const double *tp = tiles + tile_base(I, J, K, KL);
+    const double *tp = tiles + tile_base(I, J, K, KL, ly);
+    // the last block row is stored at its true width (common.hpp: TileLay): rows of the view past the prefix that belongs to AOs
+    // do not exist in the store -- they read as zeros.  (8 wl is a multiple of the patch height: a patch is in or out as a whole.)
+    const bool trunc = I == ly.last && ly.wl < 8;
     if (!dr && !dc) {
+        if (trunc && r0 >= 8 * ly.wl) {
+            a0 = b0 = a1 = b1 = a2 = b2 = a3 = b3 = make_double2(0.0, 0.0);
+            return;
+        }
         const double *q = tp + r0 * 64 + c0;
         a0 = *reinterpret_cast<const double2 *>(q);       b0 = *reinterpret_cast<const double2 *>(q + 2);
         a1 = *reinterpret_cast<const double2 *>(q + 64);  b1 = *reinterpret_cast<const double2 *>(q + 66);
@@ -47,23 +54,29 @@ DQC_DEV void tile_load_patch(const double *__restrict__ tiles, int IJ, int KL, i
         return;
     }
     const int il = r0 >> 3, j0 = r0 & 7, kl = c0 >> 3, l0 = c0 & 7;
+    const double2 z2 = make_double2(0.0, 0.0);
+    // row x of the patch (view row r0 + x = local pair (il, j0 + x)) exists unless the pair holds a padding AO of the last block
+    const bool ok0 = !trunc || (dr ? max(il, j0) < ly.wl : il < ly.wl), ok1 = !trunc || (dr ? max(il, j0 + 1) < ly.wl : il < ly.wl);
+    const bool ok2 = !trunc || (dr ? max(il, j0 + 2) < ly.wl : il < ly.wl), ok3 = !trunc || (dr ? max(il, j0 + 3) < ly.wl : il < ly.wl);
     if (!dc) {  // only the rows are packed: the four columns stay contiguous and 16-byte aligned
         const double *q0 = tp + tile_pidx(true, il, j0) * 64 + c0, *q1 = tp + tile_pidx(true, il, j0 + 1) * 64 + c0;
         const double *q2 = tp + tile_pidx(true, il, j0 + 2) * 64 + c0, *q3 = tp + tile_pidx(true, il, j0 + 3) * 64 + c0;
-        a0 = *reinterpret_cast<const double2 *>(q0); b0 = *reinterpret_cast<const double2 *>(q0 + 2);
-        a1 = *reinterpret_cast<const double2 *>(q1); b1 = *reinterpret_cast<const double2 *>(q1 + 2);
-        a2 = *reinterpret_cast<const double2 *>(q2); b2 = *reinterpret_cast<const double2 *>(q2 + 2);
-        a3 = *reinterpret_cast<const double2 *>(q3); b3 = *reinterpret_cast<const double2 *>(q3 + 2);
+        a0 = b0 = a1 = b1 = a2 = b2 = a3 = b3 = z2;
+        if (ok0) { a0 = *reinterpret_cast<const double2 *>(q0); b0 = *reinterpret_cast<const double2 *>(q0 + 2); }
+        if (ok1) { a1 = *reinterpret_cast<const double2 *>(q1); b1 = *reinterpret_cast<const double2 *>(q1 + 2); }
+        if (ok2) { a2 = *reinterpret_cast<const double2 *>(q2); b2 = *reinterpret_cast<const double2 *>(q2 + 2); }
+        if (ok3) { a3 = *reinterpret_cast<const double2 *>(q3); b3 = *reinterpret_cast<const double2 *>(q3 + 2); }
         return;
     }
     const int C = 36;
     const int pc0 = tile_pidx(dc, kl, l0), pc1 = tile_pidx(dc, kl, l0 + 1), pc2 = tile_pidx(dc, kl, l0 + 2), pc3 = tile_pidx(dc, kl, l0 + 3);
     const double *q0 = tp + tile_pidx(dr, il, j0) * C, *q1 = tp + tile_pidx(dr, il, j0 + 1) * C;
     const double *q2 = tp + tile_pidx(dr, il, j0 + 2) * C, *q3 = tp + tile_pidx(dr, il, j0 + 3) * C;
-    a0 = make_double2(q0[pc0], q0[pc1]); b0 = make_double2(q0[pc2], q0[pc3]);
-    a1 = make_double2(q1[pc0], q1[pc1]); b1 = make_double2(q1[pc2], q1[pc3]);
-    a2 = make_double2(q2[pc0], q2[pc1]); b2 = make_double2(q2[pc2], q2[pc3]);
-    a3 = make_double2(q3[pc0], q3[pc1]); b3 = make_double2(q3[pc2], q3[pc3]);
+    a0 = b0 = a1 = b1 = a2 = b2 = a3 = b3 = z2;
+    if (ok0) { a0 = make_double2(q0[pc0], q0[pc1]); b0 = make_double2(q0[pc2], q0[pc3]); }
+    if (ok1) { a1 = make_double2(q1[pc0], q1[pc1]); b1 = make_double2(q1[pc2], q1[pc3]); }
+    if (ok2) { a2 = make_double2(q2[pc0], q2[pc1]); b2 = make_double2(q2[pc2], q2[pc3]); }
+    if (ok3) { a3 = make_double2(q3[pc0], q3[pc1]); b3 = make_double2(q3[pc2], q3[pc3]); }
 }
 
 __global__ void jk_prep_kernel(double *__restrict__ work, const double *__restrict__ dm, int nao, int npad, int with_k) {
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(256) void jk_det_scale_kernel(double *__restrict__ 
     for (int i = t; i < nao; i += 256) {
         const long long b = i >> 3, IJ = b * (b + 1) / 2 + b;  // (ii|ii): tile (IJ, IJ) of the diagonal block pair (b, b)
         const int pa = tile_pidx(true, i & 7, i & 7);
-        g = fmax(g, fabs(tiles[tile_base((int)b, (int)b, (int)b, (int)IJ) + pa * 36 + pa]));
+        g = fmax(g, fabs(tiles[tile_base((int)b, (int)b, (int)b, (int)IJ, TileLay(nao)) + pa * 36 + pa]));
     }
     red[t] = g;
     __syncthreads();
@@ -131,7 +144,8 @@ __global__ __launch_bounds__(256) void jk_det_scale_kernel(double *__restrict__ 
 
 template <bool WITH_K>
 __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
-                                                       double *__restrict__ work, int npad, long long ntiles) {
+                                                       double *__restrict__ work, int npad, long long ntiles, int nao) {
+    const TileLay ly(nao);
     const double dsc = dscp ? *dscp : 0.0;  // deterministic mode: fixed-point scale of the accumulators (common.hpp: acc_add)
     constexpr int LDT = 68;  // row stride of the tile parked in LDS: 16-byte aligned rows, bank = 4 row + col (mod 32)
     __shared__ double s_col[4][64];
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
         double g[4][4];
         {
             double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
-            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3, ly);
             g[0][0] = ta0.x; g[0][1] = ta0.y; g[0][2] = tb0.x; g[0][3] = tb0.y;
             g[1][0] = ta1.x; g[1][1] = ta1.y; g[1][2] = tb1.x; g[1][3] = tb1.y;
             g[2][0] = ta2.x; g[2][1] = ta2.y; g[2][2] = tb2.x; g[2][3] = tb2.y;
@@ -267,7 +281,8 @@ __global__ __launch_bounds__(256, WITH_K ? 4 : 1) void jk_tiles_kernel(const dou
 // ---------------------------------------------------------------------------------------------
 template <int NK>
 __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
-                                                                   double *__restrict__ work, int npad, long long ntiles, int nj) {
+                                                                   double *__restrict__ work, int npad, long long ntiles, int nj, int nao) {
+    const TileLay ly(nao);
     const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     constexpr int NKD = NK ? NK : 1;
@@ -290,7 +305,7 @@ __global__ __launch_bounds__(256, NK ? 3 : 1) void jk_multi_kernel(const double 
         decode_tri((TT), ij_, kl_);                                                      \
         decode_tri(ij_, i_, j_);                                                         \
         decode_tri(kl_, k_, l_);                                                         \
-        tile_load_patch(tiles, ij_, kl_, i_, j_, k_, l_, r0, c0, na0, nb0, na1, nb1, na2, nb2, na3, nb3); \
+        tile_load_patch(tiles, ij_, kl_, i_, j_, k_, l_, r0, c0, na0, nb0, na1, nb1, na2, nb2, na3, nb3, ly); \
     }
     if ((long long)blockIdx.x < ntiles) JKM_LOAD(blockIdx.x)
     for (long long T = blockIdx.x; T < ntiles; T += gridDim.x) {
@@ -458,7 +473,8 @@ __global__ void jk_multi_finish_kernel(double *__restrict__ J, int nj, double *_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
                                                          double *__restrict__ work, int npad, long long ntiles, long long per_block,
-                                                         long long tbeg) {
+                                                         long long tbeg, int nao) {
+    const TileLay ly(nao);
     // (tiles [tbeg, ntiles): the whole store, or one rank's slice of it -- dqc_jk_from_tiles_part)
     const double dsc = dscp ? *dscp : 0.0;
     __shared__ double s_col[2][4][64];
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
         double cs[4] = {0, 0, 0, 0};
         {
             double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
-            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3, ly);
 #define DQC_JS_ROW(R_, A_, B_)                                                                           \
     rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                          \
     cs[0] += A_.x * dij[R_]; cs[1] += A_.y * dij[R_]; cs[2] += B_.x * dij[R_]; cs[3] += B_.y * dij[R_];
@@ -548,7 +564,8 @@ __global__ __launch_bounds__(256, 1) void j_stream_kernel(const double *__restri
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
                                                           double *__restrict__ work, int npad, long long ntiles, long long per_block,
-                                                          long long tbeg) {
+                                                          long long tbeg, int nao) {
+    const TileLay ly(nao);
     const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     __shared__ double s_col[4][64];  // (single buffer: two barriers per tile separate its writers and readers anyway)
@@ -604,7 +621,7 @@ __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restr
         double cs[4] = {0, 0, 0, 0};
         {
             double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
-            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3, ly);
 #define DQC_JS_ROW(R_, A_, B_)                                                                           \
     rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                          \
     cs[0] += A_.x * dij[R_]; cs[1] += A_.y * dij[R_]; cs[2] += B_.x * dij[R_]; cs[3] += B_.y * dij[R_]; \
@@ -690,7 +707,8 @@ __global__ __launch_bounds__(256, 4) void jk_stream_kernel(const double *__restr
 template <int NJ, int NK>
 __global__ __launch_bounds__(256, 3) void jk_multi_stream_kernel(const double *__restrict__ dscp, const double *__restrict__ tiles,
                                                                 double *__restrict__ work, int npad, long long ntiles,
-                                                                long long per_block) {
+                                                                long long per_block, int nao) {
+    const TileLay ly(nao);
     const double dsc = dscp ? *dscp : 0.0;
     constexpr int LDT = 68;
     __shared__ double s_col[4][64];  // (single buffer: two barriers per tile separate its writers and readers anyway)
@@ -752,7 +770,7 @@ __global__ __launch_bounds__(256, 3) void jk_multi_stream_kernel(const double *_
         double cs[4] = {0, 0, 0, 0};
         {
             double2 ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3;
-            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3);
+            tile_load_patch(tiles, IJ, KL, I, J, K, L, r0, c0, ta0, tb0, ta1, tb1, ta2, tb2, ta3, tb3, ly);
 #define DQC_JS_ROW(R_, A_, B_)                                                                           \
     if (NJ) {                                                                                            \
         rsacc[R_] += A_.x * dkl[0] + A_.y * dkl[1] + B_.x * dkl[2] + B_.y * dkl[3];                      \
@@ -873,7 +891,7 @@ long long dqc_eri_tile_offset(int nao, long long tile) {
     tri(tile, IJ, KL);
     tri(IJ, I, J);
     tri(KL, K, L);
-    return tile_base((int)I, (int)J, (int)K, (int)KL);
+    return tile_base((int)I, (int)J, (int)K, (int)KL, TileLay(nao));
 }
 
 int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm, int nao,
@@ -919,17 +937,17 @@ int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part,
         // cc-pVDZ and naphthalene / cc-pVTZ: flat within 3 % inside this window)
         const long long nblk = std::min<long long>(nrun, std::max<long long>(1024, std::min<long long>(6144, nrun / 8)));
         const long long per = (nrun + nblk - 1) / nblk;
-        hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg);
+        hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg, nao);
     } else if (with_k) {
-        hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
+        hipLaunchKernelGGL(jk_tiles_kernel<true>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, nao);
     } else if (jimpl && jimpl[0] == 's') {
-        hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles);
+        hipLaunchKernelGGL(jk_tiles_kernel<false>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, nao);
     } else {
         // contiguous tile ranges, ~6 resident blocks per CU x 2 rounds.  (Tried: 8 x 4 tile rectangles with the column sums in
         // LDS, 24 atomics per tile and no barrier -- 0.396 ms against 0.37 ms for this form: shorter contiguous runs.)
         const long long nblk = std::min<long long>(nrun, 256 * 12);
         const long long per = (nrun + nblk - 1) / nblk;
-        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg);
+        hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg, nao);
     }
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad, dscp);
@@ -970,13 +988,13 @@ int dqc_jk_from_tiles_multi(double *d_J, const double *d_dmJ, int nj, double *d_
         const dim3 grid_s((unsigned)((ntiles + per_s - 1) / per_s));
         static const char *mimpl = getenv("DQC_JK_MULTI_IMPL");  // "grid": the grid-stride kernel (A/B runs)
         const bool stream_ok = njp <= 1 && nkp >= 1 && !(mimpl && mimpl[0] == 'g');
-        if (stream_ok && njp == 1 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
-        else if (stream_ok && njp == 1 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
-        else if (stream_ok && njp == 0 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
-        else if (stream_ok && njp == 0 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s);
-        else if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
-        else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
-        else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp);
+        if (stream_ok && njp == 1 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s, nao);
+        else if (stream_ok && njp == 1 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<1, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s, nao);
+        else if (stream_ok && njp == 0 && nkp == 2) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 2>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s, nao);
+        else if (stream_ok && njp == 0 && nkp == 1) hipLaunchKernelGGL((jk_multi_stream_kernel<0, 1>), grid_s, dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per_s, nao);
+        else if (nkp == 2) hipLaunchKernelGGL(jk_multi_kernel<2>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp, nao);
+        else if (nkp == 1) hipLaunchKernelGGL(jk_multi_kernel<1>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp, nao);
+        else hipLaunchKernelGGL(jk_multi_kernel<0>, dim3(grid), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, njp, nao);
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(jk_multi_finish_kernel, dim3(64), dim3(256), 0, st, d_J, njp, d_K + (size_t)kdone * nn, nkp, d_work, nao, npad, dscp);
         DQC_CHECK_LAUNCH();

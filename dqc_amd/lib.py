@@ -446,11 +446,29 @@ class DirectContext:
 
 
 def tile_slice(nao, part, nparts):
-    """(tile_begin, tile_end, doubles) of the `part`-th of `nparts` contiguous slices of the packed tile store, equal in tiles"""
-    nt = int(load().dqc_eri_tile_count(int(nao)))
-    t0, t1 = nt * part // nparts, nt * (part + 1) // nparts
+    """(tile_begin, tile_end, doubles) of the `part`-th of `nparts` contiguous slices of the packed tile store, equal in DOUBLES to
+    within a tile (the tiles differ in size: diagonal block pairs, the truncated last block row), i.e. equal streaming work"""
     L = load()
-    return t0, t1, int(L.dqc_eri_tile_offset(int(nao), t1) - L.dqc_eri_tile_offset(int(nao), t0))
+    nao = int(nao)
+    nt = int(L.dqc_eri_tile_count(nao))
+    tot = int(L.dqc_eri_tile_offset(nao, nt))
+
+    def cut(k):  # first tile whose offset reaches k / nparts of the store (bisection on the monotone offset function)
+        if k <= 0:
+            return 0
+        if k >= nparts:
+            return nt
+        want, lo, hi = tot * k // nparts, 0, nt
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if int(L.dqc_eri_tile_offset(nao, mid)) < want:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo
+
+    t0, t1 = cut(part), cut(part + 1)
+    return t0, t1, int(L.dqc_eri_tile_offset(nao, t1) - L.dqc_eri_tile_offset(nao, t0))
 
 
 def eri_tiles_part(tab, device, t0, t1):

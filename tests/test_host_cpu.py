@@ -38,7 +38,30 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.dqc_eri_tile_count(208) == npair * (npair + 1) // 2
     L.dqc_eri_store_doubles.restype = ctypes.c_size_t
     # packed store: diagonal block pairs keep 36 of their 64 rows / columns
-    assert L.dqc_eri_store_doubles(7) == 36 * 36 and L.dqc_eri_store_doubles(16) == 36 * 36 + 64 * (36 + 64) + 36 * (36 + 64 + 36)
+    # ... and the pairs of the last block keep only the rows of real AOs (nao = 8 last + wl: 8 wl resp. wl (wl + 1) / 2 rows)
+    assert L.dqc_eri_store_doubles(7) == 28 * 36 and L.dqc_eri_store_doubles(16) == 36 * 36 + 64 * (36 + 64) + 36 * (36 + 64 + 36)
+    L.dqc_eri_tile_offset.argtypes = [ctypes.c_int, ctypes.c_longlong]
+    L.dqc_eri_tile_offset.restype = ctypes.c_longlong
+    for nao in (1, 9, 17, 23, 114, 120, 121, 412):  # explicit prefix sums over the block pairs
+        nb_ = (nao + 7) // 8
+        last, wl = nb_ - 1, nao - 8 * (nb_ - 1)
+        tot, P, tile = 0, 0, 0
+        for x in range(nb_):
+            for y in range(x + 1):
+                r = (wl * (wl + 1) // 2 if x == y else 8 * wl) if (x == last and wl < 8) else (36 if x == y else 64)
+                if nao <= 23:  # every tile offset of the small stores
+                    for kl in range(P + 1):
+                        kk = int(((8 * kl + 1) ** 0.5 - 1) / 2)
+                        while kk * (kk + 1) // 2 > kl:
+                            kk -= 1
+                        while (kk + 1) * (kk + 2) // 2 <= kl:
+                            kk += 1
+                        assert L.dqc_eri_tile_offset(nao, tile) == tot + r * (64 * kl - 28 * kk), (nao, x, y, kl)
+                        tile += 1
+                tot += r * (64 * (P + 1) - 28 * (x + (x == y)))
+                P += 1
+        assert L.dqc_eri_store_doubles(nao) == tot, nao
+    assert L.dqc_eri_store_doubles(114) * 8 / 114 ** 4 < 1.04  # benzene / cc-pVDZ: 1.26 x nao^4 bytes with a full last block
     assert 0.93 < L.dqc_eri_store_doubles(208) / (L.dqc_eri_tile_count(208) * 4096) < 0.94
     assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8 + 8  # D, J, K accumulators + the deterministic-mode scale slot
 
@@ -424,7 +447,7 @@ def test_prepare_orthogonalisers_batched_eigh_on_cpu():
 
 def test_tile_store_slices_partition_the_store_host_arithmetic():
     """dqc_eri_tile_offset / lib.tile_slice (host arithmetic of the packed tile store, no GPU needed): offsets grow tile by tile
-    by 36 x 36, 36 x 64, 64 x 36 or 64 x 64 doubles (diagonal block pairs keep their i >= j elements), the last offset is the
+    by 36 x 36, 36 x 64, 64 x 36 or 64 x 64 doubles (diagonal block pairs keep their i >= j elements; fewer rows in the last block row), the last offset is the
     store size, and the N slices of lib.tile_slice partition the tiles and the doubles for every N"""
     from dqc_amd import lib
     L = lib.load()
@@ -436,7 +459,8 @@ def test_tile_store_slices_partition_the_store_host_arithmetic():
         offs = [int(L.dqc_eri_tile_offset(nao, t)) for t in range(nt + 1)]
         assert offs[0] == 0 and offs[-1] == lib.eri_store_doubles(nao)
         sizes = {b - a for a, b in zip(offs[:-1], offs[1:])}
-        assert sizes <= {36 * 36, 36 * 64, 64 * 36, 64 * 64} and min(sizes) > 0
+        wl = nao - 8 * (nb - 1)  # the pairs of the last block keep the rows of real AOs only: 8 wl resp. wl (wl + 1) / 2
+        assert sizes <= {r * c for r in (36, 64, 8 * wl, wl * (wl + 1) // 2) for c in (36, 64)} and min(sizes) > 0
         assert int(L.dqc_eri_tile_offset(nao, nt + 5)) == offs[-1] and int(L.dqc_eri_tile_offset(nao, -3)) == 0
         for nparts in (1, 2, 3, 8, 50):
             sl = [lib.tile_slice(nao, r, nparts) for r in range(nparts)]
