@@ -75,6 +75,12 @@ def main():
                     help="self-test of the N-rank launch path only (rendezvous + one all_reduce, no GPU work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not (args.all_ranks_on_gpu0 or args.launch_check) and torch.cuda.device_count() < args.gpus:
+        # fewer devices than ranks: ONE JSON line saying so (before any rendezvous: nothing can hang) and a non-zero exit
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"error": "--gpus %d but %d device(s) visible" % (args.gpus, torch.cuda.device_count()),
+                              "n_gpus": args.gpus, "devices_visible": torch.cuda.device_count()}), flush=True)
+        raise SystemExit(2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started from a bare shell (`python bench.py --gpus N`): become the launcher -- one rank per GPU under
         # torch.distributed.run, rendezvous on 127.0.0.1; rank 0 of the children prints the ONE JSON line
@@ -546,7 +552,7 @@ def one_molecule_sharded_leg(dev, rank, world, timeout_s):
             res["fock_checksum_spread_over_ranks"] = float(chk[0] + chk[1])
             res.update({"ranks": world, "nao": int(h._nao_ao), "tile_store_gb_per_rank": h._tiles.numel() * 8 / 1e9,
                         "grid_points_per_rank": int(h.rgrid.shape[0]), "collectives_per_build": 1,
-                        "all_reduce_bytes_per_build": int(8 * (h._nao_ao ** 2 + h._ld ** 2 + 1025)),
+                        "all_reduce_bytes_per_build": int(8 * (h._nao_ao ** 2 + h._ld ** 2 + 1)),
                         "note": "C4 naphthalene RKS PBE / cc-pVTZ sg3, one molecule on all ranks: tile store and grid sliced over "
                                 "the ranks, partial J + Vxc + E_xc summed with one all_reduce per Fock build"})
             del eng, mol, h

@@ -114,6 +114,13 @@ def run_concurrent(qcs, max_inflight: int = 16, **run_kwargs):
     SURVEY.md 7 step 6 / 8e ("each rank: own HIP streams").  `qcs`: built HF / KS objects on one device; returns them."""
     if not qcs:
         return qcs
+    for q in qcs:
+        # every rank of a sharded Hamiltonian must take the same branches (its Fock builds hold collectives): this driver reads each
+        # generator's scalars on the local rank only -- use qc.run(), which broadcasts rank 0's
+        for e in getattr(q, "engines", None) or [q._engine]:
+            if getattr(getattr(e, "hamilton", None), "sharded", False):
+                raise RuntimeError("run_concurrent / run_lockstep cannot drive a Hamiltonian sharded over several GPUs (shard_over): "
+                                   "call qc.run() on every rank instead")
     dev = qcs[0]._engine.device
     n_in = max(1, min(max_inflight, len(qcs)))
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_in)]

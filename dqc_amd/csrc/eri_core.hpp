@@ -1,6 +1,7 @@
 // eri_core.hpp -- the Rys-quadrature shell-quartet kernel shared by the 4-centre ERI fill (eri.hip) and the
 // density-fitting integrals (df.hip).  See eri.hip for the design notes.
 #pragma once
+#include <atomic>
 #include <algorithm>
 
 #include "common.hpp"
@@ -19,13 +20,13 @@ const std::vector<double> &boys_table_host();       // host.hip
 
 // upload of this translation unit's copy, once per device
 static int boys_table_ensure() {
-    static bool done[64];
+    static std::atomic<bool> done[64];  // (two threads racing here both upload the same table: harmless)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DQC_EHIP;
-    if (done[dev]) return 0;
+    if (done[dev].load(std::memory_order_acquire)) return 0;
     const std::vector<double> &tab = boys_table_host();
     DQC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_boys_tab), tab.data(), sizeof(double) * BOYS_DOUBLES));
-    done[dev] = true;
+    done[dev].store(true, std::memory_order_release);
     return 0;
 }
 

@@ -1,4 +1,5 @@
 // host.hip -- error handling, table parsing and small utilities of libdqc_amd.so
+#include <atomic>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -37,15 +38,20 @@ const std::vector<double> &boys_table_host() {
     return tab;
 }
 
-static bool g_deterministic = false;
-bool deterministic_mode() { return g_deterministic; }
-static int g_generic_eri = -1;  // -1: not set (environment DQC_ERI_GENERIC decides)
+// process-wide switches, read by every entry point from whatever thread calls it: atomics
+static std::atomic<bool> g_deterministic{false};
+bool deterministic_mode() { return g_deterministic.load(std::memory_order_relaxed); }
+static std::atomic<int> g_generic_eri{-1};  // -1: not set (environment DQC_ERI_GENERIC decides)
 bool generic_eri_forced() {
-    if (g_generic_eri < 0) {
+    int v = g_generic_eri.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char *e = std::getenv("DQC_ERI_GENERIC");
-        g_generic_eri = (e && e[0] == '1') ? 1 : 0;
+        v = (e && e[0] == '1') ? 1 : 0;
+        int expect = -1;
+        g_generic_eri.compare_exchange_strong(expect, v);  // (a concurrent dqc_set_generic_eri wins)
+        v = g_generic_eri.load(std::memory_order_relaxed);
     }
-    return g_generic_eri == 1;
+    return v == 1;
 }
 
 // ---- pinned staging blocks of the stream-ordered DevPool ----
@@ -152,17 +158,15 @@ int dqc_set_deterministic(int on) {
     // process-wide: the cross-block accumulations of the Fock build (J / K accumulators, split-K Vxc partial sums, the trace of
     // the purification iterate) switch from fp64 atomics to fixed-point integer atomics (common.hpp: acc_add), which makes
     // every result bit-reproducible from run to run.  Returns the previous setting.
-    const int prev = dqc::g_deterministic ? 1 : 0;
-    dqc::g_deterministic = on != 0;
-    return prev;
+    return dqc::g_deterministic.exchange(on != 0) ? 1 : 0;
 }
-int dqc_get_deterministic(void) { return dqc::g_deterministic ? 1 : 0; }
+int dqc_get_deterministic(void) { return dqc::deterministic_mode() ? 1 : 0; }
 
 int dqc_set_generic_eri(int on) {
     // process-wide: every shell-quartet class through the runtime-angular-momentum kernel (eri_generic.hpp) instead of only the
     // classes with a g shell -- the cross-check of the two implementations.  Returns the previous setting.
     const int prev = dqc::generic_eri_forced() ? 1 : 0;
-    dqc::g_generic_eri = on != 0;
+    dqc::g_generic_eri.store(on != 0 ? 1 : 0);
     return prev;
 }
 int dqc_version(void) { return 100; }

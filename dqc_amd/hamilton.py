@@ -133,7 +133,17 @@ class HamiltonMI355(_Base):
                 self._fill_done = None
             else:
                 torch.cuda.current_stream(self.device).wait_event(ev)
-        return self._tiles_store
+        t = self._tiles_store
+        if t is not None and not torch.cuda.is_current_stream_capturing():
+            # the store was allocated on the setup side stream's pool: every stream that streams it (run_concurrent / lockstep side
+            # streams) is recorded, so that the caching allocator does not hand the block to the next molecule's fill while a J / K
+            # kernel of a dropped Hamiltonian is still reading it
+            cur = torch.cuda.current_stream(self.device)
+            seen = self.__dict__.setdefault("_tile_streams", set())
+            if cur.cuda_stream not in seen:
+                seen.add(cur.cuda_stream)
+                t.record_stream(cur)
+        return t
 
     @property
     def nao(self) -> int:
@@ -178,6 +188,12 @@ class HamiltonMI355(_Base):
                     "are free: use eri='direct' (DQC_AMD_ERI=direct: the integrals are re-evaluated in every Fock build) or the "
                     "density-fitted Coulomb operator (mol.densityfit(method='coulomb', auxbasis=...))" % (need / 1e9, tab.nao, free / 1e9))
             self._direct = mode == "direct"
+            if self._eri_mode == "auto" and self._direct:
+                import warnings
+                warnings.warn("the ERI tile store of this basis (nao = %d: %.1f GB) does not fit the %.1f GB of device memory that are "
+                              "free: direct SCF (integrals re-evaluated in every Fock build, no hipGraph / lockstep step); "
+                              "DQC_AMD_ERI=tiles insists on the store" % (tab.nao, need / 1e9, free / 1e9))
+            self.eri_mode_used = mode
         if self._df is None and self._direct:
             # direct SCF: no tile store; every J / K call re-evaluates the shell quartets -- those the
             # Schwarz bounds do not rule out (dqc_direct_*: tables and bounds stay on the device)
@@ -223,6 +239,9 @@ class HamiltonMI355(_Base):
         if family not in (1, 2, 4):
             raise RuntimeError("unknown xc family %s" % family)
         if self.is_grid_set and getattr(self, "grid", None) is grid and family == self.xcfamily:
+            if xc is not self.xc:  # another functional on the resident AO values: what was remembered of the old one goes
+                self._energy_memo = None
+                self._jk_cache = None
             self.xc = xc  # same grid, same derivative level: the AO values are already resident
             return
         self.xc = xc
@@ -325,6 +344,9 @@ class HamiltonMI355(_Base):
         self._prank, self._pworld = dist.get_rank(group), dist.get_world_size(group)
         if eri not in ("direct", "tiles"):
             raise RuntimeError("shard_over: eri must be 'direct' or 'tiles'")
+        if lib.load().dqc_get_deterministic():
+            # (tiles: the fixed-point scale reads the diagonal tiles of the WHOLE store; direct: fp64 atomics only)
+            raise RuntimeError("shard_over: the deterministic mode (dqc_set_deterministic) covers unsharded Hamiltonians only")
         self._eri_mode = eri
         self._tile_slice = None
         return self
@@ -706,19 +728,23 @@ class HamiltonMI355(_Base):
             dao = self._unconvert_dm(dm)
         if self._tile_slice is not None:  # tile store spread over the ranks: J, Vxc and E_xc parts travel in one all_reduce
             self._deferred = []
-        if self._df is not None:
-            jao = self._df.coulomb_ao(dao)
-        else:
-            jao, _ = self._jk_ao(dao, False)
-        densinfo = self._dm2densinfo(dm)
-        if hasattr(self.xc, "get_vxc_and_exc"):  # potentials and the E_xc quadrature from one pass over the grid
-            potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
-            self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
-        else:
-            potinfo, exc = self.xc.get_vxc(densinfo), None
-        vm = self._vxc_ao_from_potinfo(potinfo)
-        if self._deferred is not None:
-            self._allsum_flush()
+        try:
+            if self._df is not None:
+                jao = self._df.coulomb_ao(dao)
+            else:
+                jao, _ = self._jk_ao(dao, False)
+            densinfo = self._dm2densinfo(dm)
+            if hasattr(self.xc, "get_vxc_and_exc"):  # potentials and the E_xc quadrature from one pass over the grid
+                potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
+                exc = exc[:1]  # (the result; the rest of the buffer is the kernel's per-block scratch)
+                self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
+            else:
+                potinfo, exc = self.xc.get_vxc(densinfo), None
+            vm = self._vxc_ao_from_potinfo(potinfo)
+            if self._deferred is not None:
+                self._allsum_flush()
+        finally:
+            self._deferred = None  # (an exception in between must not leave later _allsum calls queued for ever)
         # the two-electron energies of THIS density fall out of the build (tr D J = tr D_ao J_ao): remembered under the
         # identity + version of `dm`, so that dm2energy(dm) right after dm2scp(dm) streams neither the tiles nor the grid again
         e_j = 0.5 * (dao * jao).sum()

@@ -51,6 +51,10 @@ def signature(qc):
     eng = qc._engine
     if getattr(eng, "ovlp", None) is not None:
         return None
+    # a Hamiltonian sharded over several GPUs issues collectives inside its Fock build: every rank has to take the same
+    # branches, which only SCF_QCCalc.run guarantees (it broadcasts rank 0's per-iteration scalars, hamilton.sync_scalars)
+    if getattr(eng.hamilton, "sharded", False):
+        return None
     ch = _spin_channels(eng)
     if ch is None:
         return None
