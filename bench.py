@@ -393,6 +393,9 @@ def main():
         out_extra["small_batch"] = small_batch_leg(dev)
         out_extra["direct_scf"] = direct_scf_leg(dev)
 
+    if extras and world == 1:
+        out_extra["f_rows"] = f_row_legs(dev)
+
     # N > 1 only, after everything that is timed for the headline: ONE molecule (C4) spread over the N ranks -- the path with a
     # data-path collective (last row).  Run under a watchdog: a wedged collective must not cost the line above.
     one_mol = None
@@ -415,8 +418,8 @@ def main():
         if args.df:  # two passes over the i >= j rows of j3c (dqc_df_coulomb) + inv_j2c
             naux = int(h0.df.j2c.shape[0])
             alg_bytes["jk_tiles"] = 2 * 4.0 * nao * (nao + 1) * naux + 8.0 * naux * naux + 2 * 8.0 * nao * nao
-        f_den = (2.0 * ngrid * ld * ld if dense else 4.0 * ngrid * ld * norb_pad) + 2.0 * c * ngrid * nao
-        f_vxc = 2.0 * ngrid * ld * ld + 2.0 * c * ngrid * nao
+        f_den = (2.0 * ngrid * nao * nao if dense else 4.0 * ngrid * nao * norb_pad) + 2.0 * c * ngrid * nao  # (algorithmic: nao, not the padded widths)
+        f_vxc = 2.0 * ngrid * nao * nao + 2.0 * c * ngrid * nao
         alg_flops = {
             # 2 G n^2 per GEMM pass (+ the row dots / Psi combination); J: 2 n^4 dense-equivalent
             # density: Phi . D (full matrix) or the two chained rank-n_occ GEMMs Phi . L, (Phi L) . L^T (factor form)
@@ -657,6 +660,146 @@ def small_batch_leg(dev):
                      "max_abs_energy_diff_ha": max(abs(a - b) for a, b in zip(res["lockstep"][1], res["one_molecule_drivers"][1]))}
         del mols, qcs
         torch.cuda.empty_cache()
+    return out
+
+
+def _entry_rooflines(tr_ms, nbuild, shape):
+    """per-entry-point rows from a lib.call_trace of `nbuild` Fock builds: calls per build, ms per call, algorithmic bytes / flops
+    (SURVEY.md 8d models: AO read once per pass, 2 G n^2 per GEMM pass, n^4 bytes of tiles, two passes over the i >= j rows of
+    j3c) and the fraction of the roof the call sits closer to.  An entry point may be several launches (prep / finish kernels)."""
+    n, G, r, naux = shape["nao"], shape["ngrid"], shape.get("norb_pad", 0), shape.get("naux", 0)
+    def model(name):
+        if name == "dqc_grid_density_lr":                 # two chained rank-r GEMMs, four AO components read
+            return 8.0 * 4 * G * n, 4.0 * G * n * r + 2.0 * 4 * G * n
+        if name == "dqc_grid_density_lr[value only]":     # phase 1 only, one component
+            return 8.0 * G * n, 2.0 * G * n * r
+        if name == "dqc_grid_density":
+            return 8.0 * 4 * G * n, 2.0 * G * n * n + 2.0 * 4 * G * n
+        if name == "dqc_grid_density[value only]":
+            return 8.0 * G * n, 2.0 * G * n * n
+        if name == "dqc_grid_density_pair":
+            return 8.0 * G * n, 2.0 * G * n * n
+        if name == "dqc_grid_vxc":
+            return 8.0 * 4 * G * n, 2.0 * G * n * n + 4.0 * 4 * G * n
+        if name in ("dqc_grid_vxc[no gradient term]", "dqc_grid_vxc_pair"):  # one operand: symmetric, the upper triangle only
+            return 8.0 * G * n, 1.0 * G * n * n
+        if name.startswith("dqc_xc_eval"):
+            return 8.0 * G * 9, 0.0
+        if name in ("dqc_jk_from_tiles", "dqc_jk_from_tiles_part", "dqc_jk_from_tiles_multi"):
+            return float(n) ** 4, 2.0 * float(n) ** 4
+        if name == "dqc_df_coulomb":
+            return 2 * 4.0 * n * (n + 1) * naux + 8.0 * naux * naux, 2 * 2.0 * n * (n + 1) / 2 * naux
+        return None
+
+    rows = []
+    for name, (calls, ms) in sorted(tr_ms.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        row = {"entry": name, "calls_per_build": calls / nbuild, "ms_per_call": ms}
+        m = model(name)
+        if m is not None and ms > 0:
+            gbs, tfs = m[0] / ms / 1e6, m[1] / ms / 1e9
+            mf = tfs / F64_MFMA_PEAK_TF > gbs / HBM_PEAK_GBS
+            row.update({"algorithmic_bytes": m[0], "algorithmic_flops": m[1], "bound": "mfma" if mf else "hbm",
+                        "achieved": tfs if mf else gbs, "unit": "TFLOP/s" if mf else "GB/s",
+                        "frac": tfs / F64_MFMA_PEAK_TF if mf else gbs / HBM_PEAK_GBS})
+        rows.append(row)
+    return rows
+
+
+def f_row_legs(dev, K=10):
+    """SURVEY.md 8 'next' rows on the clock, ONE C5 molecule each, steady-state Fock builds dm2scp(ao_orb2dm(C))
+    timed with HIP events + a lib.call_trace pass for the per-entry rooflines:
+       uks_pbe   unrestricted KS, two-spin grid pass (hcgto.py:260-269 polarised branch, hf.py:93-103)
+       scan      meta-GGA: tau from the factor kernel, the three tau Vxc terms through the one-operand pair form (hcgto.py:420-438, 473-489)
+       df_lda    the reference's own 20-atom benchmark call (dqc/test/benchmark.py:40-42): Mol(...).densityfit() + lda_x+lda_c_pw,
+                 with the energy error of the generated auxiliary set against exact J
+       gradient  nuclear gradient of the converged RKS PBE energy (scf_qccalc.py:63-67 by autograd there)"""
+    import warnings
+    import dqc_amd
+    from dqc_amd import lib
+    from tests import molecules as M
+    geo = M.c5_molecule(0)
+    out = {}
+
+    def steady(qc, pol):
+        eng, h = qc._engine, qc._engine.hamilton
+        n = eng.shape[-1]
+        z = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        from dqc_amd.utils.datastruct import SpinParam
+        dm = eng.scp2dm(eng.dm2scp(SpinParam(u=z, d=z) if pol else z))
+        f = eng.dm2scp(dm)
+        if pol:  # (F_u, F_d) stacked: each spin channel's own lowest orbitals (hf.py:105-113)
+            orbs = [eng._eigvecs(f[0])[..., :eng.norb.u].contiguous(), eng._eigvecs(f[1])[..., :eng.norb.d].contiguous()]
+        else:
+            orbs = eng.scp2orb(f).contiguous()
+
+        def build():
+            if pol:
+                d = SpinParam(u=h.ao_orb2dm(orbs[0], eng.orb_weight.u), d=h.ao_orb2dm(orbs[1], eng.orb_weight.d))
+            else:
+                d = h.ao_orb2dm(orbs, eng.orb_weight)
+            return eng.dm2scp(d)
+
+        for _ in range(3):
+            build()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            build()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        with lib.call_trace() as tr:
+            for _ in range(3):
+                build()
+        shape = {"nao": h._nao_ao, "ngrid": int(h.rgrid.shape[0]), "ncomp": 1 if h.xcfamily == 1 else 4,
+                 "norb_pad": lib.padded_norb(int((orbs[0] if pol else orbs).shape[1])),
+                 "naux": int(h.df.j2c.shape[0]) if h.df is not None else 0}
+        return ms, _entry_rooflines(tr.ms(), 3, shape), shape
+
+    try:
+        qc = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc=XC, restricted=False)
+        ms, rows, shape = steady(qc, True)
+        out["uks_pbe"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": rows, "shape": shape,
+                          "what": "C5 molecule 0, unrestricted KS PBE: J[D_u + D_d], two factor-form densities, spin-polarised functional, two Vxc matrices"}
+        del qc
+        qc = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc="mgga_x_scan+mgga_c_scan")
+        ms, rows, shape = steady(qc, False)
+        out["scan"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": rows, "shape": shape,
+                       "what": "C5 molecule 0, RKS SCAN (meta-GGA): density + tau from the factor, Vxc + three tau terms"}
+        del qc
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mdf = dqc_amd.Mol(geo, basis="cc-pvdz", device=dev).densityfit()
+        qdf = dqc_amd.KS(mdf, xc="lda_x+lda_c_pw")
+        ms, rows, shape = steady(qdf, False)
+        t0 = time.perf_counter()
+        qdf.run()
+        e_df, t_df = float(qdf.energy()), time.perf_counter() - t0
+        qex = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", device=dev), xc="lda_x+lda_c_pw")
+        t0 = time.perf_counter()
+        qex.run()
+        e_ex, t_ex = float(qex.energy()), time.perf_counter() - t0
+        out["df_lda"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": rows, "shape": shape,
+                         "auxbasis": "autoaux (generated from cc-pVDZ: the reference's default cc-pvtz-jkfit is external data)",
+                         "scf_s": t_df, "scf_iterations": qdf.niter, "energy_ha": e_df, "exact_j_energy_ha": e_ex,
+                         "energy_error_vs_exact_j_ha": e_df - e_ex, "exact_j_scf_s": t_ex,
+                         "what": "the reference's own 20-atom benchmark call (dqc/test/benchmark.py:40-42): "
+                                 "KS(Mol(vitamin C, 'cc-pvdz').densityfit(), 'lda_x+lda_c_pw')"}
+        del qdf, qex, mdf
+        qg = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc=XC).run()
+        qg.nuclear_gradient()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        g = qg.nuclear_gradient()
+        torch.cuda.synchronize()
+        out["gradient"] = {"seconds": time.perf_counter() - t0, "sum_of_forces_abs_max": float(g.sum(0).abs().max()),
+                           "what": "C5 molecule 0, analytic nuclear gradient of the converged RKS PBE energy (derivative ERIs, int1e, XC terms)"}
+        del qg
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        out["error"] = repr(e)[:300] + " | " + traceback.format_exc()[-600:]
+    torch.cuda.empty_cache()
     return out
 
 

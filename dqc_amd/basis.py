@@ -44,13 +44,26 @@ def loadbasis(cmd: str, dtype=torch.float64, device=torch.device("cpu"), require
     return [dataclasses.replace(b) for b in _BASIS_CACHE[key]]
 
 
+def _basis_file(name: str, atomz: int):
+    """the Gaussian94 table of (basis, element): dqc_amd/data/basis/<normalised name>/<ZZ>.gaussian94, then the same layout under
+    every directory of $DQC_AMD_BASIS_PATH (os.pathsep-separated) -- where tables from basis_set_exchange can be dropped in, the
+    file naming of the reference's own cache (loadbasis.py:89-122); None when there is none"""
+    sub = os.path.join(_normalize_basisname(name.strip()), "%02d.gaussian94" % atomz)
+    for root in [_DATA] + [d for d in os.environ.get("DQC_AMD_BASIS_PATH", "").split(os.pathsep) if d]:
+        f = os.path.join(root, sub)
+        if os.path.exists(f):
+            return f
+    return None
+
+
 def _loadbasis(cmd: str, dtype, device) -> List[CGTOBasis]:
     atomz_str, raw = cmd.split(":")
     atomz = int(atomz_str)
-    fpath = os.path.join(_DATA, _normalize_basisname(raw.strip()), "%02d.gaussian94" % atomz)
-    if not os.path.exists(fpath):
-        raise RuntimeError("The %s basis for atomz %d is not shipped with dqc_amd (%s) and cannot be "
-                           "downloaded here" % (raw, atomz, fpath))
+    fpath = _basis_file(raw, atomz)
+    if fpath is None:
+        raise RuntimeError("The %s basis for atomz %d is not shipped with dqc_amd (%s) and cannot be downloaded here; "
+                           "Gaussian94 tables from basis_set_exchange can be put under $DQC_AMD_BASIS_PATH/<name>/<ZZ>.gaussian94"
+                           % (raw, atomz, os.path.join(_DATA, _normalize_basisname(raw.strip()), "%02d.gaussian94" % atomz)))
     with open(fpath) as f:
         lines = f.read().split("\n")
     while True:
@@ -148,10 +161,76 @@ def even_tempered_aux(atomz: int, beta: float = 2.5, dtype=torch.float64) -> Lis
     return out
 
 
-def make_aux_atombases(atomzs, atompos, auxbasis) -> List[AtomCGTOBasis]:
-    if isinstance(auxbasis, str) and auxbasis.lower().startswith("etb"):
-        beta = float(auxbasis.split(":")[1]) if ":" in auxbasis else 2.5
-        auxbasis = [even_tempered_aux(int(z), beta) for z in atomzs]
+def product_etb_aux(atomz: int, orb_bases: List[CGTOBasis], beta: float = 2.0, dtype=torch.float64) -> List[CGTOBasis]:
+    """Auxiliary (Coulomb-fitting) basis GENERATED from the atom's orbital basis, auxbasis="autoaux[:beta]" -- the stand-in for
+    the named JK-fit sets, which are external data that cannot be fetched here.  Products of two orbital functions on one
+    centre carry exponents a1 + a2 and angular momenta |l1 - l2| ... l1 + l2 (step 2), so for every auxiliary l up to
+        l_aux = min(max(2 l_occ, l_basis) + 1, 4)          (l_occ: highest occupied atomic shell, l_basis: highest orbital shell)
+    an even-tempered, uncontracted row  a_k = lo beta^k  spans [lo, hi]:
+        lo = the smallest a1 + a2 over the pairs that reach l,
+        hi = the largest a1 + a2 over those pairs, capped at  2 a_s,max / (c 8^l)  (c = 15 behind a 1s core; H / He: 2 and a
+             factor 3 per l): the optimised fitting sets stop one to two decades below the tightest orbital products
+             -- core-core products that barely move valence energies -- and so does this one.
+    Accuracy against the exact Coulomb operator is measured in tests / bench (`df` leg); the round-1 "etb" set stays available."""
+    import math
+    emin, emax = {}, {}
+    for b in orb_bases:
+        a = b.alphas.detach().cpu()
+        l = int(b.angmom)
+        emin[l] = min(emin.get(l, float("inf")), float(a.min()))
+        emax[l] = max(emax.get(l, 0.0), float(a.max()))
+    ls = sorted(emin)
+    l_occ = 0 if atomz <= 4 else 1
+    l_aux = min(max(2 * l_occ, ls[-1]) + 1, 4)
+    light = atomz <= 2
+    out = []
+    for l in range(l_aux + 1):
+        pairs = [(a, b) for a in ls for b in ls if a <= b and abs(a - b) <= l <= a + b and (a + b - l) % 2 == 0]
+        if not pairs:
+            pairs = [(a, b) for a in ls for b in ls if a <= b and a + b >= l]
+        if not pairs:
+            continue
+        lo = min(emin[a] + emin[b] for a, b in pairs)
+        hi = max(emax[a] + emax[b] for a, b in pairs)
+        hi = min(hi, 2.0 * emax[0] / ((2.0 if light else 15.0) * (3.0 if light else 8.0) ** l))
+        if hi < lo:
+            hi = lo
+        n = int(math.floor(math.log(hi / lo) / math.log(beta) + 1e-9)) + 1
+        for k in range(n):
+            sh = CGTOBasis(angmom=l, alphas=torch.tensor([lo * beta ** k], dtype=dtype), coeffs=torch.tensor([1.0], dtype=dtype))
+            sh.wfnormalize_()
+            out.append(sh)
+    return out
+
+
+_FIT_NAMES = ("jkfit", "jfit", "rifit", "ri", "autoaux")
+
+
+def make_aux_atombases(atomzs, atompos, auxbasis, orb_atombases=None) -> List[AtomCGTOBasis]:
+    """auxbasis: per-atom lists of CGTOBasis, a basis name with Gaussian94 tables under dqc_amd/data/basis or $DQC_AMD_BASIS_PATH,
+    "etb[:beta]" (fixed even-tempered rows) or "autoaux[:beta]" (generated from the orbital basis, product_etb_aux).  A NAMED
+    fitting set ("cc-pvtz-jkfit", the reference's default, mol.py:190-193; "def2-universal-jkfit", ...) whose tables are not
+    there falls back to "autoaux" with a warning -- the reference would download it from basis_set_exchange."""
+    if isinstance(auxbasis, str):
+        name = auxbasis.lower()
+        if name.startswith("etb"):
+            beta = float(auxbasis.split(":")[1]) if ":" in auxbasis else 2.5
+            auxbasis = [even_tempered_aux(int(z), beta) for z in atomzs]
+        else:
+            gen = name.startswith("autoaux")
+            if not gen and any(t in name for t in _FIT_NAMES):
+                missing = [int(z) for z in atomzs if _basis_file(auxbasis, int(round(float(z)))) is None]
+                if missing:
+                    import warnings
+                    warnings.warn("auxiliary basis %r: no table for Z = %s under dqc_amd/data/basis or $DQC_AMD_BASIS_PATH (the named "
+                                  "fitting sets are external data, not shipped); using the generated set auxbasis='autoaux' instead"
+                                  % (auxbasis, sorted(set(missing))))
+                    gen = True
+            if gen:
+                if orb_atombases is None:
+                    raise RuntimeError("auxbasis='autoaux' is generated from the orbital basis: pass the orbital atom bases")
+                beta = float(auxbasis.split(":")[1]) if (name.startswith("autoaux") and ":" in auxbasis) else 2.0
+                auxbasis = [product_etb_aux(int(round(float(z))), ob.bases, beta) for z, ob in zip(atomzs, orb_atombases)]
     return make_atombases(atomzs, atompos, auxbasis)
 
 

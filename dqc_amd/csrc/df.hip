@@ -150,6 +150,20 @@ __global__ __launch_bounds__(256) void df_rhs_kernel(double *__restrict__ t, con
         soff[threadIdx.x] = off;
     }
     __syncthreads();
+    if ((naux & 1) == 0) {  // rows are 16-byte aligned: two auxiliary functions per lane and load
+        for (int k = 2 * threadIdx.x; k < naux; k += 512) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < DF_ROWS; r++) {
+                const double2 v = *reinterpret_cast<const double2 *>(j3c + soff[r] + k);
+                a0 += sw[r] * v.x;
+                a1 += sw[r] * v.y;
+            }
+            atomicAdd(&t[k], a0);
+            atomicAdd(&t[k + 1], a1);
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < naux; k += 256) {
         double acc = 0.0;
 #pragma unroll 8
@@ -178,7 +192,13 @@ __global__ __launch_bounds__(256) void df_j_kernel(double *__restrict__ jmat, co
     tri_decode(q, i, j);
     const double *row = j3c + ((size_t)i * nao + j) * naux;
     double acc = 0.0;
-    for (int k = lane; k < naux; k += 64) acc += row[k] * c[k];
+    if ((naux & 1) == 0) {
+        for (int k = 2 * lane; k < naux; k += 128) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + k), cc = *reinterpret_cast<const double2 *>(c + k);
+            acc += v.x * cc.x + v.y * cc.y;
+        }
+    } else
+        for (int k = lane; k < naux; k += 64) acc += row[k] * c[k];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if (lane == 0) {
         jmat[(size_t)i * nao + j] = acc;

@@ -84,6 +84,14 @@ DQC_DEV D5 log5(D5 a) { return chain(a, log(a.v), 1.0 / a.v); }
 DQC_DEV D5 atan5(D5 a) { return chain(a, atan(a.v), 1.0 / (1.0 + a.v * a.v)); }
 DQC_DEV D5 exp5(D5 a) { const double e = exp(a.v); return chain(a, e, e); }
 DQC_DEV D5 xasinhx5(D5 y) { double dg; const double v = xasinhx_val(y.v, dg); return chain(y, v, dg); }
+DQC_DEV D5 n_exp(D5 a) { return exp5(a); }
+DQC_DEV D5 n_log(D5 a) { return log5(a); }
+DQC_DEV D5 n_log1p(D5 a) { return log1p5(a); }
+DQC_DEV D5 n_sqrt(D5 a) { return sqrt5(a); }
+DQC_DEV D5 n_cbrt(D5 a) { return cbrt5(a); }
+DQC_DEV D5 n_pow(D5 a, double e) { return p5(a, e); }
+DQC_DEV D5 n_xasinhx(D5 a) { return xasinhx5(a); }
+DQC_DEV D5 n_floor(D5 a, double lo) { return a.v < lo ? c5(lo) : a; }
 DQC_DEV D5 operator*(D5 a, double b) { return b * a; }
 DQC_DEV D5 operator+(D5 a, double b) { return b + a; }
 DQC_DEV D5 operator-(D5 a, double b) { a.v -= b; return a; }
@@ -196,6 +204,18 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                     const double ka = id_ == DQC_XC_GGA_X_PBE_R ? 1.245 : kPbeKappa, mu_ = id_ == DQC_XC_GGA_X_PBE_SOL ? 10.0 / 81.0 : kPbeMu;
                     const bool rp = id_ == DQC_XC_GGA_X_RPBE;
                     f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu, ka, mu_, rp) + pbe_x_unpol5(2.0 * d, 4.0 * sdd, ka, mu_, rp));
+                } break;
+                case DQC_XC_GGA_X_PW91: case DQC_XC_GGA_X_B86: case DQC_XC_GGA_X_G96: case DQC_XC_GGA_X_PW86: case DQC_XC_GGA_X_OPTX:
+                case DQC_XC_GGA_X_WC:  // enhancement-factor exchange: exact spin scaling of the unpolarised form
+                    f = 0.5 * (gga_x_by_enh(terms.id[t], 2.0 * u, 4.0 * suu) + gga_x_by_enh(terms.id[t], 2.0 * d, 4.0 * sdd));
+                    break;
+                case DQC_XC_LDA_C_PZ: case DQC_XC_GGA_C_P86: {
+                    D5 fz = (p5(1.0 + zeta, 4.0 / 3.0) + p5(1.0 - zeta, 4.0 / 3.0) - c5(2.0)) / c5(0.51984209978974632953);
+                    f = rho * pz81_eps(rho, fz, true);
+                    if (terms.id[t] == DQC_XC_GGA_C_P86) {
+                        D5 dz = 1.2599210498948732 * sqrt5(p5(0.5 * (1.0 + zeta), 5.0 / 3.0) + p5(0.5 * (1.0 - zeta), 5.0 / 3.0));
+                        f = f + p86_gradient_term(rho, suu + 2.0 * sud + sdd, dz, true);
+                    }
                 } break;
                 case DQC_XC_LDA_C_VWN: f = rho * vwn_pol_eps(rho, zeta); break;
                 case DQC_XC_GGA_X_B88: f = b88_spin5(u, suu) + b88_spin5(d, sdd); break;

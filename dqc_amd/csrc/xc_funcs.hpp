@@ -43,6 +43,115 @@ DQC_DEV double xasinhx_val(double y, double &dg) {
 DQC_DEV Dual dxasinhx(Dual y) { double dg; const double v = xasinhx_val(y.v, dg); return {v, y.r * dg, y.s * dg}; }
 
 constexpr double kPi = 3.14159265358979323846;
+constexpr double kPbeKappa_ = 0.8040, kPbeMu_ = 0.2195149727645171;
+
+// number-type-generic spellings (Dual here, the five-variable D5 of the spin-polarised kernel in xc.hip) for the functionals that
+// are written once as templates: the exchange functionals given by an enhancement factor, PZ81 and P86
+DQC_DEV Dual dpow(Dual a, double e) { const double f = pow(a.v, e), d = e * f / a.v; return {f, a.r * d, a.s * d}; }
+DQC_DEV Dual n_exp(Dual a) { return dexp(a); }
+DQC_DEV Dual n_log(Dual a) { return dlog(a); }
+DQC_DEV Dual n_log1p(Dual a) { return dlog1p(a); }
+DQC_DEV Dual n_sqrt(Dual a) { return dsqrt(a); }
+DQC_DEV Dual n_cbrt(Dual a) { return dcbrt(a); }
+DQC_DEV Dual n_pow(Dual a, double e) { return dpow(a, e); }
+DQC_DEV Dual n_xasinhx(Dual a) { return dxasinhx(a); }
+DQC_DEV Dual n_floor(Dual a, double lo) { return a.v < lo ? Dual{lo, 0.0, 0.0} : a; }
+
+// ---------------------------------------------------------------------------------------------
+// Exchange GGAs as a TABLE of enhancement factors (round 4): e_x = -(3/4)(3/pi)^(1/3) rho^(4/3) F(s^2), s = |grad rho| / (2 k_F rho);
+// spin-polarised by the exact scaling E_x[rho_u, rho_d] = (E_x[2 rho_u] + E_x[2 rho_d]) / 2.  Adding one is one case below (+ its id
+// in include/dqc_amd.h and a name in dqc_amd/xc.py).  x = s / X2S is the spin-channel reduced gradient |grad rho_s| / rho_s^(4/3) the
+// original papers are written in.  Constants as libxc parametrises them (from memory of its published sources -- there is no
+// libxc here: see DESIGN.md, pin table).
+//   gga_x_pw91  Perdew, Wang (1991/92): F = 1 + [(c + d e^(-alpha s^2)) s^2 - f s^4] / [1 + a s asinh(b s) + f s^4], constants derived
+//               from bt = 0.0042, alpha = 100, expo = 4 (a = 6 bt / X2S = 0.19645, b = 1 / X2S = 7.7956, c = 0.2743, -d = 0.1508, f = 0.004)
+//   gga_x_b86   Becke, JCP 84, 4524 (1986): F = 1 + (0.0036 / C_x) x^2 / (1 + 0.004 x^2)
+//   gga_x_g96   Gill, Mol. Phys. 89, 433 (1996): F = 1 + x^(3/2) / (137 C_x)
+//   gga_x_pw86  Perdew, Wang, PRB 33, 8800 (1986): F = (1 + 1.296 s^2 + 14 s^4 + 0.2 s^6)^(1/15)
+//   gga_x_optx  Handy, Cohen, Mol. Phys. 99, 403 (2001): F = 1.05151 + (1.43169 / C_x) u^2, u = 0.006 x^2 / (1 + 0.006 x^2)
+//   gga_x_wc    Wu, Cohen, PRB 73, 235116 (2006): PBE form with x = 10/81 s^2 + (mu - 10/81) s^2 e^(-s^2) + ln(1 + c s^4)
+// ---------------------------------------------------------------------------------------------
+constexpr double kX2S = 0.1282782438530421943003109254455883701296;   // 1 / (2 (6 pi^2)^(1/3))
+constexpr double kXFactorC = 0.9305257363491000250020102180716672510262;  // (3/8) (3/pi)^(1/3) 4^(2/3)
+__host__ __device__ inline bool xc_id_is_x_enh(int id) {
+    return id == DQC_XC_GGA_X_PW91 || id == DQC_XC_GGA_X_B86 || id == DQC_XC_GGA_X_G96 || id == DQC_XC_GGA_X_PW86 ||
+           id == DQC_XC_GGA_X_OPTX || id == DQC_XC_GGA_X_WC;
+}
+template <class T>
+DQC_DEV T x_enhancement(int id, T s2) {
+    const double ix2 = 1.0 / (kX2S * kX2S);  // x^2 = s^2 / X2S^2
+    switch (id) {
+    case DQC_XC_GGA_X_PW91: {
+        const double bt = 0.0042, alpha = 100.0, beta = 0.0018903811666999256;  // beta = 5 (36 pi)^(-5/3)
+        const double a = 6.0 * bt / kX2S, b = 1.0 / kX2S, c = bt / (kXFactorC * kX2S * kX2S), d = -(bt - beta) / (kXFactorC * kX2S * kX2S),
+                     f = 1.0e-6 / (kXFactorC * kX2S * kX2S * kX2S * kX2S);
+        T s4 = s2 * s2;
+        T sas = (a / b) * n_xasinhx((b * b) * s2);
+        return 1.0 + ((c + d * n_exp((-alpha) * s2)) * s2 - f * s4) / (1.0 + sas + f * s4);
+    }
+    case DQC_XC_GGA_X_B86: {
+        T x2 = ix2 * s2;
+        return 1.0 + (0.0036 / kXFactorC) * x2 / (1.0 + 0.004 * x2);
+    }
+    case DQC_XC_GGA_X_G96:
+        return 1.0 + (1.0 / (137.0 * kXFactorC)) * n_pow(ix2 * n_floor(s2, 1e-40), 0.75);
+    case DQC_XC_GGA_X_PW86:
+        return n_pow(1.0 + 1.296 * s2 + 14.0 * (s2 * s2) + 0.2 * (s2 * s2 * s2), 1.0 / 15.0);
+    case DQC_XC_GGA_X_OPTX: {
+        T gx2 = (0.006 * ix2) * s2;
+        T u = gx2 / (1.0 + gx2);
+        return 1.05151 + (1.43169 / kXFactorC) * (u * u);
+    }
+    default: {  // DQC_XC_GGA_X_WC
+        const double kappa = kPbeKappa_, mu = kPbeMu_, c = (146.0 / 2025.0) * (4.0 / 9.0) - (73.0 / 405.0) * (2.0 / 3.0) + (mu - 10.0 / 81.0);
+        T x = (10.0 / 81.0) * s2 + (mu - 10.0 / 81.0) * (s2 * n_exp((-1.0) * s2)) + n_log1p(c * (s2 * s2));
+        return (1.0 + kappa) - kappa / (1.0 + x / kappa);
+    }
+    }
+}
+template <class T>
+DQC_DEV T gga_x_by_enh(int id, T rho, T sigma) {  // unpolarised energy density; polarised callers use the spin scaling
+    const double c2 = 4.0 * 9.5707800006273038;  // 4 (3 pi^2)^(2/3)
+    T r43 = rho * n_cbrt(rho);
+    T s2 = sigma / (c2 * (r43 * r43));
+    return (-0.75 * 0.98474502184269641) * (r43 * x_enhancement(id, s2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// lda_c_pz (Perdew, Zunger, PRB 23, 5048 (1981), appendix C) and gga_c_p86 (Perdew, PRB 33, 8822 (1986)) on top of it:
+//   eps_i(rs) = gamma_i / (1 + beta1_i sqrt(rs) + beta2_i rs)  (rs >= 1),   A_i ln rs + B_i + C_i rs ln rs + D_i rs  (rs < 1),   i = para, ferro
+//   eps = eps_P + (eps_F - eps_P) f(zeta),  f = ((1 + zeta)^(4/3) + (1 - zeta)^(4/3) - 2) / (2^(4/3) - 2)
+//   P86: e = n eps_PZ + exp(-Phi) C(n) |grad n|^2 / (d n^(4/3)),  Phi = 1.745 f~ (C(inf) / C(n)) |grad n| / n^(7/6),  f~ = 0.11,
+//        C(n) = 0.001667 + (0.002568 + a rs + b rs^2) / (1 + g rs + d rs^2 + 10^4 b rs^3),  d(zeta) = 2^(1/3) sqrt(((1+zeta)/2)^(5/3) + ((1-zeta)/2)^(5/3))
+// fz, dz: f(zeta) and d(zeta) (0 and 1 for the closed-shell forms)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+DQC_DEV T pz81_channel(T rs, int i) {
+    const double gam[2] = {-0.1423, -0.0843}, b1[2] = {1.0529, 1.3981}, b2[2] = {0.3334, 0.2611};
+    const double A[2] = {0.0311, 0.01555}, B[2] = {-0.048, -0.0269}, C[2] = {0.0020, 0.0007}, D[2] = {-0.0116, -0.0048};
+    if (rs.v >= 1.0) return gam[i] / (1.0 + b1[i] * n_sqrt(rs) + b2[i] * rs);
+    T lr = n_log(rs);
+    return A[i] * lr + B[i] + C[i] * (rs * lr) + D[i] * rs;
+}
+template <class T>
+DQC_DEV T pz81_eps(T rho, T fz, bool pol) {
+    T rs = n_cbrt((3.0 / (4.0 * kPi)) / rho);
+    T eP = pz81_channel(rs, 0);
+    if (!pol) return eP;
+    return eP + (pz81_channel(rs, 1) - eP) * fz;
+}
+template <class T>
+DQC_DEV T p86_gradient_term(T rho, T sigma, T dz, bool pol) {
+    const double a = 0.023266, b = 7.389e-6, g = 8.723, d = 0.472, cinf = 0.001667 + 0.002568, ft = 0.11;
+    T rs = n_cbrt((3.0 / (4.0 * kPi)) / rho);
+    T rs2 = rs * rs;
+    T Cn = 0.001667 + (0.002568 + a * rs + b * rs2) / (1.0 + g * rs + d * rs2 + (1.0e4 * b) * (rs2 * rs));
+    T sg = n_floor(sigma, 1e-40);
+    T r16 = n_pow(rho, 1.0 / 6.0);
+    T phi = (1.745 * ft * cinf) * n_sqrt(sg) / (Cn * (rho * r16));
+    T H = n_exp((-1.0) * phi) * Cn * sg / (rho * n_cbrt(rho));
+    return pol ? H / dz : H;
+}
 
 DQC_DEV Dual f_lda_x(Dual rho) {
     const double c = -0.75 * 0.98474502184269641;  // -(3/4) (3/pi)^(1/3)
@@ -132,18 +241,21 @@ DQC_DEV Dual f_gga_c_lyp(Dual rho, Dual sigma) {
 }
 
 __host__ __device__ inline bool xc_id_is_lda(int id) {
-    return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_PW_MOD || id == DQC_XC_LDA_C_VWN;
+    return id == DQC_XC_LDA_X || id == DQC_XC_LDA_C_PW || id == DQC_XC_LDA_C_PW_MOD || id == DQC_XC_LDA_C_VWN || id == DQC_XC_LDA_C_PZ;
 }
 __host__ __device__ inline bool xc_id_is_gga(int id) {
     return id == DQC_XC_GGA_X_PBE || id == DQC_XC_GGA_C_PBE || id == DQC_XC_GGA_X_B88 || id == DQC_XC_GGA_C_LYP || id == DQC_XC_GGA_X_PBE_R ||
-           id == DQC_XC_GGA_X_PBE_SOL || id == DQC_XC_GGA_X_RPBE || id == DQC_XC_GGA_C_PBE_SOL;
+           id == DQC_XC_GGA_X_PBE_SOL || id == DQC_XC_GGA_X_RPBE || id == DQC_XC_GGA_C_PBE_SOL || id == DQC_XC_GGA_C_P86 || xc_id_is_x_enh(id);
 }
 inline bool xc_host_is_lda(int id) { return xc_id_is_lda(id); }
 inline bool xc_host_is_gga(int id) { return xc_id_is_gga(id); }
 
 // one LDA / GGA functional of the kernel set at (rho, sigma) with its first derivatives
 DQC_DEV Dual f_lda_gga(int id, Dual dr, Dual ds) {
+    if (xc_id_is_x_enh(id)) return gga_x_by_enh(id, dr, ds);
     switch (id) {
+    case DQC_XC_LDA_C_PZ: return dr * pz81_eps(dr, dr, false);
+    case DQC_XC_GGA_C_P86: return dr * pz81_eps(dr, dr, false) + p86_gradient_term(dr, ds, dr, false);
     case DQC_XC_LDA_X: return f_lda_x(dr);
     case DQC_XC_LDA_C_PW: return f_lda_c_pw(dr);
     case DQC_XC_LDA_C_VWN: return f_lda_c_vwn(dr);

@@ -736,8 +736,9 @@ class HamiltonMI355(_Base):
             densinfo = self._dm2densinfo(dm)
             if hasattr(self.xc, "get_vxc_and_exc"):  # potentials and the E_xc quadrature from one pass over the grid
                 potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
-                exc = exc[:1]  # (the result; the rest of the buffer is the kernel's per-block scratch)
-                self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
+                if exc is not None:
+                    exc = exc[:1]  # (the result; the rest of the buffer is the kernel's per-block scratch)
+                    self._allsum(exc)  # (sharded: the quadrature of this rank's slab)
             else:
                 potinfo, exc = self.xc.get_vxc(densinfo), None
             vm = self._vxc_ao_from_potinfo(potinfo)

@@ -15,7 +15,9 @@ _lib = None
 
 XC_IDS = {"lda_x": 1, "lda_c_vwn": 7, "lda_c_pw": 12, "lda_c_pw_mod": 13, "gga_x_pbe": 101, "gga_x_pbe_r": 102, "gga_x_b88": 106,
           "gga_x_pbe_sol": 116, "gga_x_rpbe": 117, "gga_c_pbe": 130, "gga_c_lyp": 131, "gga_c_pbe_sol": 133,
-          "mgga_x_scan": 263, "mgga_c_scan": 267}
+          "mgga_x_scan": 263, "mgga_c_scan": 267,
+          "lda_c_pz": 9, "gga_x_b86": 103, "gga_x_g96": 107, "gga_x_pw86": 108, "gga_x_pw91": 109, "gga_x_optx": 110, "gga_x_wc": 118,
+          "gga_c_p86": 132}
 
 
 class DqcAmdError(RuntimeError):
@@ -123,7 +125,41 @@ def set_deterministic(on=True):
     return bool(load().dqc_set_deterministic(1 if on else 0))
 
 
+_TRACE = None      # a list while `call_trace` is active: (entry point, start event, end event) per library call
+_TRACE_OPEN = None
+
+
+class call_trace:
+    """measurement aid: `with lib.call_trace() as tr:` brackets every library call made inside with two HIP events on the stream
+    the call is enqueued on; `tr.ms()` -> {entry point: (calls, mean ms per call)} (synchronises).  bench.py's per-kernel
+    rooflines of the legs that have no hand-unrolled event chain come from here; nothing is recorded outside the block."""
+
+    def __enter__(self):
+        global _TRACE
+        self.rows = _TRACE = []
+        return self
+
+    def __exit__(self, *a):
+        global _TRACE, _TRACE_OPEN
+        _TRACE = _TRACE_OPEN = None
+        return False
+
+    def ms(self):
+        torch.cuda.synchronize()
+        out = {}
+        for what, e0, e1 in self.rows:
+            n, t = out.get(what, (0, 0.0))
+            out[what] = (n + 1, t + e0.elapsed_time(e1))
+        return {k: (n, t / n) for k, (n, t) in out.items()}
+
+
 def _check(rc, what):
+    global _TRACE_OPEN
+    if _TRACE is not None and _TRACE_OPEN is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream(_TRACE_OPEN[1]))
+        _TRACE.append((what, _TRACE_OPEN[0], e1))
+        _TRACE_OPEN = None
     if rc != 0:
         raise DqcAmdError("%s failed (%d): %s" % (what, rc, load().dqc_last_error().decode()))
 
@@ -140,9 +176,15 @@ class _on:
         self.guard = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
 
     def __enter__(self):
+        global _TRACE_OPEN
         if self.guard is not None:
             self.guard.__enter__()
-        return ctypes.c_void_p(torch.cuda.current_stream(self.idx).cuda_stream)
+        st = torch.cuda.current_stream(self.idx)
+        if _TRACE is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            _TRACE_OPEN = (e0, self.idx)
+        return ctypes.c_void_p(st.cuda_stream)
 
     def __exit__(self, *a):
         if self.guard is not None:
@@ -544,7 +586,7 @@ def grid_density(ao, nao, dm_pad, gga):
     grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
     with _on(ao.device) as st_:
         _check(load().dqc_grid_density(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(dm_pad), st_),
-               "dqc_grid_density")
+               "dqc_grid_density" if gga else "dqc_grid_density[value only]")
     return rho, grho
 
 
@@ -573,7 +615,7 @@ def grid_density_lr(ao, nao, factor, gga):
     grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if gga else None
     with _on(ao.device) as st_:
         _check(load().dqc_grid_density_lr(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(orb), _ptr(orbt),
-                                          orb.shape[1], st_), "dqc_grid_density_lr")
+                                          orb.shape[1], st_), "dqc_grid_density_lr" if gga else "dqc_grid_density_lr[value only]")
     return rho, grho
 
 
@@ -682,7 +724,7 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
     with _on(ao.device) as st_:
         _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), st_),
-               "dqc_grid_vxc")
+               "dqc_grid_vxc" if vgrad is not None else "dqc_grid_vxc[no gradient term]")
     return vm
 
 

@@ -53,7 +53,7 @@ def signature(qc):
         return None
     # a Hamiltonian sharded over several GPUs issues collectives inside its Fock build: every rank has to take the same
     # branches, which only SCF_QCCalc.run guarantees (it broadcasts rank 0's per-iteration scalars, hamilton.sync_scalars)
-    if getattr(eng.hamilton, "sharded", False):
+    if getattr(getattr(eng, "hamilton", None), "sharded", False):
         return None
     ch = _spin_channels(eng)
     if ch is None:

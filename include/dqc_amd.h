@@ -117,15 +117,23 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
  * (= zk*rho), d_vrho (n), d_vgrad (3,n) = 2*vsigma*grad rho  (libxc.py:239). */
 #define DQC_XC_LDA_X 1
 #define DQC_XC_LDA_C_VWN 7   /* VWN5 */
+#define DQC_XC_LDA_C_PZ 9    /* Perdew-Zunger 81 */
 #define DQC_XC_LDA_C_PW 12
 #define DQC_XC_LDA_C_PW_MOD 13   /* PW92 with the full-precision constants (the LDA limit inside gga_c_pbe) */
 #define DQC_XC_GGA_X_PBE 101
 #define DQC_XC_GGA_X_PBE_R 102   /* revPBE (Zhang, Yang, PRL 80, 890 (1998)): kappa = 1.245 */
+#define DQC_XC_GGA_X_B86 103     /* exchange functionals given by an enhancement factor (csrc/xc_funcs.hpp: x_enhancement) */
 #define DQC_XC_GGA_X_B88 106
+#define DQC_XC_GGA_X_G96 107
+#define DQC_XC_GGA_X_PW86 108
+#define DQC_XC_GGA_X_PW91 109
+#define DQC_XC_GGA_X_OPTX 110
+#define DQC_XC_GGA_X_WC 118
 #define DQC_XC_GGA_X_PBE_SOL 116 /* PBEsol (Perdew et al., PRL 100, 136406 (2008)): mu = 10/81 */
 #define DQC_XC_GGA_X_RPBE 117    /* RPBE (Hammer, Hansen, Norskov, PRB 59, 7413 (1999)): F = 1 + kappa (1 - exp(-mu s^2 / kappa)) */
 #define DQC_XC_GGA_C_PBE 130
 #define DQC_XC_GGA_C_LYP 131
+#define DQC_XC_GGA_C_P86 132     /* Perdew 86 on PZ81 */
 #define DQC_XC_GGA_C_PBE_SOL 133 /* PBEsol correlation: beta = 0.046 */
 #define DQC_XC_MGGA_X_SCAN 263
 #define DQC_XC_MGGA_C_SCAN 267

@@ -701,3 +701,181 @@ _FUNCS.update({"lda_c_pw_mod": (1, _variant(lda_c_pw, a=_PW_A_MOD)),
 _FUNCS_POL.update({"lda_c_pw_mod": lda_c_pw_mod_pol,
                    "gga_x_pbe_r": _variant(gga_x_pbe_pol, kappa=1.245), "gga_x_pbe_sol": _variant(gga_x_pbe_pol, mu=10.0 / 81.0),
                    "gga_x_rpbe": _variant(gga_x_pbe_pol, rpbe=True), "gga_c_pbe_sol": _variant(gga_c_pbe_pol, beta=0.046)})
+
+
+# =====================================================================================================
+# Round 4: exchange GGAs given by an enhancement factor (libxc ids 103 gga_x_b86, 107 gga_x_g96, 108 gga_x_pw86, 109 gga_x_pw91,
+# 110 gga_x_optx, 118 gga_x_wc), lda_c_pz (9) and gga_c_p86 (132).  The reference reaches them through pylibxc (getxc.py:12-36) and
+# holds no formula: PARITY against an executed libxc is UNPINNED.  Written here per SPIN CHANNEL in the reduced gradient
+# x_s = |grad rho_s| / rho_s^(4/3) of the original papers, y = x_s^2, with hand-derived F'(y) (the product evaluates one template in
+# s^2 of the total density with dual numbers and spin-scales it):
+#     e_s = -C_x rho_s^(4/3) F(y),   C_x = (3/2)(3/(4 pi))^(1/3);   s^2 = X2S^2 y,  X2S = 1 / (2 (6 pi^2)^(1/3))
+#   B86   Becke, JCP 84, 4524 (1986):               F = 1 + (0.0036 / C_x) y / (1 + 0.004 y)
+#   G96   Gill, Mol. Phys. 89, 433 (1996):          F = 1 + y^(3/4) / (137 C_x)
+#   PW86  Perdew, Wang, PRB 33, 8800 (1986):        F = (1 + 1.296 s^2 + 14 s^4 + 0.2 s^6)^(1/15)
+#   PW91  Perdew et al., PRB 46, 6671 (1992):       F = [1 + a s asinh(b s) + (c + d exp(-100 s^2)) s^2] / [1 + a s asinh(b s) + f s^4] with the
+#         constants as libxc derives them from bt = 0.0042, alpha = 100, expo = 4 (published: 0.19645, 7.7956, 0.2743, -0.1508, 0.004)
+#   OPTX  Handy, Cohen, Mol. Phys. 99, 403 (2001):  F = 1.05151 + (1.43169 / C_x) u^2,  u = 0.006 y / (1 + 0.006 y)
+#   WC    Wu, Cohen, PRB 73, 235116 (2006):         F = 1 + kappa - kappa^2 / (kappa + x),  x = 10/81 s^2 + (mu - 10/81) s^2 e^(-s^2) + ln(1 + c s^4)
+#   PZ81  Perdew, Zunger, PRB 23, 5048 (1981) app. C;  P86  Perdew, PRB 33, 8822 (1986) -- on dual arrays
+# =====================================================================================================
+_X2S = 1.0 / (2.0 * (6.0 * np.pi ** 2) ** (1.0 / 3))
+_CX = 1.5 * (3.0 / (4.0 * np.pi)) ** (1.0 / 3)
+_S2_FLOOR = 1e-40
+
+
+def _enh_pw91(y):
+    bt, alpha, beta = 0.0042, 100.0, 5.0 * (36.0 * np.pi) ** (-5.0 / 3)
+    a, b = 6.0 * bt / _X2S, 1.0 / _X2S
+    c, d, f = bt / (_CX * _X2S ** 2), -(bt - beta) / (_CX * _X2S ** 2), 1e-6 / (_CX * _X2S ** 4)
+    s2 = _X2S ** 2 * y
+    s = np.sqrt(s2)
+    small = b * s < 1e-4
+    ss = np.where(small, 1.0, s)
+    ash_s = np.where(small, b * (1.0 - (b * b * s2) / 6.0), np.arcsinh(b * ss) / ss)   # asinh(b s) / s
+    sas = a * s2 * ash_s
+    dsas = 0.5 * a * (ash_s + b / np.sqrt(1.0 + b * b * s2))                              # d (a s asinh(b s)) / d s^2
+    ex = np.exp(-alpha * s2)
+    N = (c + d * ex) * s2 - f * s2 * s2
+    dN = c + d * ex * (1.0 - alpha * s2) - 2.0 * f * s2
+    Dn = 1.0 + sas + f * s2 * s2
+    dDn = dsas + 2.0 * f * s2
+    return 1.0 + N / Dn, _X2S ** 2 * (dN * Dn - N * dDn) / (Dn * Dn)
+
+
+def _enh_b86(y):
+    be, ga = 0.0036 / _CX, 0.004
+    return 1.0 + be * y / (1.0 + ga * y), be / (1.0 + ga * y) ** 2
+
+
+def _enh_g96(y):
+    lo = _S2_FLOOR / _X2S ** 2          # the product floors s^2 at 1e-40 (a constant there: zero derivative)
+    fl = y < lo
+    ye = np.where(fl, lo, y)
+    k = 1.0 / (137.0 * _CX)
+    return 1.0 + k * ye ** 0.75, np.where(fl, 0.0, 0.75 * k * ye ** (-0.25))
+
+
+def _enh_pw86(y):
+    s2 = _X2S ** 2 * y
+    P = 1.0 + 1.296 * s2 + 14.0 * s2 ** 2 + 0.2 * s2 ** 3
+    return P ** (1.0 / 15), _X2S ** 2 * (1.0 / 15) * P ** (-14.0 / 15) * (1.296 + 28.0 * s2 + 0.6 * s2 ** 2)
+
+
+def _enh_optx(y):
+    g = 0.006
+    u = g * y / (1.0 + g * y)
+    return 1.05151 + (1.43169 / _CX) * u * u, 2.0 * (1.43169 / _CX) * u * g / (1.0 + g * y) ** 2
+
+
+def _enh_wc(y):
+    ka, mu = _PBE_KAPPA, _PBE_MU
+    c = (146.0 / 2025.0) * (4.0 / 9.0) - (73.0 / 405.0) * (2.0 / 3.0) + (mu - 10.0 / 81.0)
+    s2 = _X2S ** 2 * y
+    ex = np.exp(-s2)
+    x = (10.0 / 81.0) * s2 + (mu - 10.0 / 81.0) * s2 * ex + np.log1p(c * s2 * s2)
+    dx = 10.0 / 81.0 + (mu - 10.0 / 81.0) * ex * (1.0 - s2) + 2.0 * c * s2 / (1.0 + c * s2 * s2)
+    return 1.0 + ka - ka * ka / (ka + x), _X2S ** 2 * ka * ka * dx / (ka + x) ** 2
+
+
+_ENH = {"gga_x_pw91": _enh_pw91, "gga_x_b86": _enh_b86, "gga_x_g96": _enh_g96, "gga_x_pw86": _enh_pw86, "gga_x_optx": _enh_optx,
+        "gga_x_wc": _enh_wc}
+
+
+def _x_spin(enh, rs_, sss):
+    """one spin channel of an enhancement-factor exchange functional: e_s, d e_s / d rho_s, d e_s / d sigma_ss"""
+    r43 = rs_ ** (4.0 / 3)
+    y = sss / (r43 * r43)
+    F, dF = enh(y)
+    e = -_CX * r43 * F
+    de_dr = -(4.0 / 3) * _CX * rs_ ** (1.0 / 3) * F + _CX * r43 * dF * (8.0 / 3) * y / rs_
+    de_ds = -_CX * dF / r43
+    return e, de_dr, de_ds
+
+
+def _make_x(name):
+    enh = _ENH[name]
+
+    def unpol(rho, sigma):
+        mask, r = _safe(rho)
+        e, dr, ds = _x_spin(enh, 0.5 * r, 0.25 * np.asarray(sigma, float))
+        return np.where(mask, 2.0 * e, 0.0), np.where(mask, dr, 0.0), np.where(mask, 0.5 * ds, 0.0)
+
+    def pol(ru, rd, suu, sud, sdd):
+        mask, ru_, rd_ = _masked(ru, rd)
+        eu, du, su = _x_spin(enh, ru_, np.asarray(suu, float))
+        ed, dd, sd = _x_spin(enh, rd_, np.asarray(sdd, float))
+        z = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+        return z(eu + ed), (z(du), z(dd)), (z(su), np.zeros_like(ru_), z(sd))
+
+    return unpol, pol
+
+
+for _n in _ENH:
+    _u, _p = _make_x(_n)
+    _FUNCS[_n] = (2, _u)
+    _FUNCS_POL[_n] = _p
+
+_PZ = {"gam": (-0.1423, -0.0843), "b1": (1.0529, 1.3981), "b2": (0.3334, 0.2611), "A": (0.0311, 0.01555), "B": (-0.048, -0.0269),
+       "C": (0.0020, 0.0007), "D": (-0.0116, -0.0048)}
+
+
+def _sel(cond, a, b):
+    """where() on dual arrays"""
+    return Dual(np.where(cond, a.v, b.v), [np.where(cond, x, y) for x, y in zip(a.d, b.d)])
+
+
+def _pz_channel(rs, i):
+    hi = _PZ["gam"][i] / (1.0 + _PZ["b1"][i] * rs.sqrt() + _PZ["b2"][i] * rs)
+    lr = rs.fn(np.log, lambda x: 1.0 / x)
+    lo = _PZ["A"][i] * lr + _PZ["B"][i] + _PZ["C"][i] * (rs * lr) + _PZ["D"][i] * rs
+    return _sel(rs.v >= 1.0, hi, lo)
+
+
+def _pz_p86_dual(u, d, suu, sud, sdd, p86):
+    rho, zeta = _safe_zeta(u, d)
+    rs = ((3.0 / (4.0 * np.pi)) / rho).pow(1.0 / 3)
+    eP, eF = _pz_channel(rs, 0), _pz_channel(rs, 1)
+    fz = ((1.0 + zeta).pow(4.0 / 3) + (1.0 - zeta).pow(4.0 / 3) - 2.0) / (2.0 ** (4.0 / 3) - 2.0)
+    e = rho * (eP + (eF - eP) * fz)
+    if p86:
+        a, b, g, dd_, cinf, ft = 0.023266, 7.389e-6, 8.723, 0.472, 0.001667 + 0.002568, 0.11
+        rs2 = rs * rs
+        Cn = 0.001667 + (0.002568 + a * rs + b * rs2) / (1.0 + g * rs + dd_ * rs2 + 1e4 * b * rs2 * rs)
+        sig = suu + 2.0 * sud + sdd
+        fl = sig.v < _S2_FLOOR
+        sig = _sel(fl, Dual.const(_S2_FLOOR, sig), sig)
+        phi = 1.745 * ft * cinf * sig.sqrt() / (Cn * rho.pow(7.0 / 6))
+        dz = 2.0 ** (1.0 / 3) * ((0.5 * (1.0 + zeta)).pow(5.0 / 3) + (0.5 * (1.0 - zeta)).pow(5.0 / 3)).sqrt()
+        e = e + (-phi).fn(np.exp, np.exp) * Cn * sig / (dz * rho.pow(4.0 / 3))
+    return e
+
+
+def lda_c_pz_pol(ru, rd, suu=None, sud=None, sdd=None):
+    mask, ru_, rd_ = _masked(ru, rd)
+    z0 = np.zeros_like(ru_)
+    u, d, a, b, c = _pol_inputs(ru_, rd_, z0, z0, z0)
+    return _finish(_pz_p86_dual(u, d, a, b, c, False), mask)
+
+
+def gga_c_p86_pol(ru, rd, suu, sud, sdd):
+    mask, ru_, rd_ = _masked(ru, rd)
+    u, d, a, b, c = _pol_inputs(ru_, rd_, suu, sud, sdd)
+    return _finish(_pz_p86_dual(u, d, a, b, c, True), mask)
+
+
+def lda_c_pz(rho, sigma=None):
+    h = 0.5 * np.asarray(rho, float)
+    e, (vu, vd), _ = lda_c_pz_pol(h, h)
+    return e, 0.5 * (vu + vd), np.zeros_like(h)
+
+
+def gga_c_p86(rho, sigma):
+    """closed shell = the spin form at rho_a = rho_b (chain rule), like gga_c_lyp above"""
+    h, q = 0.5 * np.asarray(rho, float), 0.25 * np.asarray(sigma, float)
+    e, (vu, vd), (saa, sab, sbb) = gga_c_p86_pol(h, h, q, q, q)
+    return e, 0.5 * (vu + vd), 0.25 * (saa + sab + sbb)
+
+
+_FUNCS.update({"lda_c_pz": (1, lda_c_pz), "gga_c_p86": (2, gga_c_p86)})
+_FUNCS_POL.update({"lda_c_pz": lda_c_pz_pol, "gga_c_p86": gga_c_p86_pol})

@@ -109,7 +109,8 @@ def test_xc_closed_forms():
 
 
 _XC_NAMES = ["lda_x", "lda_c_pw", "gga_x_pbe", "gga_c_pbe", "lda_c_vwn", "gga_x_b88", "gga_c_lyp",
-             "lda_c_pw_mod", "gga_x_pbe_r", "gga_x_pbe_sol", "gga_x_rpbe", "gga_c_pbe_sol"]
+             "lda_c_pw_mod", "gga_x_pbe_r", "gga_x_pbe_sol", "gga_x_rpbe", "gga_c_pbe_sol",
+             "gga_x_pw91", "gga_x_b86", "gga_x_g96", "gga_x_pw86", "gga_x_optx", "gga_x_wc", "lda_c_pz", "gga_c_p86"]
 
 
 @pytest.mark.parametrize("name", _XC_NAMES)
@@ -565,3 +566,42 @@ def test_oracle_fractional_mode_vs_reference_generated_golden(name, basis, xc, g
     e, eng = oh.run_scf((g["atomzs"].tolist(), g["atompos"].tolist()), basis, spin=float(g["spin"]), tol=1e-10, **kw)
     assert np.allclose(eng.orb_weight.numpy(), g["orb_weight"], atol=1e-12)
     assert abs(e - float(g["e_tot"])) < 1e-9, (e, float(g["e_tot"]))
+
+
+def test_round4_functionals_published_limits():
+    """the enhancement-factor exchange functionals, PZ81 and P86 pinned by what their papers state (no libxc here):
+    F(0) = 1 for all but OPTX (a1 = 1.05151); PW91's derived constants equal the published ones to their digits and its
+    gradient expansion starts with c + d = 0.1235; WC starts with PBE's mu (its 10/81 term takes over once exp(-s^2) has died); PW86 ~ s^(2/5) (0.2 s^6)^(1/15) at large s; PZ81: eps_c(rs = 1) = gamma / (1 + beta1 + beta2) on both
+    branches (continuous to the quoted precision of the fit), high-density slope A ln rs; P86 = PZ81 at zero gradient and its
+    gradient term starts as C(n) |grad n|^2 / n^(4/3); every polarised form reduces to the closed-shell one at rho_u = rho_d"""
+    y0 = np.array([0.0])
+    for n, f in oxc._ENH.items():
+        assert abs(f(y0)[0][0] - (1.05151 if n == "gga_x_optx" else 1.0)) < 1e-15, n
+    bt, beta = 0.0042, 5.0 * (36.0 * np.pi) ** (-5.0 / 3)
+    assert abs(6 * bt / oxc._X2S - 0.19645) < 1e-5 and abs(1 / oxc._X2S - 7.7956) < 1e-4
+    assert abs(bt / (oxc._CX * oxc._X2S ** 2) - 0.2743) < 1e-4 and abs((bt - beta) / (oxc._CX * oxc._X2S ** 2) - 0.1508) < 1e-4
+    assert abs(1e-6 / (oxc._CX * oxc._X2S ** 4) - 0.004) < 5e-5
+    s2 = np.array([1e-6])
+    y = s2 / oxc._X2S ** 2
+    assert abs((oxc._enh_wc(y)[0][0] - 1.0) / s2[0] - oxc._PBE_MU) < 1e-5               # WC: PBE's mu at second order (exp(-s^2) -> 1)
+    assert abs((oxc._enh_pw91(y)[0][0] - 1.0) / s2[0] - (0.2743 - 0.1508)) < 1e-3        # PW91: c + d
+    big = np.array([1e6])
+    assert abs(oxc._enh_pw86(big / oxc._X2S ** 2)[0][0] / (0.2 ** (1 / 15) * big[0] ** 0.2) - 1.0) < 1e-3
+    rho1 = np.array([3.0 / (4.0 * np.pi)])                                               # rs = 1
+    assert abs(oxc.lda_c_pz(rho1)[0][0] / rho1[0] - (-0.1423 / (1 + 1.0529 + 0.3334))) < 1e-12
+    lo = 0.0311 * 0.0 - 0.048 - 0.0116                                                   # A ln 1 + B + C 1 ln 1 + D
+    assert abs(lo - (-0.1423 / (1 + 1.0529 + 0.3334))) < 5e-5                            # the two branches meet at rs = 1
+    rho = np.array([0.3, 1.1, 4.0])
+    e0, v0, _ = oxc.lda_c_pz(rho)
+    e1, v1, s1 = oxc.gga_c_p86(rho, np.zeros(3))
+    assert np.allclose(e0, e1, atol=1e-30) and np.allclose(v0, v1, rtol=1e-12)
+    sig = np.array([1e-8, 1e-8, 1e-8])
+    rs = (3.0 / (4.0 * np.pi * rho)) ** (1.0 / 3)
+    Cn = 0.001667 + (0.002568 + 0.023266 * rs + 7.389e-6 * rs ** 2) / (1 + 8.723 * rs + 0.472 * rs ** 2 + 0.07389 * rs ** 3)
+    assert np.allclose(oxc.gga_c_p86(rho, sig)[0] - e0, Cn * sig / rho ** (4.0 / 3), rtol=2e-3)
+    rng = np.random.default_rng(5)
+    r, sg = rng.uniform(0.05, 2.0, 20), rng.uniform(0.0, 1.0, 20)
+    for n in list(oxc._ENH) + ["lda_c_pz", "gga_c_p86"]:
+        eu, vu, vs = oxc._FUNCS[n][1](r, sg)
+        ep, (pu, pd), _ = oxc._FUNCS_POL[n](0.5 * r, 0.5 * r, 0.25 * sg, 0.25 * sg, 0.25 * sg)
+        assert np.allclose(eu, ep, rtol=1e-13) and np.allclose(vu, pu, rtol=1e-11) and np.allclose(vu, pd, rtol=1e-11), n
