@@ -16,7 +16,10 @@ template <int DERIV>
 __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, const double *__restrict__ coords,
                                                        int ngrid, int nao, int ld, DevShells sh) {
     constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : (DERIV == 2 ? 5 : 10));
-    constexpr int GTO_CW = DERIV == 3 ? 8 : 16;  // columns staged per flush (the 10-component tile must fit 64 KB)
+    // columns staged per flush.  The tile is what bounds the occupancy (one wave per block): 16 columns x 4 components = 35 KB
+    // allowed 4 waves per CU and the kernel wrote at 1 TB/s (round 3); 8 columns (4 with the ten components of DERIV 3) let
+    // 8 waves per CU overlap their evaluation and their stores
+    constexpr int GTO_CW = DERIV == 0 ? 16 : (DERIV == 3 ? 4 : 8);
     __shared__ double tile[1][NC][64][GTO_CW + 1];
     constexpr int wave = 0;
     const int lane = threadIdx.x;
@@ -31,12 +34,22 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
     auto flush = [&](int ncols) {
         // tile[wave][c][p][j] -> out[c][g0+p][col0+j]; lanes sweep (p, j) with j fastest
         __syncthreads();
-        for (int c = 0; c < NC; c++)
-            for (int e = lane; e < 64 * GTO_CW; e += 64) {
-                int p = e / GTO_CW, j = e % GTO_CW;
-                if (j < ncols && g0 + p < ngrid)
-                    out[c * cstride + (size_t)(g0 + p) * ld + col0 + j] = tile[wave][c][p][j];
-            }
+        if (ncols == GTO_CW) {  // a full tile: 16-byte stores (col0 is a multiple of GTO_CW and the row stride is even)
+            for (int c = 0; c < NC; c++)
+                for (int e = lane; e < 64 * (GTO_CW / 2); e += 64) {
+                    const int p = e / (GTO_CW / 2), j = 2 * (e % (GTO_CW / 2));
+                    if (g0 + p < ngrid)
+                        *reinterpret_cast<double2 *>(out + c * cstride + (size_t)(g0 + p) * ld + col0 + j) =
+                            make_double2(tile[wave][c][p][j], tile[wave][c][p][j + 1]);
+                }
+        } else {
+            for (int c = 0; c < NC; c++)
+                for (int e = lane; e < 64 * GTO_CW; e += 64) {
+                    int p = e / GTO_CW, j = e % GTO_CW;
+                    if (j < ncols && g0 + p < ngrid)
+                        out[c * cstride + (size_t)(g0 + p) * ld + col0 + j] = tile[wave][c][p][j];
+                }
+        }
         __syncthreads();
     };
 

@@ -25,5 +25,19 @@ for _ in range(K):
     eng.dm2scp(h.ao_orb2dm(orb, eng.orb_weight))
 e1.record()
 torch.cuda.synchronize()
-print(json.dumps({"config": name, "nao": h._nao_ao, "ld": h._ld, "nocc": int(eng.norb), "ngrid": int(h.rgrid.shape[0]) if h.is_grid_set else 0,
+# the same build as the SCF loop issues it: one hipGraph replay (dqc_amd/graph.py) -- what an iteration pays; the eager figure above
+# carries ~15 small launches of Python / torch host time per build, which dominates for benzene-size molecules
+from dqc_amd.graph import GraphedFock
+gf = GraphedFock(eng)
+for _ in range(3):
+    gf(orb)
+torch.cuda.synchronize()
+g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+g0.record()
+for _ in range(K):
+    gf(orb)
+g1.record()
+torch.cuda.synchronize()
+graph_ms = g0.elapsed_time(g1) / K
+print(json.dumps({"config": name, "fock_build_graph_ms": graph_ms, "nao": h._nao_ao, "ld": h._ld, "nocc": int(eng.norb), "ngrid": int(h.rgrid.shape[0]) if h.is_grid_set else 0,
                   "xc": xc, "tile_bytes": h._tiles.numel() * 8, "fock_build_ms": e0.elapsed_time(e1) / K}))
