@@ -263,7 +263,7 @@ __device__ __forceinline__ void ws_chunk(const unsigned (&pa)[MAXT], const unsig
 // the straight-line MFMA stream are sized for exactly the tiles the wave owns).  Tile u = t0 + t of the block's list maps to
 // local tile coordinates (li, lj) -- LDS columns 16 li of the A part, 16 lj of the B part -- and to the output tile
 // (r0 + li, c0 + lj):  nc > 0: rectangle, (u / nc, u % nc);  nc == 0, sym == 0: (u / T, u % T);  sym: upper triangle of T rows.
-struct WsTiles { int sym, T, nc, r0, c0, t0; };
+struct WsTiles { int sym, T, nc, r0, c0, t0, nreal; };  // nreal: tiles of the block's list that exist (vxc_ws2_kernel pads lighter blocks)
 __device__ __forceinline__ void ws_tile(const WsTiles &m, int u, int &li, int &lj) {
     if (m.nc) { li = u / m.nc; lj = u - li * m.nc; return; }
     if (!m.sym) { li = u / m.T; lj = u - li * m.T; return; }
@@ -283,7 +283,7 @@ __device__ __forceinline__ void ws_consumer(double *lds, double *__restrict__ vm
     for (int t = 0; t < NTL; t++) {
         acc[t] = v4d{0, 0, 0, 0};
         int li, lj;
-        ws_tile(m, m.t0 + t, li, lj);
+        ws_tile(m, min(m.t0 + t, m.nreal - 1), li, lj);  // (a padding tile re-reads the block's last one; its sum is discarded)
         pa[t] = lds0 + 8u * (unsigned)(lk * LSA + li * 16 + lr);
         pb[t] = lds0 + 8u * (unsigned)(XS + lk * LSB + lj * 16 + lr);
     }
@@ -300,6 +300,7 @@ __device__ __forceinline__ void ws_consumer(double *lds, double *__restrict__ vm
     }
 #pragma unroll
     for (int t = 0; t < NTL; t++) {
+        if (m.t0 + t >= m.nreal) continue;
         int li, lj;
         ws_tile(m, m.t0 + t, li, lj);
         const int ia = (m.r0 + li) * 16 + lk, ib = (m.c0 + lj) * 16 + lr;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(VWS_NT, VWS_NT / 256) void vxc_ws_kernel(double *__
     const int tc1 = min(tc0 + tiles_per_split, ttot);
     int t0, nt;
     ws_deal(tc1 - tc0, wave, t0, nt);
-    const WsTiles m{sym, T, 0, 0, 0, tc0 + t0};
+    const WsTiles m{sym, T, 0, 0, 0, tc0 + t0, tc1};
     ws_consumer_n<MAXT, KCH, WS_D, VWS_GS, VWS_GS, VWS_XS, VWS_BUF>(nt, lds, vmat, ld, nchunk, m, LS, LS);
 }
 
@@ -575,9 +576,14 @@ __global__ __launch_bounds__(VWS2_NT, 3) void vxc_ws2_kernel(double *__restrict_
     }
 
     // ---------------------------------------------------------------------- consumers
+    // EVERY block of a slab runs the tile count of the largest rectangle (the smaller ones pad with repeats of their last tile):
+    // blocks that issue the same MFMA stream per chunk walk through the slab in step, and the slab's rows then come out of
+    // the XCD's L2 for all but the first reader.  With the exact counts (T = 26: 64 ... 81 tiles) the lighter blocks ran ahead and
+    // FETCH_SIZE doubled (9.7 instead of 4.9 GB per launch at nao 412) for the same launch time
+    const int ntmax = ((T + NR - 1) / NR) * ((T + NC - 1) / NC);
     int t0, nt;
-    ws_deal(nr * nc, wave, t0, nt);
-    const WsTiles m{0, T, nc, r0, c0, t0};
+    ws_deal(ntmax, wave, t0, nt);
+    const WsTiles m{0, T, nc, r0, c0, t0, nr * nc};
     ws_consumer_n<MAXT, KCH, 4, WS2_GSA, WS2_GSB, WS2_XS, WS2_BUF>(nt, lds, vmat, ld, nchunk, m, LSA, LSB);
 }
 
@@ -1137,11 +1143,10 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             const int LSA = pad16(nrmax * 16), LSB = pad16(ncmax * 16);
             const int nla = nrmax <= 8 ? 4 : 5, nlb = (ncmax * 8 + 15) / 16 <= 4 ? 4 : 6;  // b128 loads per producer thread and row
             const int nsplit2 = NR * NC;
-            // the blocks of a slab carry different work (T = 26: 64 ... 81 tiles) and the hardware deals blocks to the CUs in index
-            // order: ~12 blocks per CU even the loads out (naphthalene / cc-pVTZ: 2.34 ms with 2 per CU, 2.17 with 12), as long
-            // as a block keeps >= 64 chunks (its prologue / atomic epilogue: nao 264 on 206 k points 0.73 -> 0.91 ms with 17-chunk
-            // blocks).  DQC_VXC_BLOCKS overrides the target (A/B runs).
-            static const int target_blocks2 = [] { const char *e = getenv("DQC_VXC_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 3072; }();
+            // two blocks per CU: the nine (NR x NC) blocks of a slab start together and stay in step (see the consumers), so the slab
+            // is fetched from HBM about once; many small blocks (DQC_VXC_BLOCKS=3072: ~12 per CU) even out the tail but start
+            // at different times -- same launch time, FETCH_SIZE x 2 (profiles/r04q_c4_blocks.txt)
+            static const int target_blocks2 = [] { const char *e = getenv("DQC_VXC_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
             int nslab = std::max(8, std::min(target_blocks2 / nsplit2, std::max(ngrid / 1024, 512 / nsplit2)) / 8 * 8);
             int slab = (ngrid + nslab - 1) / nslab;
             slab = (slab + 15) / 16 * 16;

@@ -196,13 +196,16 @@ int dqc_ao_stride(int nao) {
         const int a = e ? atoi(e) : 8;
         return (a == 2 || a == 4 || a == 8 || a == 16) ? a : 8;
     }();
+    // (measured and not it: rows an odd number of 128-byte lines apart -- 432 instead of 416 doubles at nao 412 -- leave the L2
+    // traffic of the naphthalene / cc-pVTZ Vxc pass where it is, profiles/r04r_c4_stride.txt)
     return (nao + align - 1) / align * align;
 }
 
 size_t dqc_ao_doubles(int ncomp, int ngrid, int nao) {
     // what an AO-on-grid array of ncomp components must hold: the kernels read whole 16-column tiles, i.e. up to
     // dqc_padded_nao - dqc_ao_stride doubles past the end of the last row
-    return (size_t)ncomp * (size_t)ngrid * (size_t)dqc_ao_stride(nao) + (size_t)(dqc_padded_nao(nao) - dqc_ao_stride(nao));
+    const int over = dqc_padded_nao(nao) - dqc_ao_stride(nao);
+    return (size_t)ncomp * (size_t)ngrid * (size_t)dqc_ao_stride(nao) + (size_t)(over > 0 ? over : 0);
 }
 
 size_t dqc_eri_store_doubles(int nao) {

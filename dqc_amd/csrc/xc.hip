@@ -13,6 +13,7 @@
 
 namespace dqc {
 
+template <bool EXT>
 __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                           const double *__restrict__ rho, const double *__restrict__ grho, int n, XcTerms terms,
                           int gga, const double *__restrict__ w, double *__restrict__ exc) {
@@ -22,7 +23,7 @@ __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, dou
         double gx = 0, gy = 0, gz = 0;
         if (gga) { gx = grho[i]; gy = grho[(size_t)n + i]; gz = grho[2 * (size_t)n + i]; }
         double e, vr, vs;
-        xc_point(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
+        xc_point<EXT>(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
         if (edens) edens[i] = e;
         if (exc) equad += w[i] * e;
         if (vrho) vrho[i] = vr;
@@ -164,6 +165,7 @@ DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s, double kappa = kPbeKappa, double mu = kPbeMu
 }
 
 
+template <bool EXT>
 __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
                               double *__restrict__ vgu, double *__restrict__ vgd, const double *__restrict__ ru_,
                               const double *__restrict__ rd_, const double *__restrict__ gu_,
@@ -186,6 +188,23 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
             zeta.v = fmin(fmax(zeta.v, -1.0 + 1e-10), 1.0 - 1e-10);
             for (int t = 0; t < terms.n; t++) {
                 D5 f;
+                bool ext_done = false;
+                if constexpr (EXT) {  // the round-4 functionals live in their own instantiation (see xc_funcs.hpp: xc_id_is_ext)
+                    const int id_ = terms.id[t];
+                    if (xc_id_is_x_enh(id_)) {  // enhancement-factor exchange: exact spin scaling of the unpolarised form
+                        f = 0.5 * (gga_x_by_enh(id_, 2.0 * u, 4.0 * suu) + gga_x_by_enh(id_, 2.0 * d, 4.0 * sdd));
+                        ext_done = true;
+                    } else if (id_ == DQC_XC_LDA_C_PZ || id_ == DQC_XC_GGA_C_P86) {
+                        D5 fz = (p5(1.0 + zeta, 4.0 / 3.0) + p5(1.0 - zeta, 4.0 / 3.0) - c5(2.0)) / c5(0.51984209978974632953);
+                        f = rho * pz81_eps(rho, fz, true);
+                        if (id_ == DQC_XC_GGA_C_P86) {
+                            D5 dz = 1.2599210498948732 * sqrt5(p5(0.5 * (1.0 + zeta), 5.0 / 3.0) + p5(0.5 * (1.0 - zeta), 5.0 / 3.0));
+                            f = f + p86_gradient_term(rho, suu + 2.0 * sud + sdd, dz, true);
+                        }
+                        ext_done = true;
+                    }
+                }
+                if (!ext_done)
                 switch (terms.id[t]) {
                 case DQC_XC_LDA_X:
                     f = (-0.75 * 0.98474502184269641 * 1.2599210498948732) * (u * cbrt5(u) + d * cbrt5(d));
@@ -204,18 +223,6 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                     const double ka = id_ == DQC_XC_GGA_X_PBE_R ? 1.245 : kPbeKappa, mu_ = id_ == DQC_XC_GGA_X_PBE_SOL ? 10.0 / 81.0 : kPbeMu;
                     const bool rp = id_ == DQC_XC_GGA_X_RPBE;
                     f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu, ka, mu_, rp) + pbe_x_unpol5(2.0 * d, 4.0 * sdd, ka, mu_, rp));
-                } break;
-                case DQC_XC_GGA_X_PW91: case DQC_XC_GGA_X_B86: case DQC_XC_GGA_X_G96: case DQC_XC_GGA_X_PW86: case DQC_XC_GGA_X_OPTX:
-                case DQC_XC_GGA_X_WC:  // enhancement-factor exchange: exact spin scaling of the unpolarised form
-                    f = 0.5 * (gga_x_by_enh(terms.id[t], 2.0 * u, 4.0 * suu) + gga_x_by_enh(terms.id[t], 2.0 * d, 4.0 * sdd));
-                    break;
-                case DQC_XC_LDA_C_PZ: case DQC_XC_GGA_C_P86: {
-                    D5 fz = (p5(1.0 + zeta, 4.0 / 3.0) + p5(1.0 - zeta, 4.0 / 3.0) - c5(2.0)) / c5(0.51984209978974632953);
-                    f = rho * pz81_eps(rho, fz, true);
-                    if (terms.id[t] == DQC_XC_GGA_C_P86) {
-                        D5 dz = 1.2599210498948732 * sqrt5(p5(0.5 * (1.0 + zeta), 5.0 / 3.0) + p5(0.5 * (1.0 - zeta), 5.0 / 3.0));
-                        f = f + p86_gradient_term(rho, suu + 2.0 * sud + sdd, dz, true);
-                    }
                 } break;
                 case DQC_XC_LDA_C_VWN: f = rho * vwn_pol_eps(rho, zeta); break;
                 case DQC_XC_GGA_X_B88: f = b88_spin5(u, suu) + b88_spin5(d, sdd); break;
@@ -277,8 +284,12 @@ extern "C" int dqc_xc_eval_quad(double *d_exc, double *d_edens, double *d_vrho, 
     int blocks = (n + 255) / 256;
     const int cap = d_exc ? DQC_XC_QUAD_DOUBLES - 1 : 4096;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(xc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
-                       d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
+    bool ext = false;
+    for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
+    if (ext) hipLaunchKernelGGL(xc_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
+                                d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
+    else hipLaunchKernelGGL(xc_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
+                            d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
     DQC_CHECK_LAUNCH();
     if (d_exc) {
         hipLaunchKernelGGL(xc_quad_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_exc, blocks);
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(256) void xc_mgga_pol_kernel(double *__restrict__ e
     }
 }
 
+template <bool EXT>
 __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                                double *__restrict__ vtau, const double *__restrict__ rho,
                                const double *__restrict__ grho, const double *__restrict__ tau, int n, XcTerms terms) {
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens
                                                                    : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
                     fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
                 } else {
-                    const Dual f = f_lda_gga(terms.id[t], dr, ds);
+                    const Dual f = f_lda_gga<EXT>(terms.id[t], dr, ds);
                     fv = f.v; fr = f.r; fs = f.s;
                 }
                 e += terms.c[t] * fv; vr += terms.c[t] * fr; vs += terms.c[t] * fs; vt += terms.c[t] * ft;
@@ -495,8 +507,12 @@ extern "C" int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad
     if (n <= 0) return DQC_OK;
     int blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(xc_mgga_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
-                       d_rho, d_grho, d_tau, n, t);
+    bool ext = false;
+    for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
+    if (ext) hipLaunchKernelGGL(xc_mgga_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+                                d_rho, d_grho, d_tau, n, t);
+    else hipLaunchKernelGGL(xc_mgga_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+                            d_rho, d_grho, d_tau, n, t);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
@@ -522,8 +538,12 @@ extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho
     if (n <= 0) return DQC_OK;
     int blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(xc_pol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
-                       d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
+    bool ext = false;
+    for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
+    if (ext) hipLaunchKernelGGL(xc_pol_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
+                                d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
+    else hipLaunchKernelGGL(xc_pol_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
+                            d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

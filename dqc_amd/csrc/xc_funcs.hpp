@@ -250,12 +250,20 @@ __host__ __device__ inline bool xc_id_is_gga(int id) {
 inline bool xc_host_is_lda(int id) { return xc_id_is_lda(id); }
 inline bool xc_host_is_gga(int id) { return xc_id_is_gga(id); }
 
+// the functionals of round 4 (enhancement-factor exchange, PZ81, P86): kernels that may see one are compiled as their own
+// instantiation (EXT) -- folded into the one switch they cost the PBE / LDA kernels their registers (xc_kernel 34 -> 80 us on a
+// 20-atom grid) although no such term was asked for
+__host__ __device__ inline bool xc_id_is_ext(int id) { return xc_id_is_x_enh(id) || id == DQC_XC_LDA_C_PZ || id == DQC_XC_GGA_C_P86; }
+
 // one LDA / GGA functional of the kernel set at (rho, sigma) with its first derivatives
+template <bool EXT>
 DQC_DEV Dual f_lda_gga(int id, Dual dr, Dual ds) {
-    if (xc_id_is_x_enh(id)) return gga_x_by_enh(id, dr, ds);
+    if constexpr (EXT) {
+        if (xc_id_is_x_enh(id)) return gga_x_by_enh(id, dr, ds);
+        if (id == DQC_XC_LDA_C_PZ) return dr * pz81_eps(dr, dr, false);
+        if (id == DQC_XC_GGA_C_P86) return dr * pz81_eps(dr, dr, false) + p86_gradient_term(dr, ds, dr, false);
+    }
     switch (id) {
-    case DQC_XC_LDA_C_PZ: return dr * pz81_eps(dr, dr, false);
-    case DQC_XC_GGA_C_P86: return dr * pz81_eps(dr, dr, false) + p86_gradient_term(dr, ds, dr, false);
     case DQC_XC_LDA_X: return f_lda_x(dr);
     case DQC_XC_LDA_C_PW: return f_lda_c_pw(dr);
     case DQC_XC_LDA_C_VWN: return f_lda_c_vwn(dr);
@@ -278,12 +286,13 @@ struct XcTerms {
 };
 
 // value and derivatives of sum_t c_t f_t(rho, sigma) at one point (libxc-style density threshold: all zero below 1e-15)
+template <bool EXT = false>
 DQC_DEV void xc_point(const XcTerms &terms, double r, double sigma, double &e, double &vr, double &vs) {
     e = vr = vs = 0.0;
     if (r > 1e-15) {
         const Dual dr = mk(r, 1.0, 0.0), ds = mk(sigma, 0.0, 1.0);
         for (int t = 0; t < terms.n; t++) {
-            const Dual f = f_lda_gga(terms.id[t], dr, ds);
+            const Dual f = f_lda_gga<EXT>(terms.id[t], dr, ds);
             e += terms.c[t] * f.v;
             vr += terms.c[t] * f.r;
             vs += terms.c[t] * f.s;
