@@ -96,6 +96,126 @@ __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole TC2 sequence as ONE persistent launch on ONE XCD (round 4).  The per-iteration launches above cost 7-9 us each for
+// 18 MFLOP (n = 208) -- 0.45-0.58 ms per SCF step, more than the Fock build of a benzene-size molecule and a fifth of a 20-atom
+// one (tools/gpu_one_molecule_iteration.py).  A grid-wide barrier between iterations was tried in round 2 over the whole chip:
+// every XCD has its own L2, so the iterate had to be written back / invalidated at each barrier and nothing was gained.  Here the
+// WORKERS are the blocks 0, 8, 16, ... of the launch (the others return at once): the dispatcher deals workgroups to the XCDs
+// round-robin, so all workers sit on XCD 0 and share ONE L2 -- the iterate lives there, is read with L1-bypassing loads and never
+// needs a write-back.  The workers CHECK that (hardware register XCC_ID, OR-ed into a mask before the first barrier); if they do
+// not share an XCD (another dispatch mode / partitioning) or a barrier times out, the kernel gives up, the projector's
+// idempotency error stays large and the caller takes its fallback -- no wrong result can come out of a wrong assumption.
+//   one wave per 16 x 16 tile (8 waves per worker, <= 32 workers: ld <= 256), the full K range per wave, all fragment loads of an
+//   iteration issued up front; trace / idempotency through the same atomics and slots as the launch-per-iteration kernel.
+// ctl: [0] barrier arrivals (monotone), [1] XCC mask, [2] status (0 ok, 1 workers on several XCDs, 2 barrier time-out)
+// ---------------------------------------------------------------------------------------------
+DQC_DEV double coh_load(const double *p) {  // agent-scope relaxed: bypasses the CU's L1 (the L2 is the point of coherence)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DQC_DEV void coh_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+DQC_DEV bool persist_barrier(unsigned *ctl, unsigned target) {
+    // all of this worker's stores have been issued; wait for them, arrive, spin (bounded) until every worker has arrived
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __shared__ int ok_;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int spin = 0; spin < (1 << 22); spin++) {  // ~ 0.1 us per probe: tens of milliseconds before giving up
+            if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody gave up
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) __hip_atomic_store(&ctl[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_ = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return ok_ != 0;
+}
+
+constexpr int PST_WAVES = 8;  // waves (tiles) per worker block
+__global__ __launch_bounds__(64 * PST_WAVES) void purify_tc2_persist_kernel(double *__restrict__ x0, double *__restrict__ x1, int ld,
+                                                                           double nocc, double tol, int iters,
+                                                                           double *__restrict__ trace, double *__restrict__ idem,
+                                                                           unsigned *__restrict__ ctl, int nworker, double dsc) {
+    if (blockIdx.x & 7) return;  // workers = blocks 0, 8, 16, ...: one XCD under the round-robin dispatch
+    const int w = blockIdx.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int T = ld >> 4, tile = w * PST_WAVES + wave;
+    const bool has = tile < T * T;
+    const int ti = has ? tile / T : 0, tj = has ? tile % T : 0;
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&ctl[1], 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned phase = 1;
+    if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    {
+        const unsigned mask = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__popc(mask) != 1) {  // the workers do not share an L2: every worker sees the same mask and leaves
+            if (w == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    double *cur = x0, *nxt = x1;
+    const int nk = ld >> 2;  // k-groups of 4
+    for (int k = 0; k < iters; k++) {
+        // frozen once an earlier iteration reported |X^2 - X| < tol (every worker reads the same slots: uniform decision)
+        if (k > 0 && coh_load(&idem[k - 1]) < tol) break;
+        const double tr = det_value(coh_load(&trace[k]), dsc);
+        if (has) {
+            pv4d acc = {0.0, 0.0, 0.0, 0.0};
+            // A[i][kk] = X[kk][i] (symmetric iterate): both operands are 4 rows x 128 bytes
+            const double *pa = cur + (size_t)lk * ld + ti * 16 + lr;
+            const double *pb = cur + (size_t)lk * ld + tj * 16 + lr;
+            for (int k0 = 0; k0 < nk; k0 += 16) {  // 32 loads in flight per batch
+                double a[16], b[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int kk = min(k0 + q, nk - 1);
+                    a[q] = coh_load(pa + (size_t)kk * 4 * ld);
+                    b[q] = coh_load(pb + (size_t)kk * 4 * ld);
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q++)
+                    if (k0 + q < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+            }
+            double tsum = 0.0, emax = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
+                const double x = coh_load(&cur[(size_t)row * ld + col]), x2 = acc[r];
+                const double out = tr > nocc ? x2 : 2.0 * x - x2;
+                coh_store(&nxt[(size_t)row * ld + col], out);
+                emax = fmax(emax, fabs(x2 - x));
+                if (row == col) tsum += out;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                tsum += __shfl_xor(tsum, o);
+                emax = fmax(emax, __shfl_xor(emax, o));
+            }
+            if (lane == 0) {
+                if (ti == tj) acc_add(&trace[k + 1], tsum, dsc);
+                atomicMax(reinterpret_cast<unsigned long long *>(&idem[k]), (unsigned long long)__double_as_longlong(emax));
+            }
+        }
+        phase++;
+        if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+        double *t_ = cur; cur = nxt; nxt = t_;
+    }
+    if (cur != x0 && has) {  // the result belongs in x0 (every wave copies the tile it owns)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t e = (size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr;
+            x0[e] = coh_load(&cur[e]);
+        }
+    }
+}
+
 __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double *__restrict__ trace0, size_t xstride,
                                     int sstride, double dsc) {
     x += blockIdx.x * xstride;
@@ -176,9 +296,12 @@ __global__ __launch_bounds__(64) void orth_factor_kernel(double *__restrict__ q,
 // eigendecomposition by cyclic Jacobi rotations in LDS, eigenvalues below eps N |lambda|_max dropped.  Reference:
 // the fixed-point solver of dqc/qccalc/scf_qccalc.py:109-113 (any convergent mixer has the same fixed point).
 #define DQC_DIIS_NMAX 17
-__global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cout, const double *__restrict__ gram, int H, int m) {
+__global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cout, const double *__restrict__ gram, int H, int m,
+                                                        const long long *__restrict__ d_count) {
     __shared__ double A[DQC_DIIS_NMAX][DQC_DIIS_NMAX + 1], V[DQC_DIIS_NMAX][DQC_DIIS_NMAX + 1];
-    __shared__ double rot[2];
+    // d_count: the number of valid slots is min(*d_count, H), read on the DEVICE (a step counter of an SCF loop that replays as
+    // one hipGraph: the host never learns the iteration number); NULL: m as passed
+    if (d_count != nullptr) m = (int)(*d_count < (long long)H ? (*d_count < 1 ? 1 : *d_count) : H);
     const int t = threadIdx.x, N = m + 1;
     gram += (size_t)blockIdx.x * H * H;
     cout += (size_t)blockIdx.x * H;
@@ -195,6 +318,14 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cou
         V[i][j] = i == j ? 1.0 : 0.0;
     }
     __syncthreads();
+    // Cyclic Jacobi in ROUND-ROBIN order (round 4): the N (N - 1) / 2 rotations of a sweep are done as Ne - 1 steps of Ne / 2 DISJOINT
+    // pairs (the chess-tournament schedule on Ne = N rounded up to even; a pair that holds the padding index is skipped), each
+    // step = angles by the first Ne / 2 lanes, then the row pairs, then the column pairs (+ eigenvectors) by all 64 lanes.  The
+    // one-rotation-at-a-time form (a serial chain of ~550 rotations with five barriers each) took 0.33 ms for 12 stored vectors
+    // -- invisible in the lockstep driver, a sixth of an iteration of the device-resident one-molecule loop (dqc_amd/devscf.py).
+    __shared__ double cs[DQC_DIIS_NMAX / 2 + 1][2];
+    __shared__ int pq[DQC_DIIS_NMAX / 2 + 1][2];
+    const int Ne = N + (N & 1), npair = Ne / 2;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0, dia = 0.0;  // every lane sums the whole matrix: uniform decision without a reduction
         for (int i = 0; i < N; i++) {
@@ -202,46 +333,50 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cou
             for (int j = i + 1; j < N; j++) off += A[i][j] * A[i][j];
         }
         if (off <= 1e-34 * dia) break;  // quadratic convergence: the next sweep would not change a digit
-        for (int p = 0; p < N - 1; p++)
-            for (int q = p + 1; q < N; q++) {
-                if (t == 0) {
+        for (int step = 0; step < Ne - 1; step++) {
+            if (t < npair) {
+                // player Ne - 1 stays, the others rotate: pair 0 = (Ne - 1, step), pair k = (step + k, step - k) mod (Ne - 1)
+                int p = t == 0 ? Ne - 1 : (step + t) % (Ne - 1), q = t == 0 ? step : (step - t + (Ne - 1)) % (Ne - 1);
+                if (p > q) { const int x = p; p = q; q = x; }
+                double c = 1.0, sn = 0.0;
+                if (q < N) {
                     const double apq = A[p][q];
-                    double c = 1.0, sn = 0.0;
                     if (fabs(apq) > 1e-300) {
                         const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
                         const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                         c = 1.0 / sqrt(tt * tt + 1.0);
                         sn = tt * c;
                     }
-                    rot[0] = c;
-                    rot[1] = sn;
+                } else {
+                    q = -1;  // the padding index: no rotation
                 }
-                __syncthreads();
-                const double c = rot[0], sn = rot[1];
-                // columns p, q of A and V (lane t = row), then rows p, q of A (lane t = column)
-                double akp = 0, akq = 0;
-                if (t < N) {
-                    akp = A[t][p]; akq = A[t][q];
-                    const double vkp = V[t][p], vkq = V[t][q];
-                    V[t][p] = c * vkp - sn * vkq;
-                    V[t][q] = sn * vkp + c * vkq;
-                }
-                __syncthreads();
-                if (t < N) {
-                    A[t][p] = c * akp - sn * akq;
-                    A[t][q] = sn * akp + c * akq;
-                }
-                __syncthreads();
-                if (t < N) {
-                    akp = A[p][t]; akq = A[q][t];
-                }
-                __syncthreads();
-                if (t < N) {
-                    A[p][t] = c * akp - sn * akq;
-                    A[q][t] = sn * akp + c * akq;
-                }
-                __syncthreads();
+                cs[t][0] = c; cs[t][1] = sn;
+                pq[t][0] = p; pq[t][1] = q;
             }
+            __syncthreads();
+            // A <- A J (columns p, q of every pair, all rows) and V <- V J; the pairs are disjoint, so no two items touch one element
+            for (int e = t; e < npair * N; e += 64) {
+                const int k = e / N, r = e - k * N, p = pq[k][0], q = pq[k][1];
+                if (q < 0) continue;
+                const double c = cs[k][0], sn = cs[k][1];
+                const double akp = A[r][p], akq = A[r][q], vkp = V[r][p], vkq = V[r][q];
+                A[r][p] = c * akp - sn * akq;
+                A[r][q] = sn * akp + c * akq;
+                V[r][p] = c * vkp - sn * vkq;
+                V[r][q] = sn * vkp + c * vkq;
+            }
+            __syncthreads();
+            // A <- J^T A (rows p, q of every pair, all columns)
+            for (int e = t; e < npair * N; e += 64) {
+                const int k = e / N, r = e - k * N, p = pq[k][0], q = pq[k][1];
+                if (q < 0) continue;
+                const double c = cs[k][0], sn = cs[k][1];
+                const double akp = A[p][r], akq = A[q][r];
+                A[p][r] = c * akp - sn * akq;
+                A[q][r] = sn * akp + c * akq;
+            }
+            __syncthreads();
+        }
     }
     double lmax = 0.0;
     for (int i = 0; i < N; i++) lmax = fmax(lmax, fabs(A[i][i]));
@@ -265,13 +400,45 @@ extern "C" int dqc_diis_solve(double *d_c, const double *d_gram, int nmol, int n
     using namespace dqc;
     if (nmol <= 0) return DQC_OK;
     if (m < 1 || m > nhist || nhist + 1 > DQC_DIIS_NMAX) { set_error("dqc_diis_solve: need 1 <= m <= nhist <= 16"); return DQC_EINVAL; }
-    hipLaunchKernelGGL(diis_solve_kernel, dim3(nmol), dim3(64), 0, (hipStream_t)stream, d_c, d_gram, nhist, m);
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(nmol), dim3(64), 0, (hipStream_t)stream, d_c, d_gram, nhist, m, (const long long *)nullptr);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_diis_solve_dev(double *d_c, const double *d_gram, int nmol, int nhist, const long long *d_count, void *stream) {
+    // the same with the number of valid slots min(*d_count, nhist) read from device memory (hipGraph-resident SCF loops)
+    using namespace dqc;
+    if (nmol <= 0) return DQC_OK;
+    if (nhist < 1 || nhist + 1 > DQC_DIIS_NMAX || d_count == nullptr) { set_error("dqc_diis_solve_dev: need 1 <= nhist <= 16 and a device counter"); return DQC_EINVAL; }
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(nmol), dim3(64), 0, (hipStream_t)stream, d_c, d_gram, nhist, nhist, d_count);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
 
 extern "C" int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nmol, double nocc, int iters, double tol,
                                       double *d_state, void *stream);
+
+extern "C" int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
+                                      unsigned *d_ctl, void *stream) {
+    // dqc_purify_tc2 as ONE persistent launch on one XCD (purify_tc2_persist_kernel); d_ctl: 4 unsigned ints of scratch
+    // (zeroed here).  ld <= 256.  When the kernel gives up (d_ctl[2] != 0: its workers did not share an XCD, or a barrier timed
+    // out) d_x is NOT a projector -- the caller's idempotency check sees that, as for a purification that did not converge.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ld <= 0 || (ld & 15) || ld > 256) { set_error("dqc_purify_tc2_persist: ld must be a multiple of 16, <= 256"); return DQC_EINVAL; }
+    if (iters < 1) { set_error("dqc_purify_tc2_persist: iters must be >= 1"); return DQC_EINVAL; }
+    const int T = ld / 16, nworker = (T * T + PST_WAVES - 1) / PST_WAVES;
+    double *trace = d_state, *idem = d_state + (iters + 2);
+    DQC_HIP(hipMemsetAsync(d_state, 0, sizeof(double) * 2 * (size_t)(iters + 2), st));
+    DQC_HIP(hipMemsetAsync(d_ctl, 0, sizeof(unsigned) * 4, st));
+    const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
+    hipLaunchKernelGGL(purify_trace_kernel, dim3(1), dim3(256), 0, st, d_x, ld, trace, (size_t)ld * ld, 2 * (iters + 2), dsc);
+    DQC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(purify_tc2_persist_kernel, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_x, d_tmp, ld, nocc, tol, iters,
+                       trace, idem, d_ctl, nworker, dsc);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
 
 extern "C" int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                               void *stream) {

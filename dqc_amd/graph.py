@@ -73,7 +73,9 @@ class GraphedSCFStep:
     `err` (0-dim device tensor) is the idempotency + trace error of the projector(s); the caller checks it at the point
     where it synchronises anyway and falls back to the eigh path when purification did not converge."""
 
-    def __init__(self, engine, warmup: int = 1):
+    def __init__(self, engine, warmup: int = 1, capture: bool = True):
+        """capture=False: only the static members and `_body()` -- for a caller that captures the step inside a larger graph
+        (dqc_amd/devscf.py: the whole SCF iteration)"""
         self.engine = engine
         self.pol = engine.polarized
         ws = [engine.orb_weight.u, engine.orb_weight.d] if self.pol else [engine.orb_weight]
@@ -90,6 +92,8 @@ class GraphedSCFStep:
         self.f_in = torch.zeros(shape, dtype=engine.dtype, device=engine.device)
         idx = torch.arange(n, device=engine.device)
         self.f_in[..., idx, idx] = idx.to(engine.dtype)  # any matrix with a gap at n_occ
+        if not capture:
+            return
         s = torch.cuda.Stream(device=engine.device)
         s.wait_stream(torch.cuda.current_stream(engine.device))
         with torch.cuda.stream(s):

@@ -85,6 +85,8 @@ def load():
     lib.dqc_purify_tc2_batched.argtypes = [c_dp, c_dp, c_int, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_orth_factor_batched.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_vp]
     lib.dqc_diis_solve.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_vp]
+    lib.dqc_diis_solve_dev.argtypes = [c_dp, c_dp, c_int, c_int, c_vp, c_vp]
+    lib.dqc_purify_tc2_persist.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
     lib.dqc_jk_from_tiles.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_vp]
@@ -361,6 +363,16 @@ def purify_tc2(x_pad, tmp, nocc, iters, tol, state):
     return x_pad
 
 
+def purify_tc2_persist(x_pad, tmp, nocc, iters, tol, state, ctl):
+    """purify_tc2 as ONE persistent launch on one XCD (ld <= 256); ctl: 4-element int32 device scratch, ctl[2] != 0 afterwards =
+    the kernel gave up and x_pad is not a projector (the caller's idempotency error shows it)"""
+    assert ctl.dtype == torch.int32 and ctl.is_cuda and ctl.numel() >= 4
+    with _on(x_pad.device) as st_:
+        _check(load().dqc_purify_tc2_persist(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
+                                             ctypes.c_void_p(ctl.data_ptr()), st_), "dqc_purify_tc2_persist")
+    return x_pad
+
+
 def purify_tc2_batched(x_pad, tmp, nocc, iters, tol, state):
     """in-place TC2 purification of the (nmol, ld, ld) batch x_pad; state (nmol, 2 (iters + 2))"""
     nmol, ld = x_pad.shape[0], x_pad.shape[-1]
@@ -387,6 +399,15 @@ def diis_solve(gram, m, out=None):
     with _on(gram.device) as st_:
         _check(load().dqc_diis_solve(_ptr(c), _ptr(gram), nmol, H, int(m), st_), "dqc_diis_solve")
     return c
+
+
+def diis_solve_dev(gram, count, out):
+    """diis_solve with the number of valid slots min(count, H) read from the device (count: 0-dim / 1-element int64 device tensor)"""
+    nmol, H, _ = gram.shape
+    assert count.dtype == torch.int64 and count.is_cuda
+    with _on(gram.device) as st_:
+        _check(load().dqc_diis_solve_dev(_ptr(out), _ptr(gram), nmol, H, ctypes.c_void_p(count.data_ptr()), st_), "dqc_diis_solve_dev")
+    return out
 
 
 def orth_factor(y, g):

@@ -24,6 +24,8 @@ import torch
 # 4 x wider than the spectrum) need 45-55 iterations, converged ones ~40; with 52 launches 1-3 steps per SCF run fell back to
 # eigh (4.5 ms each): 64 launches (frozen iterates cost 3 us each) make the run 8 % faster (tools/gpu_scf_time.py)
 _TC2_ITERS = int(os.environ.get("DQC_AMD_TC2_ITERS", "64"))
+# DQC_AMD_PURIFY=launch: one launch per TC2 iteration (the round-2 form, and what the lockstep batches use) instead of the persistent kernel
+_PERSISTENT = os.environ.get("DQC_AMD_PURIFY", "persist") != "launch"
 
 
 def projector_from_fock(fock: torch.Tensor, nocc: int, iters: int = None, tol: float = 1e-13, fused: bool = True):
@@ -45,7 +47,14 @@ def projector_from_fock(fock: torch.Tensor, nocc: int, iters: int = None, tol: f
         xp[:n, :n] = x
         tmp = torch.empty_like(xp)
         state = torch.empty(2 * (iters + 2), dtype=fock.dtype, device=fock.device)
-        lib.purify_tc2(xp, tmp, nocc, iters, tol, state)
+        if ld <= 256 and _PERSISTENT:
+            # ONE persistent launch whose workers share an XCD (csrc/purify.hip): 0.12-0.15 instead of 0.45-0.58 ms per step.
+            # Should the kernel give up (workers on several XCDs, a barrier time-out) the error returned below is large and the
+            # caller falls back, exactly as for a purification that did not converge
+            ctl = torch.empty(4, dtype=torch.int32, device=fock.device)
+            lib.purify_tc2_persist(xp, tmp, nocc, iters, tol, state, ctl)
+        else:
+            lib.purify_tc2(xp, tmp, nocc, iters, tol, state)
         x = xp[:n, :n]
     else:
         done = torch.zeros((), dtype=torch.bool, device=fock.device)

@@ -152,6 +152,17 @@ class SCF_QCCalc:
     def run(self, dm0="1e", eigen_options=None, fwd_options=None, bck_options=None):
         """the SCF loop, driven synchronously: every host read of the generator below is a blocking device -> host copy.
         dqc_amd.batch.run_concurrent drives many of these generators at once, one stream per molecule."""
+        # one molecule, core guess, purification step: the whole iteration replays as ONE hipGraph and the host only looks at two
+        # doubles per iteration, one iteration late (dqc_amd/devscf.py); everything else takes the host-driven generator below
+        from . import devscf
+        opts = {"maxiter": 50, "f_tol": 1e-9, "history": 12}
+        opts.update(fwd_options or {})
+        if self._engine.device.type == "cuda" and devscf.eligible(self._engine, dm0, opts):
+            loop = getattr(self, "_devloop", None)
+            if loop is None or loop.H != int(opts["history"]):
+                loop = self._devloop = devscf.DeviceLoop(self._engine, int(opts["history"]))
+            if loop.run(self, opts):
+                return self
         gen = self._run_gen(dm0, fwd_options)
         # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
         # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives

@@ -229,6 +229,11 @@ int dqc_becke_weights(double *d_w, const double *d_xyz, const int *d_atom_off, c
  * d_state: 2 * (iters + 2) doubles, on return trace[k] = tr X_k and (from offset iters + 2) idem[k] = max|X_k^2 - X_k|. */
 int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                    void *stream);
+/* the same sequence as ONE persistent launch whose worker blocks share one XCD (one L2: no write-back between iterations);
+ * ld <= 256; d_ctl: 4 unsigned ints of scratch, d_ctl[2] != 0 afterwards = the kernel gave up (see csrc/purify.hip) and d_x is not
+ * a projector -- the caller's idempotency check catches it like a purification that did not converge. */
+int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
+                           unsigned *d_ctl, void *stream);
 
 /* Orthonormal basis of the range of a projector (the orbitals `ao_orb2dm` wants, hcgto.py:272-281, without an eigensolver):
  * d_y (n, r) = P . Omega with full column rank, d_g (r, r) = Y^T Y  ->  d_q (n, r) = Y C^-T with G = C C^T, so Q^T Q = 1 and
@@ -248,6 +253,9 @@ int dqc_orth_factor_batched(double *d_q, const double *d_y, const double *d_g, i
  * numpy.linalg.lstsq gives it in the one-molecule driver.  nhist <= 16.  Replaces the fixed-point mixer of
  * scf_qccalc.py:109-113 (xitorch Broyden) -- any convergent mixer has the same fixed point. */
 int dqc_diis_solve(double *d_c, const double *d_gram, int nmol, int nhist, int m, void *stream);
+/* the same with the number of valid slots min(*d_count, nhist) read from DEVICE memory: the step counter of an SCF loop that
+ * replays as one hipGraph per iteration (dqc_amd/devscf.py) */
+int dqc_diis_solve_dev(double *d_c, const double *d_gram, int nmol, int nhist, const long long *d_count, void *stream);
 
 /* ---- Vxc matrix  (HamiltonCGTO._get_vxc_from_potinfo, hcgto.py:445-495) ----------------------
  * d_vmat (ld, ld) <- sym( sum_g w_g phi_ga [ vrho_g phi_gb + sum_d 2 vgrad_dg d_d phi_gb ] ),
