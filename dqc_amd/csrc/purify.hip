@@ -113,6 +113,10 @@ __global__ __launch_bounds__(256) void purify_tc2_kernel(double *__restrict__ xo
 DQC_DEV double coh_load(const double *p) {  // agent-scope relaxed: bypasses the CU's L1 (the L2 is the point of coherence)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// agent-scope relaxed store (sc1, write-through).  Measured both ways on MI355X (tools/gpu_projector_stress.py, n = 208): these
+// 0.60 ms per projector, PLAIN stores + s_waitcnt vmcnt(0) before the barrier (which keep the line in the L2) 0.68 ms -- the
+// phases are bound by their chain of L2 round trips and by the one XCD's L2 bandwidth (9 MB of 8-byte fragment loads per
+// phase), not by where the stored line lives
 DQC_DEV void coh_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 DQC_DEV bool persist_barrier(unsigned *ctl, unsigned target) {
@@ -214,6 +218,210 @@ __global__ __launch_bounds__(64 * PST_WAVES) void purify_tc2_persist_kernel(doub
             x0[e] = coh_load(&cur[e]);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F -> P in ONE launch: the persistent kernel above with the steps around it folded in (the torch ops they were cost 5-6 us of
+// launch latency each inside the SCF-iteration graph: ~30 nodes around 0.2 ms of purification):
+//     Gershgorin bounds (row radii through atomics, then every wave reduces the n bounds itself),  X0 = (e_max I - F) / (e_max - e_min)
+//     TC2 iterations until frozen
+//     two McWeeny steps  X <- 3 X^2 - 2 X^3   (two tile GEMMs each, a barrier between them)
+//     P = (X + X^T) / 2,   err = max |P^2 - P| + |tr P - n_occ|
+// fock, pout: (n, n) contiguous; bufs: 3 ld^2 doubles (two iterates + the X^2 of the McWeeny steps); rad: ld doubles (zeroed by the
+// host); fin: 4 doubles (zeroed): max |P^2 - P| bits, tr P, err, ran-to-the-end flag.  Same ctl / give-up protocol as purify_tc2_persist_kernel; on a
+// give-up the flag stays 0 and projector_err_kernel reports a large error.
+// ---------------------------------------------------------------------------------------------
+DQC_DEV pv4d persist_tile_gemm(const double *__restrict__ a_rows, const double *__restrict__ b_rows, int ld, int ti, int tj, int lane) {
+    // tile (ti, tj) of A B with A given through its TRANSPOSE rows (A symmetric: a_rows == A) -- both operands 4 rows x 128 bytes
+    const int lr = lane & 15, lk = lane >> 4, nk = ld >> 2;
+    pv4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double *pa = a_rows + (size_t)lk * ld + ti * 16 + lr;
+    const double *pb = b_rows + (size_t)lk * ld + tj * 16 + lr;
+    for (int k0 = 0; k0 < nk; k0 += 16) {  // 32 loads in flight per batch (64 per batch measured slower: 0.66 vs 0.60 ms at n = 208)
+        double a[16], b[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int kk = min(k0 + q, nk - 1);
+            a[q] = coh_load(pa + (size_t)kk * 4 * ld);
+            b[q] = coh_load(pb + (size_t)kk * 4 * ld);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (k0 + q < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(double *__restrict__ pout, const double *__restrict__ fock, int n,
+                                                                          int ld, double nocc, double tol, int iters,
+                                                                          double *__restrict__ bufs, double *__restrict__ rad,
+                                                                          double *__restrict__ trace, double *__restrict__ idem,
+                                                                          double *__restrict__ fin, unsigned *__restrict__ ctl,
+                                                                          int nworker, double dsc) {
+    if (blockIdx.x & 7) return;
+    const int w = blockIdx.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int T = ld >> 4, tile = w * PST_WAVES + wave;
+    const bool has = tile < T * T;
+    const int ti = has ? tile / T : 0, tj = has ? tile % T : 0;
+    const size_t n2 = (size_t)ld * ld;
+    double *cur = bufs, *nxt = bufs + n2, *yb = bufs + 2 * n2;
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(&ctl[1], 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- Gershgorin radii: rad_i = sum_{j != i} |F_ij|
+    if (has) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
+            double a = (row < n && col < n && row != col) ? fabs(fock[(size_t)row * n + col]) : 0.0;
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+            if (lr == 0 && row < n) acc_add(&rad[row], a, dsc);
+        }
+    }
+    unsigned phase = 1;
+    if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    {
+        const unsigned mask = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__popc(mask) != 1) {
+            if (w == 0 && threadIdx.x == 0) __hip_atomic_store(&ctl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    // ---- bounds (every wave for itself: n values), X0 and its trace
+    double emin = 1e300, emax = -1e300, trf = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double d = fock[(size_t)i * n + i], rr = det_value(coh_load(&rad[i]), dsc);
+        emin = fmin(emin, d - rr);
+        emax = fmax(emax, d + rr);
+        trf += d;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        emin = fmin(emin, __shfl_xor(emin, o));
+        emax = fmax(emax, __shfl_xor(emax, o));
+        trf += __shfl_xor(trf, o);
+    }
+    const double isc = 1.0 / (emax - emin);
+    if (has) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
+            const double v = (row < n && col < n) ? ((row == col ? emax : 0.0) - fock[(size_t)row * n + col]) * isc : 0.0;
+            coh_store(&cur[(size_t)row * ld + col], v);
+        }
+    }
+    if (w == 0 && threadIdx.x == 0) {
+        const double tr0 = ((double)n * emax - trf) * isc;
+        coh_store(&trace[0], dsc == 0.0 ? tr0 : __longlong_as_double(__double2ll_rn(tr0 * dsc)));
+    }
+    phase++;
+    if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    // ---- TC2
+    for (int k = 0; k < iters; k++) {
+        // the two scalars this iteration decides on and the tile's own elements are requested TOGETHER with the fragments (one L2
+        // round trip instead of three dependent ones in front of the GEMM); a frozen iterate costs one wasted tile GEMM
+        const double idprev = k > 0 ? coh_load(&idem[k - 1]) : 1e300;
+        const double trraw = coh_load(&trace[k]);
+        double xel[4] = {0.0, 0.0, 0.0, 0.0};
+        pv4d acc = {0.0, 0.0, 0.0, 0.0};
+        if (has) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) xel[r] = coh_load(&cur[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr]);
+            acc = persist_tile_gemm(cur, cur, ld, ti, tj, lane);
+        }
+        if (idprev < tol) break;
+        const double tr = det_value(trraw, dsc);
+        if (has) {
+            double tsum = 0.0, em = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
+                const double x = xel[r], x2 = acc[r];
+                const double out = tr > nocc ? x2 : 2.0 * x - x2;
+                coh_store(&nxt[(size_t)row * ld + col], out);
+                em = fmax(em, fabs(x2 - x));
+                if (row == col) tsum += out;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                tsum += __shfl_xor(tsum, o);
+                em = fmax(em, __shfl_xor(em, o));
+            }
+            if (lane == 0) {
+                if (ti == tj) acc_add(&trace[k + 1], tsum, dsc);
+                atomicMax(reinterpret_cast<unsigned long long *>(&idem[k]), (unsigned long long)__double_as_longlong(em));
+            }
+        }
+        phase++;
+        if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+        double *t_ = cur; cur = nxt; nxt = t_;
+    }
+    // ---- two McWeeny steps X <- 3 X^2 - 2 X^3 (contracting at both 0 and 1)
+    for (int mw = 0; mw < 2; mw++) {
+        if (has) {
+            const pv4d y = persist_tile_gemm(cur, cur, ld, ti, tj, lane);
+#pragma unroll
+            for (int r = 0; r < 4; r++) coh_store(&yb[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr], y[r]);
+        }
+        phase++;
+        if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+        if (has) {
+            const pv4d z = persist_tile_gemm(yb, cur, ld, ti, tj, lane);  // (X^2 symmetric: read through its rows)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const size_t e = (size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr;
+                coh_store(&nxt[e], 3.0 * coh_load(&yb[e]) - 2.0 * z[r]);
+            }
+        }
+        phase++;
+        if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+        double *t_ = cur; cur = nxt; nxt = t_;
+    }
+    // ---- P = (X + X^T) / 2 (to the caller's (n, n) array and, padded, to `nxt` for the error), tr P
+    if (has) {
+        double tsum = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = ti * 16 + lk + 4 * r, col = tj * 16 + lr;
+            const double pv = 0.5 * (coh_load(&cur[(size_t)row * ld + col]) + coh_load(&cur[(size_t)col * ld + row]));
+            coh_store(&nxt[(size_t)row * ld + col], pv);
+            if (row < n && col < n) pout[(size_t)row * n + col] = pv;
+            if (row == col) tsum += pv;
+        }
+        if (ti == tj) {
+            for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
+            if (lane == 0) atomicAdd(&fin[1], tsum);
+        }
+    }
+    phase++;
+    if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    if (has) {
+        const pv4d q = persist_tile_gemm(nxt, nxt, ld, ti, tj, lane);
+        double em = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) em = fmax(em, fabs(q[r] - coh_load(&nxt[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr])));
+        for (int o = 32; o > 0; o >>= 1) em = fmax(em, __shfl_xor(em, o));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long *>(&fin[0]), (unsigned long long)__double_as_longlong(em));
+    }
+    phase++;
+    if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    if (w == 0 && threadIdx.x == 0) {
+        fin[2] = coh_load(&fin[0]) + fabs(coh_load(&fin[1]) - nocc);
+        fin[3] = 1.0;  // ran to its end
+    }
+}
+
+__global__ void projector_init_kernel(double *__restrict__ z, int nz) {
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0.0;
+}
+__global__ void projector_init_u32_kernel(unsigned *__restrict__ z, int nz) {
+    for (int i = threadIdx.x; i < nz; i += blockDim.x) z[i] = 0u;
+}
+
+// d_err <- the persistent kernel's error when it ran to its end (ctl[2] == 0 and the closing phase was reached), else a LARGE value
+__global__ void projector_err_kernel(double *__restrict__ err, const double *__restrict__ fin, const unsigned *__restrict__ ctl) {
+    if (threadIdx.x == 0) err[0] = (ctl[2] == 0u && fin[3] == 1.0) ? fin[2] : 1e300;
 }
 
 __global__ void purify_trace_kernel(const double *__restrict__ x, int ld, double *__restrict__ trace0, size_t xstride,
@@ -418,6 +626,38 @@ extern "C" int dqc_diis_solve_dev(double *d_c, const double *d_gram, int nmol, i
 extern "C" int dqc_purify_tc2_batched(double *d_x, double *d_tmp, int ld, int nmol, double nocc, int iters, double tol,
                                       double *d_state, void *stream);
 
+extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_fock, int n, double nocc, int iters, double tol,
+                                double *d_work, void *stream) {
+    // P (n, n) <- projector onto the nocc lowest eigenvectors of the symmetric F (n, n), d_err[0] <- max |P^2 - P| + |tr P - nocc|
+    // (large when the purification did not converge or the kernel gave up: the caller then falls back to an eigensolver).
+    // n <= 256.  d_work: dqc_projector_work_doubles(n) doubles.  ONE persistent launch (projector_persist_kernel).  Enqueues only.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0 || n > 256) { set_error("dqc_projector_tc2: 1 <= n <= 256"); return DQC_EINVAL; }
+    if (iters < 1) { set_error("dqc_projector_tc2: iters must be >= 1"); return DQC_EINVAL; }
+    const int ld = (n + 15) / 16 * 16, T = ld / 16, nworker = (T * T + PST_WAVES - 1) / PST_WAVES;
+    const size_t n2 = (size_t)ld * ld;
+    double *bufs = d_work, *rad = bufs + 3 * n2, *trace = rad + ld, *idem = trace + (iters + 2), *fin = idem + (iters + 2);
+    unsigned *ctl = (unsigned *)(fin + 4);
+    // rad, trace, idem, fin, ctl start at zero -- by a KERNEL, not hipMemsetAsync: inside a hipGraph that is replayed back to back
+    // (dqc_amd/devscf.py launches iteration k + 1 before it has looked at iteration k) the memset node of the next replay was seen
+    // to clear the control words while this replay's kernels were still reading them (err = 1e300 on a perfectly good projector)
+    hipLaunchKernelGGL(projector_init_kernel, dim3(1), dim3(256), 0, st, rad, ld + 2 * (iters + 2) + 4 + 2);
+    DQC_CHECK_LAUNCH();
+    const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
+    hipLaunchKernelGGL(projector_persist_kernel, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
+                       bufs, rad, trace, idem, fin, ctl, nworker, dsc);
+    DQC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(projector_err_kernel, dim3(1), dim3(64), 0, st, d_err, fin, ctl);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" size_t dqc_projector_work_doubles(int n, int iters) {
+    const size_t ld = (size_t)(n + 15) / 16 * 16;
+    return 3 * ld * ld + ld + 2 * (size_t)(iters + 2) + 4 + 2;
+}
+
 extern "C" int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                                       unsigned *d_ctl, void *stream) {
     // dqc_purify_tc2 as ONE persistent launch on one XCD (purify_tc2_persist_kernel); d_ctl: 4 unsigned ints of scratch
@@ -429,8 +669,9 @@ extern "C" int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double
     if (iters < 1) { set_error("dqc_purify_tc2_persist: iters must be >= 1"); return DQC_EINVAL; }
     const int T = ld / 16, nworker = (T * T + PST_WAVES - 1) / PST_WAVES;
     double *trace = d_state, *idem = d_state + (iters + 2);
-    DQC_HIP(hipMemsetAsync(d_state, 0, sizeof(double) * 2 * (size_t)(iters + 2), st));
-    DQC_HIP(hipMemsetAsync(d_ctl, 0, sizeof(unsigned) * 4, st));
+    // (zeroed by kernels, not memset nodes: see dqc_projector_tc2)
+    hipLaunchKernelGGL(projector_init_kernel, dim3(1), dim3(256), 0, st, d_state, 2 * (iters + 2));
+    hipLaunchKernelGGL(projector_init_u32_kernel, dim3(1), dim3(64), 0, st, d_ctl, 4);
     const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
     hipLaunchKernelGGL(purify_trace_kernel, dim3(1), dim3(256), 0, st, d_x, ld, trace, (size_t)ld * ld, 2 * (iters + 2), dsc);
     DQC_CHECK_LAUNCH();

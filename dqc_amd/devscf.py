@@ -21,7 +21,8 @@ and the host loop is `replay(); look at the scalars of the iteration BEFORE the 
 the device runs iteration k the host reads iteration k - 1's two doubles from pinned memory.  Convergence is therefore seen one
 iteration late -- one speculative replay at the end -- and the converged pair is taken from the ring (the later iteration writes
 the other slot).  Same numbers as `_run_gen`: same error vector, same history length, same minimum-norm Pulay solve, same
-purification; it falls back to `_run_gen` when a step's purification does not converge (vanishing gap: eigh needed) and for
+purification; the step from the core guess goes through eigh when its purification fails (degenerate bare-nucleus levels), a
+later step that fails hands the run to `_run_gen` (vanishing gap: eigh needed), which also takes
 everything it does not cover (a user dm0, non-uniform occupations, a raw AO basis, direct / sharded Hamiltonians).
 """
 import os
@@ -166,7 +167,20 @@ class DeviceLoop:
         for t in (self.fh, self.eh, self.gram, self.count):
             t.zero_()
         if not float(self.perr) < 1e-9:   # (the one synchronisation before the loop)
-            return False
+            # the bare-nucleus Hamiltonian often has a degenerate or vanishing gap at the Fermi level (open pi shells, ...): this one
+            # step through eigh, as the reference's (hf.py:137-150) -- later steps that fail hand the run to the host-driven loop
+            qc.eigh_fallbacks = getattr(qc, "eigh_fallbacks", 0) + 1
+            dm = eng.scp2dm(f0)
+            fock = eng.dm2scp(dm)
+            if self.pol:
+                self.fock.copy_(fock)
+                self.dm[0].copy_(dm.u)
+                self.dm[1].copy_(dm.d)
+            else:
+                self.fock[0].copy_(fock)
+                self.dm[0].copy_(dm)
+                self.etot.copy_(eng.dm2energy(dm))
+            self.perr.zero_()
         if self.graph is None:
             self._capture()
         evs = [torch.cuda.Event(), torch.cuda.Event()]

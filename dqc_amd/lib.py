@@ -86,6 +86,9 @@ def load():
     lib.dqc_orth_factor_batched.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_vp]
     lib.dqc_diis_solve.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_vp]
     lib.dqc_diis_solve_dev.argtypes = [c_dp, c_dp, c_int, c_int, c_vp, c_vp]
+    lib.dqc_projector_work_doubles.argtypes = [c_int, c_int]
+    lib.dqc_projector_work_doubles.restype = c_sz
+    lib.dqc_projector_tc2.argtypes = [c_dp, c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_purify_tc2_persist.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp, c_vp]
     lib.dqc_df_coulomb.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_eri_tiles_to_dense.argtypes = [c_dp, c_dp, c_int, c_vp]
@@ -371,6 +374,18 @@ def purify_tc2_persist(x_pad, tmp, nocc, iters, tol, state, ctl):
         _check(load().dqc_purify_tc2_persist(_ptr(x_pad), _ptr(tmp), x_pad.shape[-1], float(nocc), int(iters), float(tol), _ptr(state),
                                              ctypes.c_void_p(ctl.data_ptr()), st_), "dqc_purify_tc2_persist")
     return x_pad
+
+
+def projector_tc2(fock, nocc, iters, tol):
+    """fock (n, n) symmetric, n <= 256 -> (P (n, n), err (0-dim)): ONE persistent launch (dqc_projector_tc2)"""
+    n = fock.shape[-1]
+    p = torch.empty((n, n), dtype=torch.float64, device=fock.device)
+    err = torch.empty(1, dtype=torch.float64, device=fock.device)
+    work = torch.empty(int(load().dqc_projector_work_doubles(n, int(iters))), dtype=torch.float64, device=fock.device)
+    with _on(fock.device) as st_:
+        _check(load().dqc_projector_tc2(_ptr(p), _ptr(err), _ptr(fock.contiguous()), n, float(nocc), int(iters), float(tol), _ptr(work), st_),
+               "dqc_projector_tc2")
+    return p, err[0]
 
 
 def purify_tc2_batched(x_pad, tmp, nocc, iters, tol, state):

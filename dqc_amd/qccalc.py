@@ -162,7 +162,9 @@ class SCF_QCCalc:
             if loop is None or loop.H != int(opts["history"]):
                 loop = self._devloop = devscf.DeviceLoop(self._engine, int(opts["history"]))
             if loop.run(self, opts):
+                self.driver_used = "device"  # (which loop produced the result: diagnostics / tests)
                 return self
+        self.driver_used = "host"
         gen = self._run_gen(dm0, fwd_options)
         # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
         # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives

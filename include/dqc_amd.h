@@ -234,6 +234,13 @@ int dqc_purify_tc2(double *d_x, double *d_tmp, int ld, double nocc, int iters, d
  * a projector -- the caller's idempotency check catches it like a purification that did not converge. */
 int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double nocc, int iters, double tol, double *d_state,
                            unsigned *d_ctl, void *stream);
+/* F -> P in ONE launch: Gershgorin bounds, X0, the TC2 iterations, two McWeeny steps, symmetrisation and the error
+ * d_err[0] = max |P^2 - P| + |tr P - nocc| (large when the purification did not converge or the kernel gave up).  d_fock, d_p: (n, n)
+ * contiguous, n <= 256; d_work: dqc_projector_work_doubles(n, iters) doubles.  Replaces `diagonalize` + the projector part of
+ * `ao_orb2dm` (dqc/qccalc/hf.py:105-113, 227-247) for uniform occupations in an orthonormal basis. */
+size_t dqc_projector_work_doubles(int n, int iters);
+int dqc_projector_tc2(double *d_p, double *d_err, const double *d_fock, int n, double nocc, int iters, double tol, double *d_work,
+                      void *stream);
 
 /* Orthonormal basis of the range of a projector (the orbitals `ao_orb2dm` wants, hcgto.py:272-281, without an eigensolver):
  * d_y (n, r) = P . Omega with full column rank, d_g (r, r) = Y^T Y  ->  d_q (n, r) = Y C^-T with G = C C^T, so Q^T Q = 1 and

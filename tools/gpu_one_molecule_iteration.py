@@ -18,8 +18,11 @@ torch.cuda.synchronize(); t0 = time.perf_counter(); qc.run(); torch.cuda.synchro
 print("%s: run() %.1f ms, %d iterations -> %.3f ms per iteration (%.0f /s), eigh fallbacks %s" % (name, 1e3 * t, qc.niter, 1e3 * t / qc.niter, qc.niter / t, getattr(qc, "eigh_fallbacks", 0)))
 e1 = float(qc.energy())
 torch.cuda.synchronize(); t0 = time.perf_counter(); qc.run(); torch.cuda.synchronize(); t = time.perf_counter() - t0
-print("%s: run() AGAIN on the same object (graphs captured) %.1f ms, %d iterations -> %.3f ms per iteration (%.0f /s); energy %.10f (first run %.10f)" % (
-    name, 1e3 * t, qc.niter, 1e3 * t / qc.niter, qc.niter / t, float(qc.energy()), e1))
+print("%s: run() AGAIN on the same object (graphs captured) %.1f ms, %d iterations -> %.3f ms per iteration (%.0f /s); energy %.10f (first run %.10f) driver %s" % (
+    name, 1e3 * t, qc.niter, 1e3 * t / qc.niter, qc.niter / t, float(qc.energy()), e1, qc.driver_used))
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable(); qc.run(); torch.cuda.synchronize(); pr.disable()
+sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(14); print("\n".join(l for l in sio.getvalue().splitlines() if l.strip())[:2600])
 os.environ["DQC_AMD_SCF_DRIVER"] = "host"
 qh = mk()
 torch.cuda.synchronize(); t0 = time.perf_counter(); qh.run(); torch.cuda.synchronize(); t = time.perf_counter() - t0
