@@ -712,6 +712,7 @@ def f_row_legs(dev, K=10):
        scan      meta-GGA: tau from the factor kernel, the three tau Vxc terms through the one-operand pair form (hcgto.py:420-438, 473-489)
        df_lda    the reference's own 20-atom benchmark call (dqc/test/benchmark.py:40-42): Mol(...).densityfit() + lda_x+lda_c_pw,
                  with the energy error of the generated auxiliary set against exact J
+       anonymous_dm  the same PBE build from a density matrix without a known orbital factor (dense density kernel, hcgto.py:407-418)
        gradient  nuclear gradient of the converged RKS PBE energy (scf_qccalc.py:63-67 by autograd there)"""
     import warnings
     import dqc_amd
@@ -773,20 +774,55 @@ def f_row_legs(dev, K=10):
             mdf = dqc_amd.Mol(geo, basis="cc-pvdz", device=dev).densityfit()
         qdf = dqc_amd.KS(mdf, xc="lda_x+lda_c_pw")
         ms, rows, shape = steady(qdf, False)
-        t0 = time.perf_counter()
-        qdf.run()
-        e_df, t_df = float(qdf.energy()), time.perf_counter() - t0
+        def timed_runs(q):  # first run(): captures the iteration graph; second: the SCF loop alone
+            ts = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                q.run()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return ts
+
+        t_df1, t_df = timed_runs(qdf)
+        e_df = float(qdf.energy())
         qex = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", device=dev), xc="lda_x+lda_c_pw")
-        t0 = time.perf_counter()
-        qex.run()
-        e_ex, t_ex = float(qex.energy()), time.perf_counter() - t0
+        t_ex1, t_ex = timed_runs(qex)
+        e_ex = float(qex.energy())
         out["df_lda"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": rows, "shape": shape,
                          "auxbasis": "autoaux (generated from cc-pVDZ: the reference's default cc-pvtz-jkfit is external data)",
-                         "scf_s": t_df, "scf_iterations": qdf.niter, "energy_ha": e_df, "exact_j_energy_ha": e_ex,
-                         "energy_error_vs_exact_j_ha": e_df - e_ex, "exact_j_scf_s": t_ex,
+                         "scf_s": t_df, "first_run_s": t_df1, "scf_iterations": qdf.niter, "energy_ha": e_df, "exact_j_energy_ha": e_ex,
+                         "energy_error_vs_exact_j_ha": e_df - e_ex, "exact_j_scf_s": t_ex, "exact_j_first_run_s": t_ex1,
+                         "exact_j_scf_iterations": qex.niter, "scf_driver": getattr(qdf, "driver_used", None),
                          "what": "the reference's own 20-atom benchmark call (dqc/test/benchmark.py:40-42): "
                                  "KS(Mol(vitamin C, 'cc-pvdz').densityfit(), 'lda_x+lda_c_pw')"}
         del qdf, qex, mdf
+        # an ANONYMOUS density matrix (a user's dm0, a density from elsewhere: no orbital factor known) -- the full-matrix
+        # density kernel Phi . D (hcgto.py:407-418) instead of the two thin GEMMs
+        qa = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc=XC)
+        ea, ha = qa._engine, qa._engine.hamilton
+        na = ea.shape[-1]
+        za = torch.zeros((na, na), dtype=torch.float64, device=dev)
+        dm_a = ea.scp2dm(ea.dm2scp(za)).clone()  # (a copy: the Hamiltonian does not know its factor)
+        before = dict(ha.grid_path_counts)
+        for _ in range(3):
+            ea.dm2scp(dm_a.clone())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(K):
+            ea.dm2scp(dm_a.clone())
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / K
+        with lib.call_trace() as tr:
+            for _ in range(3):
+                ea.dm2scp(dm_a.clone())
+        shape = {"nao": ha._nao_ao, "ngrid": int(ha.rgrid.shape[0]), "ncomp": 4, "norb_pad": 0, "naux": 0}
+        out["anonymous_dm"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": _entry_rooflines(tr.ms(), 3, shape), "shape": shape,
+                               "dense_density_passes": ha.grid_path_counts["dense"] - before.get("dense", 0),
+                               "what": "C5 molecule 0, RKS PBE Fock build of a density matrix whose orbital factor is not known: dense Phi . D density kernel"}
+        del qa, dm_a
         qg = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc=XC).run()
         qg.nuclear_gradient()
         torch.cuda.synchronize()

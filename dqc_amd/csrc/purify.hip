@@ -639,9 +639,12 @@ extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_foc
     const size_t n2 = (size_t)ld * ld;
     double *bufs = d_work, *rad = bufs + 3 * n2, *trace = rad + ld, *idem = trace + (iters + 2), *fin = idem + (iters + 2);
     unsigned *ctl = (unsigned *)(fin + 4);
-    // rad, trace, idem, fin, ctl start at zero -- by a KERNEL, not hipMemsetAsync: inside a hipGraph that is replayed back to back
-    // (dqc_amd/devscf.py launches iteration k + 1 before it has looked at iteration k) the memset node of the next replay was seen
-    // to clear the control words while this replay's kernels were still reading them (err = 1e300 on a perfectly good projector)
+    // rad, trace, idem, fin, ctl start at zero -- by a KERNEL, not hipMemsetAsync.  With a memset node here, the SECOND use of a
+    // captured SCF iteration (dqc_amd/devscf.py: replays issued back to back, a rerun of the same object) reported err = 1e300
+    // on perfectly good projectors in 6 of 6 reruns, and in none of 8 with this kernel; the same replays with a host sync between
+    // them were fine either way.  tools/ubench/graph_memset_order.hip (memset node -> slow kernel -> check, 300 launches back to
+    // back) does NOT reproduce a mis-ordered memset node, so the mechanism is not pinned down -- the control words of a kernel that
+    // spins on them through L2 are simply not left to a copy-engine / blit path.
     hipLaunchKernelGGL(projector_init_kernel, dim3(1), dim3(256), 0, st, rad, ld + 2 * (iters + 2) + 4 + 2);
     DQC_CHECK_LAUNCH();
     const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
