@@ -948,7 +948,12 @@ def cpu_baseline(nsteps, gpu_eng, gpu_dm):
     e_cpu, e_gpu = float(eng.dm2energy(dm)), float(gpu_eng.dm2energy(gpu_dm))
     par = {"parity_max_abs_fock": float((F_gpu - F_cpu).abs().max()), "parity_energy_diff_ha": e_gpu - e_cpu,
            "parity_note": "C5 molecule 0: Fock matrix (AO representation S X F X^T S) and total energy of the GPU's own "
-                          "second-iterate density, GPU dm2scp / dm2energy vs the oracle engine timed as cpu_baseline"}
+                          "second-iterate density, GPU dm2scp / dm2energy vs the oracle engine timed as cpu_baseline",
+           "functional_pins": "the bench functional gga_x_pbe+gga_c_pbe: exchange pinned by a closed form and RKS energies the "
+                              "reference's tests hold (test_xc.py:422-428, test_ks.py:49-55); gga_c_pbe has no reference-held "
+                              "literal (PBE paper + libxc constants: parity against an executed libxc unpinned).  Of the 22 "
+                              "functionals only lda_x, lda_c_pw, gga_x_pbe, mgga_x_scan have reference-held pins "
+                              "(DESIGN.md 5, pin table)"}
     return ({"value": nsteps / dt, "unit": "SCF Fock-build iterations/s", "cores": nt,
              "kind": "port", "setup_s": setup,
              "sample": "molecule 0 of the C5 set, %d dm2scp calls after 1 warm-up; J from the packed-s4 ERI matrix "

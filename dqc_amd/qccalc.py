@@ -88,6 +88,9 @@ class _Engine:
         if self.is_ks and dm.dim() == 2 and hasattr(self.hamilton, "get_elrep_plus_vxc"):
             # J + Vxc with one AO -> orthogonal conversion (the operators' own sum, ks.py:176-187, converts each)
             return self.knvext.fullmatrix() + self.hamilton.get_elrep_plus_vxc(dm)
+        if not self.is_ks and dm.dim() == 2 and self.hamilton.df is None and hasattr(self.hamilton, "get_elrep_plus_exchange"):
+            # J - K / 2 with one AO -> orthogonal conversion (hf.py:198-199 converts each operator)
+            return self.knvext.fullmatrix() + self.hamilton.get_elrep_plus_exchange(dm)
         elrep = self.hamilton.get_elrep(dm)
         if self.is_ks:
             fock = self.knvext + elrep + self.hamilton.get_vxc(dm)
