@@ -145,7 +145,21 @@ def main():
     # the batch's device memory in one request (the driver clears fresh VRAM at ~35 GB/s: its own line of the breakdown)
     brk["device_memory_reserve"] = reserve_device_memory(len(mine) * molecule_bytes(208, 353400) + (4 << 30), dev)
     from dqc_amd.batch import prepare_orthogonalisers
+    # once per PROCESS, like the reserve: the first call of every rocSOLVER / rocBLAS routine and the first launch of every kernel
+    # family of libdqc_amd.so load their code objects (tools/gpu_cold_start.py: first eigh 0.07-0.14 s, first Cholesky 0.15-0.25 s,
+    # first 20-atom molecule 0.16-0.54 s against 0.021 s for the second) -- paid here on a water molecule, its own line of the
+    # breakdown.  (Running it in a thread underneath the reserve gains nothing: the allocation holds the allocator / driver lock,
+    # 3.93 s serial against 3.96 s overlapped.)
     t = time.perf_counter()
+    wq = dqc_amd.KS(dqc_amd.Mol(M.H2O, basis="cc-pvdz", grid="sg3", device=dev), xc=XC)
+    we = wq._engine
+    wz = torch.zeros(we.shape[-2:], dtype=torch.float64, device=dev)
+    we.dm2scp(we.scp2dm(we.dm2scp(wz)))  # (integrals, grid, AO, eigh, one Fock build with the grid pass)
+    wa = we.hamilton._ovlp_ao
+    torch.linalg.eigh(torch.stack([wa, wa]))
+    torch.linalg.cholesky(wa)
+    del wq, we, wz, wa
+    t = lap("process_warmup", t)
     mols = []
     for i in mine:
         zs, pos = M.c5_molecule(i)
@@ -480,9 +494,13 @@ def main():
             "setup_s_per_rank": setup_s,
             "setup_breakdown_s_rank0": brk,
             "setup_s_excluding_memory_reserve_rank0": setup_s - brk.get("device_memory_reserve", 0.0),
+            "setup_s_batch_only_rank0": setup_s - brk.get("device_memory_reserve", 0.0) - brk.get("process_warmup", 0.0),
             "setup_note": "device_memory_reserve = ONE request for the batch's device memory: the kernel driver clears VRAM that a "
                           "previous process released at ~35 GB/s before handing it out again (instant on a box that has been idle "
-                          "for seconds; tools/gpu_alloc_cost3.py) -- a property of the box state, paid once per process",
+                          "for seconds; tools/gpu_alloc_cost3.py) -- a property of the box state, paid once per process; "
+                          "process_warmup = first-use loading of the vendor libraries' and this library's code objects, on a water "
+                          "molecule, also once per process; setup_s_batch_only_rank0 = the batch's own setup (tables, orthogonalisers, "
+                          "ERI fill, grid, AO, two Fock builds) without those two",
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
