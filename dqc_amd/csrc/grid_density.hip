@@ -29,6 +29,24 @@ constexpr int DEN_NT = DEN_BM * 4;  // threads per block
 constexpr int DEN_KC = 16;    // K chunk
 constexpr int DEN_SA = DEN_KC + 2;  // LDS row stride of the A chunk (conflict-free ds_read_b64 fragments)
 
+#ifdef DEN_TRACE  // per-block timeline for tools/ubench/den_trace*.hip: CU slot, start / MFMA-end / end (100 MHz ticks)
+__device__ long long g_den_trace[4 * 16384];
+DQC_DEV void den_trace(int k) {
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        if (k == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_den_trace[4 * blockIdx.x + 3] = (long long)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));
+        }
+        g_den_trace[4 * blockIdx.x + k] = wall_clock64();
+    }
+}
+#define DEN_TRACE_POINT(k) den_trace(k)
+#else
+#define DEN_TRACE_POINT(k)
+#endif
+
 #ifdef DEN_EXP_UNPAIRED  // A/B builds: 8-byte epilogue loads
 constexpr bool DEN_PAIRED = false;
 #else
@@ -146,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
 #pragma unroll
     for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * lda + (DEN_PAIRED ? 2 : 1) * lr;
 
+    DEN_TRACE_POINT(0);
     const int nk = ld / DEN_KC;
     // every panel is a full one: the last panel is shifted back to end at ntile and the tiles it shares with its
     // predecessor (tile index < jnew) get zero D columns, so nothing is counted twice and nothing is read past ld
@@ -154,7 +173,15 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
         v4d acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) acc[ct] = v4d{0, 0, 0, 0};
-        double2 pa0 = make_double2(0.0, 0.0), pa1 = pa0, pb[NB2];  // scalars: an array would be left in scratch
+        // TWO register sets: the loads of chunk kc + 2 are issued (in slices between the MFMA groups: waves issue in order, a wave
+        // that first pushes a whole prefetch through the address pipe starts its MFMAs late) while chunk kc is multiplied and
+        // chunk kc + 1 -- loaded one chunk period earlier -- waits in the other set to be staged.  With ONE set (rounds 1-3) a chunk
+        // was staged right after the MFMAs it was loaded under: 0.894 -> 0.865 ms on the C5 shape.  tools/ubench/den_trace_dense.hip:
+        // a block's K loop takes 50 us (was 58) for 20 us of MFMAs (676 x 64 cycles), two blocks per CU, a wave of either in its
+        // K loop 98 % of the time -- the loop itself keeps the matrix pipe half busy (fragment reads are not pipelined ahead of the
+        // MFMAs, one barrier per chunk); the consumer / producer split of the Vxc kernels is what this kernel still lacks.
+        // Scalars / token-pasted names, not arrays indexed by the set: those would live in scratch across the back-edge.
+        double2 paA0 = make_double2(0.0, 0.0), paA1 = paA0, paB0 = paA0, paB1 = paA0, pbA[NB2], pbB[NB2];
         int boff[NB2];
         bool bzero[NB2];
 #pragma unroll
@@ -163,68 +190,80 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             const int row = e / LSB, col = e - row * LSB;
             boff[i] = row * ld + jc * 16 + col;
             bzero[i] = jc * 16 + col < jnew * 16;
+            pbA[i] = pbB[i] = make_double2(0.0, 0.0);
         }
-        // the next chunk's loads are issued in slices between the MFMA groups of the current one (waves issue in
-        // order: a wave that first pushes its whole prefetch through the address pipe starts its MFMAs late)
-        auto prefetch_part = [&](int kc, int part) {
-            if (part == 0) {
-                const double *s_ = aoblk + kc * DEN_KC + aoff;
-                pa0 = *reinterpret_cast<const double2 *>(s_);
-                pa1 = *reinterpret_cast<const double2 *>(s_ + 2);
-            }
-            const double *d_ = dm + (size_t)kc * DEN_KC * ld;
-#pragma unroll
-            for (int i = 0; i < NB2; i++) {
-                if (i % NKK != part) continue;
-                pb[i] = *reinterpret_cast<const double2 *>(d_ + boff[i]);
-                if (bzero[i]) pb[i] = make_double2(0.0, 0.0);
-            }
-        };
-        auto stage = [&](int buf) {
-            double *a = sA + buf * A_SZ + arow * DEN_SA + aseg;
-            *reinterpret_cast<double2 *>(a) = pa0;
-            *reinterpret_cast<double2 *>(a + 2) = pa1;
-#pragma unroll
-            for (int i = 0; i < NB2; i++) {
-                const int e = (tid + i * DEN_NT) * 2;
-                const int row = e / LSB, col = e - row * LSB;
-                if (row < DEN_KC) {  // two 8-byte stores: odd row stride
-                    double *d = sB + buf * B_SZ + row * LSBP + col;
-                    d[0] = pb[i].x;
-                    d[1] = pb[i].y;
-                }
-            }
-        };
+#define DQC_DEN_PREF(KC, S, PART)                                                                          \
+    {                                                                                                      \
+        const int kq_ = min((KC), nk - 1); /* past-the-end chunks re-read the last one, never staged */     \
+        if ((PART) == 0) {                                                                                 \
+            const double *s_ = aoblk + kq_ * DEN_KC + aoff;                                                \
+            pa##S##0 = *reinterpret_cast<const double2 *>(s_);                                             \
+            pa##S##1 = *reinterpret_cast<const double2 *>(s_ + 2);                                         \
+        }                                                                                                  \
+        const double *d_ = dm + (size_t)kq_ * DEN_KC * ld;                                                 \
+        _Pragma("unroll") for (int i = 0; i < NB2; i++) {                                                  \
+            if (i % NKK != (PART)) continue;                                                               \
+            pb##S[i] = *reinterpret_cast<const double2 *>(d_ + boff[i]);                                   \
+            if (bzero[i]) pb##S[i] = make_double2(0.0, 0.0);                                               \
+        }                                                                                                  \
+    }
+#define DQC_DEN_STAGE(KC, S)                                                                               \
+    if ((KC) < nk) {                                                                                       \
+        const int buf_ = (KC) & 1;                                                                         \
+        double *a_ = sA + buf_ * A_SZ + arow * DEN_SA + aseg;                                              \
+        *reinterpret_cast<double2 *>(a_) = pa##S##0;                                                       \
+        *reinterpret_cast<double2 *>(a_ + 2) = pa##S##1;                                                   \
+        _Pragma("unroll") for (int i = 0; i < NB2; i++) {                                                  \
+            const int e = (tid + i * DEN_NT) * 2;                                                          \
+            const int row = e / LSB, col = e - row * LSB;                                                  \
+            if (row < DEN_KC) { /* two 8-byte stores: odd row stride */                                    \
+                double *d = sB + buf_ * B_SZ + row * LSBP + col;                                           \
+                d[0] = pb##S[i].x;                                                                         \
+                d[1] = pb##S[i].y;                                                                         \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+#define DQC_DEN_MFMAS(KC, S)                                                                               \
+    {                                                                                                      \
+        const int buf_ = (KC) & 1;                                                                         \
+        const double *a = sA + buf_ * A_SZ + (wave * 16 + lr) * DEN_SA + lk;                               \
+        const double *b = sB + buf_ * B_SZ + lk * LSBP + lr;                                               \
+        const double *b2 = b + lr; /* permuted columns: tile 2 m + h, lane lr <- column 32 m + 2 lr + h */ \
+        _Pragma("unroll") for (int kk = 0; kk < NKK; kk++) {                                               \
+            DQC_DEN_PREF((KC) + 2, S, kk) /* global loads in flight during the MFMAs */                    \
+            const double av = a[kk * 4];                                                                   \
+            _Pragma("unroll") for (int ct = 0; ct < NCT; ct++) {                                           \
+                const double bv = (DEN_PAIRED && ct < 2 * (NCT / 2)) ? b2[kk * 4 * LSBP + 32 * (ct >> 1) + (ct & 1)] \
+                                                                    : b[kk * 4 * LSBP + ct * 16];          \
+                acc[ct] = mfma_f64(av, bv, acc[ct]);                                                       \
+            }                                                                                              \
+        }                                                                                                  \
+    }
         __syncthreads();  // buffers free (previous column panel fully consumed)
 #pragma unroll
-        for (int part = 0; part < NKK; part++) prefetch_part(0, part);
-        stage(0);
+        for (int part = 0; part < NKK; part++) DQC_DEN_PREF(0, A, part)
+#pragma unroll
+        for (int part = 0; part < NKK; part++) DQC_DEN_PREF(1, B, part)
+        DQC_DEN_STAGE(0, A)
         __syncthreads();
-        for (int kc = 0; kc < nk; kc++) {
-            const int buf = kc & 1;
-            const bool more = kc + 1 < nk;
-            const double *a = sA + buf * A_SZ + (wave * 16 + lr) * DEN_SA + lk;
-            const double *b = sB + buf * B_SZ + lk * LSBP + lr;
-            const double *b2 = b + lr;  // permuted columns: tile 2 m + h, lane lr <- column 32 m + 2 lr + h
-#pragma unroll
-            for (int kk = 0; kk < NKK; kk++) {
-                if (more) prefetch_part(kc + 1, kk);  // global loads in flight during the MFMAs
-                const double av = a[kk * 4];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ct++) {
-                    const double bv = (DEN_PAIRED && ct < 2 * (NCT / 2)) ? b2[kk * 4 * LSBP + 32 * (ct >> 1) + (ct & 1)]
-                                                                        : b[kk * 4 * LSBP + ct * 16];
-#ifndef ABL_DEN_NO_MFMA
-                    acc[ct] = mfma_f64(av, bv, acc[ct]);
-#else
-                    acc[ct][0] += av * bv;
-#endif
-                }
-            }
-            if (more) stage(buf ^ 1);
+        int kc = 0;
+        for (; kc + 1 < nk; kc += 2) {
+            DQC_DEN_MFMAS(kc, A)          // (set A <- chunk kc + 2)
+            DQC_DEN_STAGE(kc + 1, B)
+            __syncthreads();
+            DQC_DEN_MFMAS(kc + 1, B)      // (set B <- chunk kc + 3)
+            DQC_DEN_STAGE(kc + 2, A)
             __syncthreads();
         }
+        if (kc < nk) {  // odd chunk count: the last chunk was staged by the loop's second half
+            DQC_DEN_MFMAS(kc, A)
+            __syncthreads();
+        }
+#undef DQC_DEN_PREF
+#undef DQC_DEN_STAGE
+#undef DQC_DEN_MFMAS
         // epilogue: row dots with Phi (and its gradient) in the accumulator layout, straight from global
+        DEN_TRACE_POINT(1);
 #ifdef ABL_DEN_NO_EPI
         if (ngrid < 0)
 #endif
@@ -244,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rh
             v += __shfl_xor(v, 8);
             p[r][q] = v;
         }
+    DEN_TRACE_POINT(2);
     if (lr == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -269,6 +309,7 @@ static constexpr size_t density_lds_bytes() {
 template <bool GGA>
 static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
                           int ngrid, int ld, const double *dm, int ntile, const double *aoe, int lda) {
+
 #define DQC_DENS_CASE(N)                                                                                           \
     case N:                                                                                                        \
         if constexpr (!GGA || N <= 14) { /* GGA panels of 15 / 16 tiles would spill: never instantiated */          \
@@ -303,23 +344,6 @@ static int launch_density(int nct, dim3 grid, hipStream_t st, double *rho, doubl
 // leaves the VGPRs.  Phase 2 and the row-dot epilogue are those of density_kernel.
 //   orb  (ld x RP)  row-major, zero padded;  orbt (RP x ld) its transpose;  RP = 16 * NRT.
 // ---------------------------------------------------------------------------------------------
-#ifdef DEN_TRACE  // per-block timeline for tools/ubench/den_trace.hip: CU slot, start / MFMA-end / end (100 MHz ticks)
-__device__ long long g_den_trace[4 * 16384];
-DQC_DEV void den_trace(int k) {
-    if (threadIdx.x == 0 && blockIdx.x < 16384) {
-        if (k == 0) {
-            unsigned hw, xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            g_den_trace[4 * blockIdx.x + 3] = (long long)(((xcc & 7u) << 8) | ((hw >> 8) & 0xffu));
-        }
-        g_den_trace[4 * blockIdx.x + k] = wall_clock64();
-    }
-}
-#define DEN_TRACE_POINT(k) den_trace(k)
-#else
-#define DEN_TRACE_POINT(k)
-#endif
 
 template <int NRT>
 struct LrGeom {
