@@ -231,13 +231,16 @@ __global__ __launch_bounds__(64 * PST_WAVES) void purify_tc2_persist_kernel(doub
 // host); fin: 4 doubles (zeroed): max |P^2 - P| bits, tr P, err, ran-to-the-end flag.  Same ctl / give-up protocol as purify_tc2_persist_kernel; on a
 // give-up the flag stays 0 and projector_err_kernel reports a large error.
 // ---------------------------------------------------------------------------------------------
-DQC_DEV pv4d persist_tile_gemm(const double *__restrict__ a_rows, const double *__restrict__ b_rows, int ld, int ti, int tj, int lane) {
-    // tile (ti, tj) of A B with A given through its TRANSPOSE rows (A symmetric: a_rows == A) -- both operands 4 rows x 128 bytes
+DQC_DEV pv4d persist_tile_gemm(const double *__restrict__ a_rows, const double *__restrict__ b_rows, int ld, int ti, int tj, int lane,
+                               int kpart = 0, int ksplit = 1) {
+    // tile (ti, tj) of A B with A given through its TRANSPOSE rows (A symmetric: a_rows == A) -- both operands 4 rows x 128 bytes.
+    // kpart / ksplit: this wave's share of the K range (split-K over the waves of a workgroup, summed by tile_reduce)
     const int lr = lane & 15, lk = lane >> 4, nk = ld >> 2;
+    const int per = (nk + ksplit - 1) / ksplit, kbeg = kpart * per, kend = min(nk, kbeg + per);
     pv4d acc = {0.0, 0.0, 0.0, 0.0};
     const double *pa = a_rows + (size_t)lk * ld + ti * 16 + lr;
     const double *pb = b_rows + (size_t)lk * ld + tj * 16 + lr;
-    for (int k0 = 0; k0 < nk; k0 += 16) {  // 32 loads in flight per batch (64 per batch measured slower: 0.66 vs 0.60 ms at n = 208)
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {  // 32 loads in flight per batch (64 per batch measured slower: 0.66 vs 0.60 ms at n = 208)
         double a[16], b[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -247,11 +250,37 @@ DQC_DEV pv4d persist_tile_gemm(const double *__restrict__ a_rows, const double *
         }
 #pragma unroll
         for (int q = 0; q < 16; q++)
-            if (k0 + q < nk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+            if (k0 + q < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
     }
     return acc;
 }
 
+// sum of the KS partial tiles of a workgroup's waves (wave = KS * local tile + kpart) into the kpart == 0 wave, through LDS, in a
+// fixed order (deterministic).  Called by EVERY wave of the block (two barriers).
+template <int KS>
+DQC_DEV pv4d tile_reduce(pv4d acc, double (*sred)[256], int wave, int lane) {
+    if constexpr (KS == 1) return acc;
+    const int kpart = wave % KS;
+    if (kpart) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) sred[wave][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (!kpart) {
+#pragma unroll
+        for (int p = 1; p < KS; p++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] += sred[wave + p][r * 64 + lane];
+    }
+    __syncthreads();
+    return acc;
+}
+
+// KS: split-K factor.  A tile GEMM of one wave is a chain of dependent L2 round trips (ld / 4 fragment pairs, 32 in flight) and the
+// kernel is a chain of ~35 such GEMMs with a grid barrier each: KS waves per tile shorten every link (n = 114: 32 -> 16 fragment
+// pairs per wave, one batch) at the price of an LDS reduction -- pays for mid-sized matrices only (see dqc_projector_tc2).  gemm = has (this wave multiplies), own = the wave that owns the
+// tile's epilogue (kpart == 0).
+template <int KS>
 __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(double *__restrict__ pout, const double *__restrict__ fock, int n,
                                                                           int ld, double nocc, double tol, int iters,
                                                                           double *__restrict__ bufs, double *__restrict__ rad,
@@ -259,11 +288,14 @@ __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(doubl
                                                                           double *__restrict__ fin, unsigned *__restrict__ ctl,
                                                                           int nworker, double dsc) {
     if (blockIdx.x & 7) return;
+    __shared__ double sred[KS == 1 ? 1 : PST_WAVES][256];
     const int w = blockIdx.x >> 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
-    const int T = ld >> 4, tile = w * PST_WAVES + wave;
-    const bool has = tile < T * T;
-    const int ti = has ? tile / T : 0, tj = has ? tile % T : 0;
+    const int kpart = wave % KS;
+    const int T = ld >> 4, tile = w * (PST_WAVES / KS) + wave / KS;
+    const bool gemm = tile < T * T;       // this wave multiplies its share of tile `tile`
+    const int ti = gemm ? tile / T : 0, tj = gemm ? tile % T : 0;
+    const bool has = gemm && kpart == 0;  // ... and owns the tile's element-wise work
     const size_t n2 = (size_t)ld * ld;
     double *cur = bufs, *nxt = bufs + n2, *yb = bufs + 2 * n2;
     if (threadIdx.x == 0) {
@@ -329,9 +361,10 @@ __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(doubl
         if (has) {
 #pragma unroll
             for (int r = 0; r < 4; r++) xel[r] = coh_load(&cur[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr]);
-            acc = persist_tile_gemm(cur, cur, ld, ti, tj, lane);
         }
+        if (gemm) acc = persist_tile_gemm(cur, cur, ld, ti, tj, lane, kpart, KS);
         if (idprev < tol) break;
+        acc = tile_reduce<KS>(acc, sred, wave, lane);
         const double tr = det_value(trraw, dsc);
         if (has) {
             double tsum = 0.0, em = 0.0;
@@ -359,19 +392,28 @@ __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(doubl
     }
     // ---- two McWeeny steps X <- 3 X^2 - 2 X^3 (contracting at both 0 and 1)
     for (int mw = 0; mw < 2; mw++) {
-        if (has) {
-            const pv4d y = persist_tile_gemm(cur, cur, ld, ti, tj, lane);
+        {
+            pv4d y = {0.0, 0.0, 0.0, 0.0};
+            if (gemm) y = persist_tile_gemm(cur, cur, ld, ti, tj, lane, kpart, KS);
+            y = tile_reduce<KS>(y, sred, wave, lane);
+            if (has) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) coh_store(&yb[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr], y[r]);
+                for (int r = 0; r < 4; r++) coh_store(&yb[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr], y[r]);
+            }
         }
         phase++;
         if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
-        if (has) {
-            const pv4d z = persist_tile_gemm(yb, cur, ld, ti, tj, lane);  // (X^2 symmetric: read through its rows)
+        {
+            pv4d z = {0.0, 0.0, 0.0, 0.0};
+            // (X^2 symmetric: read through its rows)
+            if (gemm) z = persist_tile_gemm(yb, cur, ld, ti, tj, lane, kpart, KS);
+            z = tile_reduce<KS>(z, sred, wave, lane);
+            if (has) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const size_t e = (size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr;
-                coh_store(&nxt[e], 3.0 * coh_load(&yb[e]) - 2.0 * z[r]);
+                for (int r = 0; r < 4; r++) {
+                    const size_t e = (size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr;
+                    coh_store(&nxt[e], 3.0 * coh_load(&yb[e]) - 2.0 * z[r]);
+                }
             }
         }
         phase++;
@@ -396,8 +438,10 @@ __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(doubl
     }
     phase++;
     if (!persist_barrier(ctl, (unsigned)nworker * phase)) return;
+    pv4d q = {0.0, 0.0, 0.0, 0.0};
+    if (gemm) q = persist_tile_gemm(nxt, nxt, ld, ti, tj, lane, kpart, KS);
+    q = tile_reduce<KS>(q, sred, wave, lane);
     if (has) {
-        const pv4d q = persist_tile_gemm(nxt, nxt, ld, ti, tj, lane);
         double em = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) em = fmax(em, fabs(q[r] - coh_load(&nxt[(size_t)(ti * 16 + lk + 4 * r) * ld + tj * 16 + lr])));
@@ -635,7 +679,17 @@ extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_foc
     hipStream_t st = (hipStream_t)stream;
     if (n <= 0 || n > 256) { set_error("dqc_projector_tc2: 1 <= n <= 256"); return DQC_EINVAL; }
     if (iters < 1) { set_error("dqc_projector_tc2: iters must be >= 1"); return DQC_EINVAL; }
-    const int ld = (n + 15) / 16 * 16, T = ld / 16, nworker = (T * T + PST_WAVES - 1) / PST_WAVES;
+    const int ld = (n + 15) / 16 * 16, T = ld / 16;
+    // split-K (two waves per tile) for 80 < n <= 160, where a tile GEMM is a short chain of L2 round trips and more waves shorten it
+    // (n = 114: 0.340 -> 0.284 ms); at n = 208 the XCD's L2 bandwidth is the bound and more waves only add contention (0.55 -> 0.63 ms;
+    // four waves per tile: 1.3 ms), at n = 24 the LDS reduction costs more than the chain (0.13 -> 0.21 ms).
+    // DQC_PROJECTOR_KSPLIT = 1 | 2 overrides (A/B runs)
+    static const int ks_env = [] { const char *e = getenv("DQC_PROJECTOR_KSPLIT"); return e ? atoi(e) : 0; }();
+    int ks = (T >= 6 && T <= 10) ? 2 : 1;
+    if (ks_env == 1 || ks_env == 2) ks = ks_env;
+    // (tried for n = 208 / 250, where a GEMM step takes 16 us: the block's eight waves sharing their tile row's A panel through LDS --
+    // 44 % less L2 traffic, 0.555 -> 0.620 ms; so neither the L2 bandwidth nor the length of the load chain alone is the bound there)
+    const int nworker = (T * T * ks + PST_WAVES - 1) / PST_WAVES;
     const size_t n2 = (size_t)ld * ld;
     double *bufs = d_work, *rad = bufs + 3 * n2, *trace = rad + ld, *idem = trace + (iters + 2), *fin = idem + (iters + 2);
     unsigned *ctl = (unsigned *)(fin + 4);
@@ -648,8 +702,12 @@ extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_foc
     hipLaunchKernelGGL(projector_init_kernel, dim3(1), dim3(256), 0, st, rad, ld + 2 * (iters + 2) + 4 + 2);
     DQC_CHECK_LAUNCH();
     const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
-    hipLaunchKernelGGL(projector_persist_kernel, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
-                       bufs, rad, trace, idem, fin, ctl, nworker, dsc);
+    if (ks == 2)
+        hipLaunchKernelGGL(projector_persist_kernel<2>, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
+                           bufs, rad, trace, idem, fin, ctl, nworker, dsc);
+    else
+        hipLaunchKernelGGL(projector_persist_kernel<1>, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
+                           bufs, rad, trace, idem, fin, ctl, nworker, dsc);
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(projector_err_kernel, dim3(1), dim3(64), 0, st, d_err, fin, ctl);
     DQC_CHECK_LAUNCH();
