@@ -15,7 +15,7 @@ _lib = None
 
 XC_IDS = {"lda_x": 1, "lda_c_vwn": 7, "lda_c_pw": 12, "lda_c_pw_mod": 13, "gga_x_pbe": 101, "gga_x_pbe_r": 102, "gga_x_b88": 106,
           "gga_x_pbe_sol": 116, "gga_x_rpbe": 117, "gga_c_pbe": 130, "gga_c_lyp": 131, "gga_c_pbe_sol": 133,
-          "mgga_x_scan": 263, "mgga_c_scan": 267,
+          "mgga_x_scan": 263, "mgga_c_scan": 267, "mgga_x_tpss": 202,
           "lda_c_pz": 9, "gga_x_b86": 103, "gga_x_g96": 107, "gga_x_pw86": 108, "gga_x_pw91": 109, "gga_x_optx": 110, "gga_x_wc": 118,
           "gga_c_p86": 132}
 

@@ -12,7 +12,7 @@ from . import lib
 from .utils.datastruct import ValGrad, SpinParam
 
 _FAMILY = {"lda_x": 1, "lda_c_pw": 1, "lda_c_pw_mod": 1, "lda_c_vwn": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "gga_x_b88": 2, "gga_c_lyp": 2,
-           "gga_x_pbe_r": 2, "gga_x_pbe_sol": 2, "gga_x_rpbe": 2, "gga_c_pbe_sol": 2, "mgga_x_scan": 4, "mgga_c_scan": 4,
+           "gga_x_pbe_r": 2, "gga_x_pbe_sol": 2, "gga_x_rpbe": 2, "gga_c_pbe_sol": 2, "mgga_x_scan": 4, "mgga_c_scan": 4, "mgga_x_tpss": 4,
            # round 4: exchange GGAs given by an enhancement factor (one table entry each, csrc/xc_funcs.hpp), PZ81, P86
            "gga_x_pw91": 2, "gga_x_b86": 2, "gga_x_g96": 2, "gga_x_pw86": 2, "gga_x_optx": 2, "gga_x_wc": 2, "lda_c_pz": 1, "gga_c_p86": 2}
 

@@ -135,6 +135,7 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
 #define DQC_XC_GGA_C_LYP 131
 #define DQC_XC_GGA_C_P86 132     /* Perdew 86 on PZ81 */
 #define DQC_XC_GGA_C_PBE_SOL 133 /* PBEsol correlation: beta = 0.046 */
+#define DQC_XC_MGGA_X_TPSS 202
 #define DQC_XC_MGGA_X_SCAN 263
 #define DQC_XC_MGGA_C_SCAN 267
 int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
@@ -157,7 +158,7 @@ int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double 
 
 /* meta-GGA variant (CalcMGGALibXCUnpol, dqc/xc/libxc_wrapper.py; inputs rho, grad rho, tau -- the supported
  * functionals do not depend on the laplacian, so vlapl = 0): adds d_vtau (n).  Terms may mix LDA/GGA ids with
- * DQC_XC_MGGA_X_SCAN and DQC_XC_MGGA_C_SCAN. */
+ * DQC_XC_MGGA_X_SCAN, DQC_XC_MGGA_X_TPSS and DQC_XC_MGGA_C_SCAN. */
 int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d_vtau, const double *d_rho,
                      const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
                      int nterm, void *stream);

@@ -429,6 +429,38 @@ def test_scan_closed_form_and_derivatives():
     assert np.allclose((f(rho, sig, tau + h) - f(rho, sig, tau - h)) / (2 * h), vt, rtol=1e-6, atol=1e-8)
 
 
+def test_tpss_exchange_published_pins_and_derivatives():
+    """mgga_x_tpss (no formula or literal in the reference): F_x = 1 for the uniform gas; the exchange energy of the exact hydrogen
+    atom is -0.3125 Ha -- the condition that fixed the paper's constants c and e (Tao, Perdew, Staroverov, Scuseria, PRL 91,
+    146401); the second-order gradient coefficient 10/81 at alpha = 1 (z -> 0 limit of the slowly varying gas); finite differences"""
+    rr = np.array([0.05, 0.7, 4.0])
+    tu = 0.3 * (3 * np.pi ** 2 * rr) ** (2 / 3) * rr
+    lda = -0.75 * (3 / np.pi) ** (1 / 3) * rr ** (4 / 3)
+    assert np.allclose(oxc.mgga_x_tpss(rr, np.zeros(3), tu)[0], lda, rtol=1e-14)
+    # slowly varying: F_x - 1 -> (10/81) p  (tau = tau_unif + tau_W: alpha = 1, z = 5p/3 / (1 + 5p/3) small)
+    p = 1e-6
+    sig = p * 4 * (3 * np.pi ** 2) ** (2 / 3) * rr ** (8 / 3)
+    fx = oxc.mgga_x_tpss(rr, sig, tu + sig / (8 * rr))[0] / lda
+    assert np.allclose((fx - 1) / p, 10 / 81, rtol=2e-3)
+    r = np.linspace(1e-6, 40, 200001)
+    rho = np.exp(-2 * r) / np.pi
+    sg = 4 * rho * rho
+    e = oxc.mgga_x_tpss(2 * rho, 4 * sg, 2 * sg / (8 * rho))[0]   # fully polarised: E_x[n, 0] = E_x[2n] / 2
+    assert abs(0.5 * np.sum(4 * np.pi * r * r * e) * (r[1] - r[0]) + 0.3125) < 2e-6
+    rng = np.random.default_rng(3)
+    n = 200
+    rho = rng.uniform(0.05, 1.5, n)
+    gr = rng.standard_normal((3, n)) * rho
+    sig = (gr * gr).sum(0)
+    tau = sig / (8 * rho) + rng.uniform(0.01, 2.0, n) * 0.3 * (3 * np.pi ** 2 * rho) ** (2 / 3) * rho
+    e, vr, vs, vt = oxc.mgga_x_tpss(rho, sig, tau)
+    f = lambda a, b, c: oxc.mgga_x_tpss(a, b, c)[0]  # noqa: E731
+    h = 1e-6
+    assert np.allclose((f(rho + h, sig, tau) - f(rho - h, sig, tau)) / (2 * h), vr, rtol=1e-6, atol=1e-8)
+    assert np.allclose((f(rho, sig + h, tau) - f(rho, sig - h, tau)) / (2 * h), vs, rtol=1e-6, atol=1e-8)
+    assert np.allclose((f(rho, sig, tau + h) - f(rho, sig, tau - h)) / (2 * h), vt, rtol=1e-6, atol=1e-8)
+
+
 def test_rks_scan_reference_literals():
     """dqc/test/test_ks.py:58-63, 89-111: RKS mgga_x_scan / 6-311++G** / grid 4, atol 1.3e-3 (H2 is xfail there)"""
     for sym, d, ref in [("Li", 5.0, -14.8687500), ("N", 2.0, -109.055074), ("C O", 2.0, -112.836255)]:
