@@ -969,7 +969,7 @@ def cpu_baseline(nsteps, gpu_eng, gpu_dm):
                           "second-iterate density, GPU dm2scp / dm2energy vs the oracle engine timed as cpu_baseline",
            "functional_pins": "the bench functional gga_x_pbe+gga_c_pbe: exchange pinned by a closed form and RKS energies the "
                               "reference's tests hold (test_xc.py:422-428, test_ks.py:49-55); gga_c_pbe has no reference-held "
-                              "literal (PBE paper + libxc constants: parity against an executed libxc unpinned).  Of the 23 "
+                              "literal (PBE paper + libxc constants: parity against an executed libxc unpinned).  Of the 24 "
                               "functionals only lda_x, lda_c_pw, gga_x_pbe, mgga_x_scan have reference-held pins "
                               "(DESIGN.md 5, pin table)"}
     return ({"value": nsteps / dt, "unit": "SCF Fock-build iterations/s", "cores": nt,

@@ -307,7 +307,7 @@ extern "C" int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, con
 namespace dqc {
 
 __host__ __device__ inline bool xc_id_is_mgga(int id) {
-    return id == DQC_XC_MGGA_X_SCAN || id == DQC_XC_MGGA_C_SCAN || id == DQC_XC_MGGA_X_TPSS;
+    return id == DQC_XC_MGGA_X_SCAN || id == DQC_XC_MGGA_C_SCAN || id == DQC_XC_MGGA_X_TPSS || id == DQC_XC_MGGA_C_TPSS;
 }
 
 DQC_DEV D5 exp5c(D5 a) {  // exp with the argument clipped at 50 (only active in a discarded branch)
@@ -454,6 +454,117 @@ DQC_DEV D5 f_mgga_c_scan_pol(D5 u, D5 d, D5 sg, D5 ta) {
     return rho * (eps1 + fc * (eps0 - eps1));
 }
 
+// ---------------------------------------------------------------------------------------------
+// TPSS correlation (mgga_c_tpss): Tao, Perdew, Staroverov, Scuseria, PRL 91, 146401 (2003), eqs. (11)-(14) -- formulas in
+// oracle/xc.py.  Unlike SCAN it depends on sigma_uu, sigma_ud, sigma_dd separately (|grad zeta|, the one-spin PBE terms): six
+// variables with tau.  The five-slot dual carries (rho_u, rho_d, sigma_uu, sigma_ud, sigma_dd); tau enters ONLY through
+// z = tau_W / tau, so the core takes z as an argument: evaluated once with z = sigma / (8 n tau) as a dual of the five (tau fixed)
+// and once with z alone as the variable -- d e / d tau = (d e / d z)(-z / tau).  The closed-shell kernel has three variables
+// (rho, sigma, tau) and evaluates the same core once at rho_u = rho_d = rho / 2, sigma_ss' = sigma / 4.
+// No formula or literal in the reference: pinned by its construction (no correlation for a one-electron density, PBE where z = 0,
+// uniform-gas limit) -- parity against libxc UNPINNED.
+// ---------------------------------------------------------------------------------------------
+DQC_DEV D5 pbe_c_eps5(D5 rho, D5 eps, D5 phi2, D5 phi3, D5 sig) {
+    const double beta = kPbeBeta, gamma = 0.031090690869654895;
+    D5 kf = cbrt5((3.0 * kPi * kPi) * rho);
+    D5 t2 = sig / (4.0 * phi2 * ((4.0 / kPi) * kf) * (rho * rho));
+    D5 A = c5(beta / gamma) / expm15(c5(0.0) - eps / (gamma * phi3));
+    D5 At2 = A * t2;
+    D5 X = (beta / gamma) * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2);
+    return eps + gamma * phi3 * log1p5(X);
+}
+
+DQC_DEV D5 pbe_c_eps5_ferro(D5 rs_, D5 sss) {  // eps_PBE(n_s, 0, grad n_s, 0): zeta = 1 in closed form (phi = 2^(-1/3), PW92's ferromagnetic fit)
+    const double a = 0.01554534543482745, alpha1 = 0.20548, b1 = 14.1189, b2 = 6.1977, b3 = 3.3662, b4 = 0.62517;
+    D5 rs = cbrt5((3.0 / (4.0 * kPi)) / rs_);
+    D5 sq = sqrt5(rs);
+    D5 q1 = (2.0 * a) * (b1 * sq + b2 * rs + b3 * (rs * sq) + b4 * (rs * rs));
+    D5 eps = (-2.0 * a) * (1.0 + alpha1 * rs) * log1p5(1.0 / q1);
+    return pbe_c_eps5(rs_, eps, c5(0.62996052494743658), c5(0.5), sss);  // 2^(-2/3), 2^(-1)
+}
+
+DQC_DEV D5 dmax5(D5 a, D5 b) { return a.v >= b.v ? a : b; }
+
+DQC_DEV D5 tpss_c_core(D5 u, D5 d, D5 suu, D5 sud, D5 sdd, D5 z) {
+    const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
+    D5 rho = u + d;
+    D5 zeta = (u - d) / rho;
+    zeta.v = fmin(fmax(zeta.v, -1.0 + 1e-10), 1.0 - 1e-10);
+    D5 sig = suu + 2.0 * sud + sdd;
+    sig.v = fmax(sig.v, 1e-40);
+    D5 opz = 1.0 + zeta, omz = 1.0 - zeta;
+    D5 phi = 0.5 * (p5(opz, 2.0 / 3.0) + p5(omz, 2.0 / 3.0));
+    D5 eps = pbe_c_eps5(rho, pw92_pol_eps(rho, zeta, a3), phi * phi, phi * phi * phi, sig);
+    D5 et_u = dmax5(pbe_c_eps5_ferro(u, suu), eps);
+    D5 et_d = dmax5(pbe_c_eps5_ferro(d, sdd), eps);
+    D5 z2_ = zeta * zeta;
+    D5 c0 = 0.53 + 0.87 * z2_ + 0.50 * (z2_ * z2_) + 2.26 * (z2_ * z2_ * z2_);
+    D5 gz2 = (omz * omz * suu - 2.0 * (omz * opz) * sud + opz * opz * sdd) / (rho * rho);
+    D5 xi2 = gz2 / (4.0 * p5((3.0 * kPi * kPi) * rho, 2.0 / 3.0));
+    D5 cd = 1.0 + 0.5 * xi2 * (p5(opz, -4.0 / 3.0) + p5(omz, -4.0 / 3.0));
+    D5 cd2 = cd * cd;
+    D5 C = c0 / (cd2 * cd2);
+    D5 zz = z * z;
+    D5 erev = eps * (1.0 + C * zz) - (1.0 + C) * zz * ((u * et_u + d * et_d) / rho);
+    return rho * erev * (1.0 + 2.8 * erev * (zz * z));
+}
+
+// polarised meta-GGA correlation with a gradient potential PER SPIN (dqc_xc_eval_mgga_pol2): mgga_c_scan (depends on the total
+// gradient: both potentials are 2 v_sigma grad n) and mgga_c_tpss (v_grad,u = 2 v_uu grad n_u + v_ud grad n_d, libxc.py:205-215)
+__global__ __launch_bounds__(256) void xc_mgga_pol2_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
+                                                           double *__restrict__ vgu, double *__restrict__ vgd, double *__restrict__ vtau,
+                                                           const double *__restrict__ ru_, const double *__restrict__ rd_,
+                                                           const double *__restrict__ gu_, const double *__restrict__ gd_,
+                                                           const double *__restrict__ tu_, const double *__restrict__ td_, int n,
+                                                           XcTerms terms) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double ru = ru_[i], rd = rd_[i];
+        double gu[3], gd[3];
+        for (int k = 0; k < 3; k++) { gu[k] = gu_[(size_t)k * n + i]; gd[k] = gd_[(size_t)k * n + i]; }
+        double e = 0, dv[5] = {0, 0, 0, 0, 0}, vt = 0;  // d/d (rho_u, rho_d, sigma_uu, sigma_ud, sigma_dd), d/d tau
+        if (ru + rd > 1e-15) {
+            ru = fmax(ru, 0.5e-15);
+            rd = fmax(rd, 0.5e-15);
+            const double suu = fmax(gu[0] * gu[0] + gu[1] * gu[1] + gu[2] * gu[2], 1e-40);
+            const double sdd = fmax(gd[0] * gd[0] + gd[1] * gd[1] + gd[2] * gd[2], 1e-40);
+            const double sud = gu[0] * gd[0] + gu[1] * gd[1] + gu[2] * gd[2];
+            const double tk = fmax(tu_[i] + td_[i], 1e-20);
+            for (int t = 0; t < terms.n; t++) {
+                if (terms.id[t] == DQC_XC_MGGA_C_SCAN) {
+                    const double sig = fmax(suu + 2.0 * sud + sdd, 1e-40);
+                    const D5 f = f_mgga_c_scan_pol(var5(ru, 0), var5(rd, 1), var5(sig, 2), var5(tk, 3));
+                    e += terms.c[t] * f.v;
+                    dv[0] += terms.c[t] * f.d[0]; dv[1] += terms.c[t] * f.d[1];
+                    dv[2] += terms.c[t] * f.d[2]; dv[3] += terms.c[t] * 2.0 * f.d[2]; dv[4] += terms.c[t] * f.d[2];
+                    vt += terms.c[t] * f.d[3];
+                } else {  // DQC_XC_MGGA_C_TPSS
+                    const D5 u = var5(ru, 0), d = var5(rd, 1), a = var5(suu, 2), b = var5(sud, 3), c = var5(sdd, 4);
+                    D5 sg = a + 2.0 * b + c;
+                    sg.v = fmax(sg.v, 1e-40);
+                    D5 z = sg / ((8.0 * tk) * (u + d));
+                    const bool over = z.v > 1.0;
+                    if (over) z = c5(1.0);
+                    const D5 f = tpss_c_core(u, d, a, b, c, z);
+                    e += terms.c[t] * f.v;
+                    for (int k = 0; k < 5; k++) dv[k] += terms.c[t] * f.d[k];
+                    if (!over) {
+                        const D5 fz = tpss_c_core(c5(ru), c5(rd), c5(suu), c5(sud), c5(sdd), var5(z.v, 0));
+                        vt += terms.c[t] * fz.d[0] * (-z.v / tk);
+                    }
+                }
+            }
+        }
+        if (edens) edens[i] = e;
+        if (vru) { vru[i] = dv[0]; vrd[i] = dv[1]; }
+        if (vgu)
+            for (int k = 0; k < 3; k++) {
+                vgu[(size_t)k * n + i] = 2.0 * dv[2] * gu[k] + dv[3] * gd[k];
+                vgd[(size_t)k * n + i] = 2.0 * dv[4] * gd[k] + dv[3] * gu[k];
+            }
+        if (vtau) vtau[i] = vt;
+    }
+}
+
 __global__ __launch_bounds__(256) void xc_mgga_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
                                                           double *__restrict__ vgrad, double *__restrict__ vtau,
                                                           const double *__restrict__ ru_, const double *__restrict__ rd_,
@@ -497,9 +608,17 @@ __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens
             for (int t = 0; t < terms.n; t++) {
                 double fv, fr, fs, ft = 0.0;
                 if (xc_id_is_mgga(terms.id[t])) {
-                    const D5 f = terms.id[t] == DQC_XC_MGGA_X_SCAN   ? f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2))
-                                 : terms.id[t] == DQC_XC_MGGA_X_TPSS ? f_mgga_x_tpss(var5(r, 0), var5(sig, 1), var5(tk, 2))
-                                                                     : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                    D5 f;
+                    if (terms.id[t] == DQC_XC_MGGA_C_TPSS) {  // closed shell: the general form at rho_u = rho_d, sigma_ss' = sigma / 4
+                        const D5 h = 0.5 * var5(r, 0), q = 0.25 * var5(sig, 1);
+                        D5 z = var5(sig, 1) / (8.0 * var5(r, 0) * var5(tk, 2));
+                        if (z.v > 1.0) z = c5(1.0);
+                        f = tpss_c_core(h, h, q, q, q, z);
+                    } else {
+                        f = terms.id[t] == DQC_XC_MGGA_X_SCAN   ? f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2))
+                            : terms.id[t] == DQC_XC_MGGA_X_TPSS ? f_mgga_x_tpss(var5(r, 0), var5(sig, 1), var5(tk, 2))
+                                                                : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                    }
                     fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
                 } else {
                     const Dual f = f_lda_gga<EXT>(terms.id[t], dr, ds);
@@ -601,6 +720,38 @@ extern "C" int dqc_xc_eval_mgga_pol(double *d_edens, double *d_vrho_u, double *d
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(xc_mgga_pol_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d, d_vgrad,
                        d_vtau, d_rho_u, d_rho_d, d_grho_u, d_grho_d, d_tau_u, d_tau_d, n, t);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_xc_eval_mgga_pol2(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
+                                     double *d_vtau, const double *d_rho_u, const double *d_rho_d, const double *d_grho_u,
+                                     const double *d_grho_d, const double *d_tau_u, const double *d_tau_d, int n, const int *ids,
+                                     const double *coefs, int nterm, void *stream) {
+    // dqc_xc_eval_mgga_pol with one gradient potential per spin: DQC_XC_MGGA_C_SCAN and DQC_XC_MGGA_C_TPSS (the latter depends on
+    // sigma_uu, sigma_ud, sigma_dd separately).  d_vtau is shared by the spins (both functionals see tau_u + tau_d only).
+    using namespace dqc;
+    if (nterm < 0 || nterm > 8) { set_error("dqc_xc_eval_mgga_pol2: at most 8 functional terms"); return DQC_EINVAL; }
+    if (!d_grho_u || !d_grho_d || !d_tau_u || !d_tau_d) { set_error("dqc_xc_eval_mgga_pol2: needs both density gradients and both tau"); return DQC_EINVAL; }
+    if ((d_vrho_u == nullptr) != (d_vrho_d == nullptr) || (d_vgrad_u == nullptr) != (d_vgrad_d == nullptr)) {
+        set_error("dqc_xc_eval_mgga_pol2: give both spin outputs or none");
+        return DQC_EINVAL;
+    }
+    XcTerms t;
+    t.n = nterm;
+    for (int i = 0; i < nterm; i++) {
+        t.id[i] = ids[i];
+        t.c[i] = coefs[i];
+        if (ids[i] != DQC_XC_MGGA_C_SCAN && ids[i] != DQC_XC_MGGA_C_TPSS) {
+            set_error("dqc_xc_eval_mgga_pol2: only meta-GGA correlation ids (DQC_XC_MGGA_C_SCAN, DQC_XC_MGGA_C_TPSS)");
+            return DQC_EINVAL;
+        }
+    }
+    if (n <= 0) return DQC_OK;
+    int blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(xc_mgga_pol2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d, d_vgrad_u,
+                       d_vgrad_d, d_vtau, d_rho_u, d_rho_d, d_grho_u, d_grho_d, d_tau_u, d_tau_d, n, t);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

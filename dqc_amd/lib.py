@@ -15,7 +15,7 @@ _lib = None
 
 XC_IDS = {"lda_x": 1, "lda_c_vwn": 7, "lda_c_pw": 12, "lda_c_pw_mod": 13, "gga_x_pbe": 101, "gga_x_pbe_r": 102, "gga_x_b88": 106,
           "gga_x_pbe_sol": 116, "gga_x_rpbe": 117, "gga_c_pbe": 130, "gga_c_lyp": 131, "gga_c_pbe_sol": 133,
-          "mgga_x_scan": 263, "mgga_c_scan": 267, "mgga_x_tpss": 202,
+          "mgga_x_scan": 263, "mgga_c_scan": 267, "mgga_x_tpss": 202, "mgga_c_tpss": 231,
           "lda_c_pz": 9, "gga_x_b86": 103, "gga_x_g96": 107, "gga_x_pw86": 108, "gga_x_pw91": 109, "gga_x_optx": 110, "gga_x_wc": 118,
           "gga_c_p86": 132}
 
@@ -103,6 +103,7 @@ def load():
     lib.dqc_xc_eval_pol.argtypes = [c_dp] * 9 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga_pol.argtypes = [c_dp] * 11 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_xc_eval_mgga_pol2.argtypes = [c_dp] * 12 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
@@ -356,6 +357,25 @@ def becke_weights(xyz, atom_off, pos, inv_rij, aij, cut):
                                         _ptr(inv_rij.contiguous()), _ptr(aij.contiguous()), natm, ngrid, float(cut), st_),
                "dqc_becke_weights")
     return w
+
+
+def xc_eval_mgga_pol2(terms, rho_u, rho_d, grho_u, grho_d, tau_u, tau_d, want_e=True, want_v=True):
+    """spin-polarised meta-GGA correlation terms with one gradient potential per spin (mgga_c_scan, mgga_c_tpss)
+    -> edens, (vrho_u, vrho_d), (vgrad_u, vgrad_d) (3, n) each, vtau shared"""
+    n = rho_u.shape[0]
+    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
+    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
+    e = torch.empty_like(rho_u) if want_e else None
+    vu = torch.empty_like(rho_u) if want_v else None
+    vd = torch.empty_like(rho_u) if want_v else None
+    gu = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if want_v else None
+    gd = torch.empty((3, n), dtype=torch.float64, device=rho_u.device) if want_v else None
+    vt = torch.empty_like(rho_u) if want_v else None
+    with _on(rho_u.device) as st_:
+        _check(load().dqc_xc_eval_mgga_pol2(_ptr(e), _ptr(vu), _ptr(vd), _ptr(gu), _ptr(gd), _ptr(vt), _ptr(rho_u), _ptr(rho_d),
+                                            _ptr(grho_u), _ptr(grho_d), _ptr(tau_u), _ptr(tau_d), n, ids, cfs, len(terms), st_),
+               "dqc_xc_eval_mgga_pol2")
+    return e, (vu, vd), (gu, gd), vt
 
 
 def purify_tc2(x_pad, tmp, nocc, iters, tol, state):

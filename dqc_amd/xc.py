@@ -12,7 +12,7 @@ from . import lib
 from .utils.datastruct import ValGrad, SpinParam
 
 _FAMILY = {"lda_x": 1, "lda_c_pw": 1, "lda_c_pw_mod": 1, "lda_c_vwn": 1, "gga_x_pbe": 2, "gga_c_pbe": 2, "gga_x_b88": 2, "gga_c_lyp": 2,
-           "gga_x_pbe_r": 2, "gga_x_pbe_sol": 2, "gga_x_rpbe": 2, "gga_c_pbe_sol": 2, "mgga_x_scan": 4, "mgga_c_scan": 4, "mgga_x_tpss": 4,
+           "gga_x_pbe_r": 2, "gga_x_pbe_sol": 2, "gga_x_rpbe": 2, "gga_c_pbe_sol": 2, "mgga_x_scan": 4, "mgga_c_scan": 4, "mgga_x_tpss": 4, "mgga_c_tpss": 4,
            # round 4: exchange GGAs given by an enhancement factor (one table entry each, csrc/xc_funcs.hpp), PZ81, P86
            "gga_x_pw91": 2, "gga_x_b86": 2, "gga_x_g96": 2, "gga_x_pw86": 2, "gga_x_optx": 2, "gga_x_wc": 2, "lda_c_pz": 1, "gga_c_p86": 2}
 
@@ -68,7 +68,7 @@ class LibXC(BaseXC):
         relation E_x[rho_u, rho_d] = 1/2 E_x[2 rho_u] + 1/2 E_x[2 rho_d], so mgga_x_* terms run through the unpolarised
         kernel on (2 rho_s, 2 grad rho_s, 2 tau_s); d e / d rho_s, d e / d grad rho_s, d e / d tau_s are then exactly the
         kernel's outputs at the scaled arguments.  mgga_c_* terms run through the polarised correlation kernel
-        (dqc_xc_eval_mgga_pol), LDA / GGA terms through the polarised LDA / GGA kernel.  Returns
+        (dqc_xc_eval_mgga_pol2), LDA / GGA terms through the polarised LDA / GGA kernel.  Returns
         (edens, [ValGrad_u, ValGrad_d])"""
         mx = [(c, n) for c, n in self.terms if n.startswith("mgga_x_")]
         mc = [(c, n) for c, n in self.terms if n.startswith("mgga_c_")]
@@ -87,15 +87,15 @@ class LibXC(BaseXC):
                                 kin=vt if vt is not None else z(d.value)) if want_v else None)
         if mc:  # correlation: the general polarised form (depends on rho_u, rho_d, |grad rho|^2, tau_u + tau_d)
             u, d = densinfo.u, densinfo.d
-            ec, (vu, vd), vgc, vtc = lib.xc_eval_mgga_pol(mc, u.value.contiguous(), d.value.contiguous(), u.grad.contiguous(),
-                                                          d.grad.contiguous(), u.kin.contiguous(), d.kin.contiguous(),
-                                                          want_e=want_e, want_v=want_v)
+            ec, (vu, vd), vgc, vtc = lib.xc_eval_mgga_pol2(mc, u.value.contiguous(), d.value.contiguous(), u.grad.contiguous(),
+                                                           d.grad.contiguous(), u.kin.contiguous(), d.kin.contiguous(),
+                                                           want_e=want_e, want_v=want_v)
             if want_e:
                 e = e + ec
-            if want_v:
-                for p_, v_ in zip(pots, (vu, vd)):
+            if want_v:  # (one gradient potential per spin: TPSS correlation sees sigma_uu, sigma_ud, sigma_dd separately)
+                for p_, v_, g_ in zip(pots, (vu, vd), vgc):
                     p_.value = p_.value + v_
-                    p_.grad = p_.grad + vgc
+                    p_.grad = p_.grad + g_
                     p_.kin = p_.kin + vtc
         if rest:
             gga = max(_FAMILY[n] for _, n in rest) == 2

@@ -136,6 +136,7 @@ int dqc_grid_density(double *d_rho, double *d_grho, const double *d_ao, int ncom
 #define DQC_XC_GGA_C_P86 132     /* Perdew 86 on PZ81 */
 #define DQC_XC_GGA_C_PBE_SOL 133 /* PBEsol correlation: beta = 0.046 */
 #define DQC_XC_MGGA_X_TPSS 202
+#define DQC_XC_MGGA_C_TPSS 231
 #define DQC_XC_MGGA_X_SCAN 263
 #define DQC_XC_MGGA_C_SCAN 267
 int dqc_xc_eval(double *d_edens, double *d_vrho, double *d_vgrad, const double *d_rho,
@@ -158,7 +159,7 @@ int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, double 
 
 /* meta-GGA variant (CalcMGGALibXCUnpol, dqc/xc/libxc_wrapper.py; inputs rho, grad rho, tau -- the supported
  * functionals do not depend on the laplacian, so vlapl = 0): adds d_vtau (n).  Terms may mix LDA/GGA ids with
- * DQC_XC_MGGA_X_SCAN, DQC_XC_MGGA_X_TPSS and DQC_XC_MGGA_C_SCAN. */
+ * DQC_XC_MGGA_X_SCAN, DQC_XC_MGGA_X_TPSS, DQC_XC_MGGA_C_SCAN and DQC_XC_MGGA_C_TPSS. */
 int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad, double *d_vtau, const double *d_rho,
                      const double *d_grho, const double *d_tau, int n, const int *ids, const double *coefs,
                      int nterm, void *stream);
@@ -171,6 +172,14 @@ int dqc_xc_eval_mgga_pol(double *d_edens, double *d_vrho_u, double *d_vrho_d, do
                          const double *d_rho_u, const double *d_rho_d, const double *d_grho_u, const double *d_grho_d,
                          const double *d_tau_u, const double *d_tau_d, int n, const int *ids, const double *coefs, int nterm,
                          void *stream);
+
+/* the same with ONE GRADIENT POTENTIAL PER SPIN: DQC_XC_MGGA_C_SCAN and DQC_XC_MGGA_C_TPSS (TPSS correlation depends on
+ * sigma_uu, sigma_ud, sigma_dd separately: v_grad,u = 2 v_uu grad n_u + v_ud grad n_d, dqc/xc/libxc.py:205-215); d_vgrad_u,
+ * d_vgrad_d (3, n) each, d_vtau (n) shared. */
+int dqc_xc_eval_mgga_pol2(double *d_edens, double *d_vrho_u, double *d_vrho_d, double *d_vgrad_u, double *d_vgrad_d,
+                          double *d_vtau, const double *d_rho_u, const double *d_rho_d, const double *d_grho_u,
+                          const double *d_grho_d, const double *d_tau_u, const double *d_tau_d, int n, const int *ids,
+                          const double *coefs, int nterm, void *stream);
 
 /* ---- density-fitting integrals  (DFMol.build, dqc/df/dfmol.py:24-58) --------------------------
  * intor.coul2c(auxbw) = int2c2e_sph and intor.coul3c(basisw, basisw, auxbw) = int3c2e_sph

@@ -561,7 +561,84 @@ def mgga_x_tpss(rho, sigma, tau):
     return zz(en.v), zz(en.d[0]), zz(en.d[1]), zz(en.d[2])
 
 
-_FUNCS_MGGA = {"mgga_x_scan": mgga_x_scan, "mgga_c_scan": mgga_c_scan, "mgga_x_tpss": mgga_x_tpss}
+# =====================================================================================================
+# TPSS correlation (mgga_c_tpss, libxc id 231): the same letter, eqs. (11)-(14):
+#   eps_revPKZB = eps_PBE(n_u, n_d, grad n_u, grad n_d) [1 + C(zeta, xi) z^2] - [1 + C(zeta, xi)] z^2 sum_s (n_s / n) epst_s,   z = tau_W / tau
+#   epst_s = max[eps_PBE(n_s, 0, grad n_s, 0), eps_PBE(n_u, n_d, ...)],      eps_TPSS = eps_revPKZB [1 + d eps_revPKZB z^3],  d = 2.8
+#   C(zeta, xi) = C(zeta, 0) / {1 + xi^2 [(1 + zeta)^(-4/3) + (1 - zeta)^(-4/3)] / 2}^4,  C(zeta, 0) = 0.53 + 0.87 z^2 + 0.50 z^4 + 2.26 z^6,
+#   xi = |grad zeta| / (2 (3 pi^2 n)^(1/3)),   grad zeta = [(1 - zeta) grad n_u - (1 + zeta) grad n_d] / n
+# Unlike SCAN it depends on sigma_uu, sigma_ud, sigma_dd separately (through |grad zeta| and the one-spin PBE terms): six variables.
+# PBE = this file's gga_c_pbe (modified-PW92 LSDA part, as in libxc).  The reference holds no formula or literal: PARITY against
+# libxc UNPINNED; pinned by the constraints the construction states -- no correlation for any one-electron density (zeta = 1, z = 1),
+# = PBE correlation where z = 0, the uniform-gas limit -- and finite differences (tests/test_oracle_cpu.py).
+# =====================================================================================================
+def _pbe_c_eps(rho, zeta, sig, ferro=False):
+    """PBE correlation energy per particle as a Dual; ferro: the fully polarised limit zeta = 1 in closed form (phi = 2^(-1/3),
+    LSDA = PW92's ferromagnetic fit) -- (1 - zeta)^(2/3) is not differentiable there"""
+    g_, b_ = _PBE_GAMMA, _PBE_BETA
+    if ferro:
+        a, p = _PW_A_MOD3[1], _PW_POL
+        rs = ((3.0 / (4.0 * np.pi)) / rho).pow(1.0 / 3)
+        sq = rs.sqrt()
+        q1 = 2.0 * a * (p["beta1"][1] * sq + p["beta2"][1] * rs + p["beta3"][1] * (rs * sq) + p["beta4"][1] * (rs * rs))
+        eps = (-2.0 * a) * (1.0 + p["alpha1"][1] * rs) * (1.0 / q1).log1p()
+        phi2, phi3 = 2.0 ** (-2.0 / 3), 0.5
+    else:
+        eps = _pw92_pol_eps(rho, zeta, _PW_A_MOD3)
+        phi = 0.5 * ((1.0 + zeta).pow(2.0 / 3) + (1.0 - zeta).pow(2.0 / 3))
+        phi2, phi3 = phi * phi, phi * phi * phi
+    kf = ((3.0 * np.pi ** 2) * rho).pow(1.0 / 3)
+    t2 = sig / (4.0 * phi2 * ((4.0 / np.pi) * kf) * rho * rho)
+    Ac = (b_ / g_) / (-(eps / (g_ * phi3))).expm1()
+    At2 = Ac * t2
+    X = (b_ / g_) * t2 * (1.0 + At2) / (1.0 + At2 + At2 * At2)
+    return eps + g_ * phi3 * X.log1p()
+
+
+def _dmax(a, b):
+    pick = a.v >= b.v
+    return Dual(np.where(pick, a.v, b.v), [np.where(pick, x, y) for x, y in zip(a.d, b.d)])
+
+
+def mgga_c_tpss_pol(ru, rd, suu, sud, sdd, tau):
+    """-> e (= n eps_c), (d/drho_u, d/drho_d), (d/dsigma_uu, d/dsigma_ud, d/dsigma_dd), d/dtau_total"""
+    mask, ru_, rd_ = _masked(ru, rd)
+    fl = lambda a, lo: np.where(mask, np.maximum(np.asarray(a, float), lo), 1.0)  # noqa: E731
+    suu_, sdd_, ta_ = fl(suu, 1e-40), fl(sdd, 1e-40), fl(tau, 1e-20)
+    sud_ = np.where(mask, np.asarray(sud, float), 1.0)
+    u, d, guu, gud, gdd, ta = (Dual.var(x, i, 6) for i, x in enumerate((ru_, rd_, suu_, sud_, sdd_, ta_)))
+    rho, zeta = _safe_zeta(u, d)
+    sig = guu + 2.0 * gud + gdd
+    sig.v = np.maximum(sig.v, 1e-40)
+    eps = _pbe_c_eps(rho, zeta, sig)
+    et_u = _dmax(_pbe_c_eps(u, None, guu, ferro=True), eps)
+    et_d = _dmax(_pbe_c_eps(d, None, gdd, ferro=True), eps)
+    z2_ = zeta * zeta
+    c0 = 0.53 + 0.87 * z2_ + 0.50 * z2_ * z2_ + 2.26 * z2_ * z2_ * z2_
+    omz, opz = 1.0 - zeta, 1.0 + zeta
+    gz2 = (omz * omz * guu - 2.0 * omz * opz * gud + opz * opz * gdd) / (rho * rho)
+    xi2 = gz2 / (4.0 * ((3.0 * np.pi ** 2) * rho).pow(2.0 / 3))
+    cd = 1.0 + 0.5 * xi2 * (opz.pow(-4.0 / 3) + omz.pow(-4.0 / 3))
+    cd2 = cd * cd
+    C = c0 / (cd2 * cd2)
+    z = sig / (8.0 * rho * ta)
+    over = z.v > 1.0
+    z = Dual(np.where(over, 1.0, z.v), [np.where(over, 0.0, a) for a in z.d])
+    zz = z * z
+    erev = eps * (1.0 + C * zz) - (1.0 + C) * zz * (u * et_u + d * et_d) / rho
+    e = rho * erev * (1.0 + 2.8 * erev * zz * z)
+    w = lambda a: np.where(mask, a, 0.0)  # noqa: E731
+    return w(e.v), (w(e.d[0]), w(e.d[1])), (w(e.d[2]), w(e.d[3]), w(e.d[4])), w(e.d[5])
+
+
+def mgga_c_tpss(rho, sigma, tau):
+    """unpolarised: E[rho/2, rho/2; sigma/4 each]; -> e, vrho, vsigma, vtau"""
+    rho, sigma = np.asarray(rho, float), np.asarray(sigma, float)
+    e, (vu, vd), (a, b, c), vt = mgga_c_tpss_pol(0.5 * rho, 0.5 * rho, 0.25 * sigma, 0.25 * sigma, 0.25 * sigma, tau)
+    return e, 0.5 * (vu + vd), 0.25 * (a + b + c), vt
+
+
+_FUNCS_MGGA = {"mgga_x_scan": mgga_x_scan, "mgga_c_scan": mgga_c_scan, "mgga_x_tpss": mgga_x_tpss, "mgga_c_tpss": mgga_c_tpss}
 
 
 class XCM(XC):

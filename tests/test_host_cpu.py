@@ -164,7 +164,8 @@ def test_xc_parser():
     assert dqc_amd.get_xc("mgga_x_scan + gga_c_pbe").family == 4
     assert dqc_amd.get_xc("mgga_x_scan + mgga_c_scan").family == 4
     with pytest.raises(ValueError):
-        dqc_amd.get_xc("mgga_c_tpss")  # not in the kernel set: loud, no fallback
+        dqc_amd.get_xc("mgga_c_revtpss")  # not in the kernel set: loud, no fallback
+    assert dqc_amd.get_xc("mgga_x_tpss + mgga_c_tpss").family == 4
     assert dqc_amd.get_xc(None).terms == []
 
 

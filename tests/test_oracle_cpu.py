@@ -461,6 +461,48 @@ def test_tpss_exchange_published_pins_and_derivatives():
     assert np.allclose((f(rho, sig, tau + h) - f(rho, sig, tau - h)) / (2 * h), vt, rtol=1e-6, atol=1e-8)
 
 
+def test_tpss_correlation_constraints_and_derivatives():
+    """mgga_c_tpss (six variables: rho_u, rho_d, sigma_uu, sigma_ud, sigma_dd, tau; no formula or literal in the reference) by what its
+    construction states (PRL 91, 146401): no correlation energy for ANY one-electron density (fully polarised, tau = tau_W); PBE
+    correlation where z = tau_W / tau -> 0; the uniform-gas limit; spin symmetry; closed shell = polarised form at rho_u = rho_d;
+    finite differences of all six derivatives"""
+    rng = np.random.default_rng(11)
+    n = 60
+    r = np.exp(rng.uniform(-3, 1, n))
+    g = r ** (4 / 3) * rng.uniform(0.1, 3, n)
+    zero = np.zeros(n)
+    e1 = oxc.mgga_c_tpss_pol(r, zero, g * g, zero, zero, g * g / (8 * r) * (1 + 1e-12))[0]
+    assert np.abs(e1 / r).max() < 1e-9
+    big = np.full(n, 1e14)
+    assert np.allclose(oxc.mgga_c_tpss(r, g * g, big)[0], oxc.gga_c_pbe(r, g * g)[0], rtol=1e-12)
+    tu = 0.3 * (3 * np.pi ** 2 * r) ** (2 / 3) * r
+    assert np.allclose(oxc.mgga_c_tpss(r, zero, tu)[0], oxc.lda_c_pw(r, None, a=oxc._PW_A_MOD3[0])[0], rtol=1e-13)
+    ru, rd = rng.uniform(0.05, 1.2, n), rng.uniform(0.05, 1.2, n)
+    gu, gd = rng.standard_normal((3, n)) * ru, rng.standard_normal((3, n)) * rd
+    a, b, c = (gu * gu).sum(0), (gu * gd).sum(0), (gd * gd).sum(0)
+    gt = gu + gd
+    tw = (gt * gt).sum(0) / (8 * (ru + rd))
+    tau = tw + rng.uniform(0.05, 2.0, n) * 0.3 * (3 * np.pi ** 2 * (ru + rd)) ** (2 / 3) * (ru + rd)
+    assert np.allclose(oxc.mgga_c_tpss_pol(ru, rd, a, b, c, big)[0], oxc.gga_c_pbe_pol(ru, rd, a, b, c)[0], rtol=1e-12)
+    e, (vu, vd), (va, vb, vc), vt = oxc.mgga_c_tpss_pol(ru, rd, a, b, c, tau)
+    e2, (vd2, vu2), (vc2, vb2, va2), vt2 = oxc.mgga_c_tpss_pol(rd, ru, c, b, a, tau)
+    assert np.allclose(e, e2, rtol=1e-13) and np.allclose(vu, vu2, rtol=1e-10) and np.allclose(va, va2, rtol=1e-9, atol=1e-14)
+    f = lambda *x: oxc.mgga_c_tpss_pol(*x)[0]  # noqa: E731
+    x0 = [ru, rd, a, b, c, tau]
+    for k, (ana, h) in enumerate(zip((vu, vd, va, vb, vc, vt), (1e-6, 1e-6, 1e-6, 1e-6, 1e-6, 1e-6))):
+        xp, xm = list(x0), list(x0)
+        xp[k] = x0[k] + h
+        xm[k] = x0[k] - h
+        assert np.allclose((f(*xp) - f(*xm)) / (2 * h), ana, rtol=2e-5, atol=2e-8), k
+    rho = ru + rd
+    sg = (gt * gt).sum(0)
+    eu, vr, vs, vtt = oxc.mgga_c_tpss(rho, sg, tau)
+    ep, (pu, pd), (pa, pb, pc), pt = oxc.mgga_c_tpss_pol(rho / 2, rho / 2, sg / 4, sg / 4, sg / 4, tau)
+    assert np.allclose(eu, ep, rtol=1e-14) and np.allclose(vr, pu, rtol=1e-10) and np.allclose(vtt, pt, rtol=1e-12)
+    fu = lambda *x: oxc.mgga_c_tpss(*x)[0]  # noqa: E731
+    assert np.allclose((fu(rho, sg + 1e-6, tau) - fu(rho, sg - 1e-6, tau)) / 2e-6, vs, rtol=2e-5, atol=2e-8)
+
+
 def test_rks_scan_reference_literals():
     """dqc/test/test_ks.py:58-63, 89-111: RKS mgga_x_scan / 6-311++G** / grid 4, atol 1.3e-3 (H2 is xfail there)"""
     for sym, d, ref in [("Li", 5.0, -14.8687500), ("N", 2.0, -109.055074), ("C O", 2.0, -112.836255)]:
