@@ -689,6 +689,8 @@ def _entry_rooflines(tr_ms, nbuild, shape):
     def model(name):
         if name == "dqc_grid_density_lr":                 # two chained rank-r GEMMs, four AO components read
             return 8.0 * 4 * G * n, 4.0 * G * n * r + 2.0 * 4 * G * n
+        if name == "dqc_grid_density_lr_tau":             # four rank-r GEMMs, four AO components read once
+            return 8.0 * 4 * G * n, 8.0 * G * n * r
         if name == "dqc_grid_density_lr[value only]":     # phase 1 only, one component
             return 8.0 * G * n, 2.0 * G * n * r
         if name == "dqc_grid_density":
@@ -701,6 +703,8 @@ def _entry_rooflines(tr_ms, nbuild, shape):
             return 8.0 * 4 * G * n, 2.0 * G * n * n + 4.0 * 4 * G * n
         if name in ("dqc_grid_vxc[no gradient term]", "dqc_grid_vxc_pair"):  # one operand: symmetric, the upper triangle only
             return 8.0 * G * n, 1.0 * G * n * n
+        if name == "dqc_grid_vxc_pair[three gradient components]":  # the tau term: one symmetric update over 3 G stacked rows
+            return 8.0 * 3 * G * n, 3.0 * G * n * n
         if name.startswith("dqc_xc_eval"):
             return 8.0 * G * 9, 0.0
         if name in ("dqc_jk_from_tiles", "dqc_jk_from_tiles_part", "dqc_jk_from_tiles_multi"):
@@ -727,7 +731,7 @@ def f_row_legs(dev, K=10):
     """SURVEY.md 8 'next' rows on the clock, ONE C5 molecule each, steady-state Fock builds dm2scp(ao_orb2dm(C))
     timed with HIP events + a lib.call_trace pass for the per-entry rooflines:
        uks_pbe   unrestricted KS, two-spin grid pass (hcgto.py:260-269 polarised branch, hf.py:93-103)
-       scan      meta-GGA: tau from the factor kernel, the three tau Vxc terms through the one-operand pair form (hcgto.py:420-438, 473-489)
+       scan      meta-GGA: rho, grad rho and tau from one factor-form pass, the tau Vxc term as one one-operand update over the stacked gradient components (hcgto.py:420-438, 473-489)
        df_lda    the reference's own 20-atom benchmark call (dqc/test/benchmark.py:40-42): Mol(...).densityfit() + lda_x+lda_c_pw,
                  with the energy error of the generated auxiliary set against exact J
        anonymous_dm  the same PBE build from a density matrix without a known orbital factor (dense density kernel, hcgto.py:407-418)
@@ -785,7 +789,7 @@ def f_row_legs(dev, K=10):
         qc = dqc_amd.KS(dqc_amd.Mol(geo, basis="cc-pvdz", grid="sg3", device=dev), xc="mgga_x_scan+mgga_c_scan")
         ms, rows, shape = steady(qc, False)
         out["scan"] = {"fock_build_ms": ms, "fock_builds_per_s": 1e3 / ms, "entries": rows, "shape": shape,
-                       "what": "C5 molecule 0, RKS SCAN (meta-GGA): density + tau from the factor, Vxc + three tau terms"}
+                       "what": "C5 molecule 0, RKS SCAN (meta-GGA): density + gradient + tau from the factor in one pass, Vxc + the tau term"}
         del qc
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")

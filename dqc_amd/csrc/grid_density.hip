@@ -612,6 +612,156 @@ static int launch_density_lr_n(int nct, dim3 grid, hipStream_t st, double *rho, 
     return DQC_EINVAL;
 }
 
+// ---------------------------------------------------------------------------------------------
+// meta-GGA densities from the orbital factor in ONE pass (round 4): psi = Phi L and d_d psi = (d_d Phi) L for the three gradient
+// components -- four phase-1 GEMMs of density_lr_kernel, no phase 2 and no row-dot epilogue --
+//     rho = sum_r psi_r^2,   grad_d rho = 2 sum_r psi_r d_d psi_r,   tau = 1/2 sum_d sum_r (d_d psi_r)^2        (hcgto.py:398-438)
+// The AO components are read once, as GEMM operands staged through LDS (coalesced, two chunks of prefetch), instead of once by
+// density_lr_kernel (value: GEMM operand; gradients: latency-bound row dots) plus once more by three value-only passes for tau.
+// Two components per sweep over K (LDS: 2 x 2 A chunks + 2 L chunks = 49 KB per block), psi kept in registers for the second sweep.
+// ---------------------------------------------------------------------------------------------
+template <int NRT>
+__global__ __launch_bounds__(256, 2) void density_lr_tau_kernel(double *__restrict__ rho, double *__restrict__ grho, double *__restrict__ tau,
+                                                                const double *__restrict__ ao, int ngrid, int ld,
+                                                                const double *__restrict__ orb, int lda) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int RP = LrGeom<NRT>::RP, RPS = LrGeom<NRT>::RPS;
+    constexpr int A_SZ = DEN_BM * DEN_SA, B_SZ = DEN_KC * RPS;
+    constexpr int NL2 = (DEN_KC * RP / 2 + DEN_NT - 1) / DEN_NT;
+    static_assert(NL2 <= 4, "L chunk wider than 4 double2 per thread");
+    double *sA = lds, *sB = lds + 4 * A_SZ;  // sA: [buffer][component of the pair][A_SZ]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int g0 = blockIdx.x * DEN_BM;
+    const size_t cs = (size_t)ngrid * lda;
+    const double *aoblk = ao + (size_t)g0 * lda;
+    const int rmax = ngrid - 1 - g0;
+    const int arow = tid >> 2, aseg = (tid & 3) * 4;
+    const int aoff = min(arow, rmax) * lda + aseg;
+    const int nk = ld / DEN_KC;
+    const int lo0 = min((tid + 0 * DEN_NT) * 2, DEN_KC * RP - 2), lo1 = min((tid + 1 * DEN_NT) * 2, DEN_KC * RP - 2);
+    const int lo2 = min((tid + 2 * DEN_NT) * 2, DEN_KC * RP - 2), lo3 = min((tid + 3 * DEN_NT) * 2, DEN_KC * RP - 2);
+
+    v4d psi[NRT];
+    double rs = 0.0, ts = 0.0, gs[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int pair = 0; pair < 2; pair++) {
+        const double *blk0 = aoblk + (size_t)(2 * pair) * cs, *blk1 = blk0 + cs;
+        v4d a0[NRT], a1[NRT];
+#pragma unroll
+        for (int ct = 0; ct < NRT; ct++) a0[ct] = a1[ct] = v4d{0, 0, 0, 0};
+        double2 x0a, x0b, y0a, y0b, x1a, x1b, y1a, y1b, pl0a, pl0b, pl0c, pl0d, pl1a, pl1b, pl1c, pl1d;
+        pl0a = pl0b = pl0c = pl0d = pl1a = pl1b = pl1c = pl1d = make_double2(0.0, 0.0);
+#define DQC_LT_PREFETCH(KC, S)                                                                            \
+    {                                                                                                     \
+        const int kq = min((KC), nk - 1); /* past-the-end chunks re-read the last one, never staged */     \
+        const double *s0_ = blk0 + kq * DEN_KC + aoff, *s1_ = blk1 + kq * DEN_KC + aoff;                  \
+        x##S##a = *reinterpret_cast<const double2 *>(s0_);                                                \
+        x##S##b = *reinterpret_cast<const double2 *>(s0_ + 2);                                            \
+        y##S##a = *reinterpret_cast<const double2 *>(s1_);                                                \
+        y##S##b = *reinterpret_cast<const double2 *>(s1_ + 2);                                            \
+        const double *l_ = orb + (size_t)kq * DEN_KC * RP;                                                \
+        pl##S##a = *reinterpret_cast<const double2 *>(l_ + lo0);                                          \
+        if (NL2 > 1) pl##S##b = *reinterpret_cast<const double2 *>(l_ + lo1);                             \
+        if (NL2 > 2) pl##S##c = *reinterpret_cast<const double2 *>(l_ + lo2);                             \
+        if (NL2 > 3) pl##S##d = *reinterpret_cast<const double2 *>(l_ + lo3);                             \
+    }
+#define DQC_LT_PUT(I, V)                                                                                  \
+    {                                                                                                     \
+        const int e_ = (tid + (I) * DEN_NT) * 2;                                                          \
+        const int row_ = e_ / RP, col_ = e_ - row_ * RP;                                                  \
+        if (row_ < DEN_KC) *reinterpret_cast<double2 *>(sB + buf_ * B_SZ + row_ * RPS + col_) = V;        \
+    }
+#define DQC_LT_STAGE(KC, S)                                                                               \
+    if ((KC) < nk) {                                                                                      \
+        const int buf_ = (KC) & 1;                                                                        \
+        double *a_ = sA + buf_ * 2 * A_SZ + arow * DEN_SA + aseg;                                         \
+        *reinterpret_cast<double2 *>(a_) = x##S##a;                                                       \
+        *reinterpret_cast<double2 *>(a_ + 2) = x##S##b;                                                   \
+        *reinterpret_cast<double2 *>(a_ + A_SZ) = y##S##a;                                                \
+        *reinterpret_cast<double2 *>(a_ + A_SZ + 2) = y##S##b;                                            \
+        DQC_LT_PUT(0, pl##S##a)                                                                           \
+        if (NL2 > 1) DQC_LT_PUT(1, pl##S##b)                                                              \
+        if (NL2 > 2) DQC_LT_PUT(2, pl##S##c)                                                              \
+        if (NL2 > 3) DQC_LT_PUT(3, pl##S##d)                                                              \
+    }
+#define DQC_LT_MFMAS(KC)                                                                                  \
+    {                                                                                                     \
+        const int buf_ = (KC) & 1;                                                                        \
+        const double *b_ = sA + buf_ * 2 * A_SZ + (wave * 16 + lr) * DEN_SA + lk; /* Phi_c[pt][ao] (B operand) */ \
+        const double *l_ = sB + buf_ * B_SZ + lk * RPS + lr;                      /* L[ao][r]      (A operand) */ \
+        _Pragma("unroll") for (int kk = 0; kk < DEN_KC / 4; kk++) {                                       \
+            const double bv0 = b_[kk * 4], bv1 = b_[A_SZ + kk * 4];                                       \
+            _Pragma("unroll") for (int ct = 0; ct < NRT; ct++) {                                          \
+                const double lv = l_[kk * 4 * RPS + ct * 16];                                             \
+                a0[ct] = mfma_f64(lv, bv0, a0[ct]);                                                       \
+                a1[ct] = mfma_f64(lv, bv1, a1[ct]);                                                       \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+        __syncthreads();  // (the previous sweep's last chunk fully consumed)
+        DQC_LT_PREFETCH(0, 0)
+        DQC_LT_PREFETCH(1, 1)
+        DQC_LT_STAGE(0, 0)
+        __syncthreads();
+        int kc = 0;
+        for (; kc + 1 < nk; kc += 2) {
+            DQC_LT_PREFETCH(kc + 2, 0)
+            DQC_LT_MFMAS(kc)
+            DQC_LT_STAGE(kc + 1, 1)
+            __syncthreads();
+            DQC_LT_PREFETCH(kc + 3, 1)
+            DQC_LT_MFMAS(kc + 1)
+            DQC_LT_STAGE(kc + 2, 0)
+            __syncthreads();
+        }
+        if (kc < nk) {
+            DQC_LT_MFMAS(kc)
+            __syncthreads();
+        }
+#undef DQC_LT_PREFETCH
+#undef DQC_LT_STAGE
+#undef DQC_LT_PUT
+#undef DQC_LT_MFMAS
+        // lane (lr = point, lk) holds r = 16 ct + 4 q + lk of both components
+        if (pair == 0) {  // a0 = psi, a1 = d_x psi
+#pragma unroll
+            for (int ct = 0; ct < NRT; ct++) {
+                psi[ct] = a0[ct];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    rs += a0[ct][q] * a0[ct][q];
+                    gs[0] += a0[ct][q] * a1[ct][q];
+                    ts += a1[ct][q] * a1[ct][q];
+                }
+            }
+        } else {  // a0 = d_y psi, a1 = d_z psi
+#pragma unroll
+            for (int ct = 0; ct < NRT; ct++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    gs[1] += psi[ct][q] * a0[ct][q];
+                    gs[2] += psi[ct][q] * a1[ct][q];
+                    ts += a0[ct][q] * a0[ct][q] + a1[ct][q] * a1[ct][q];
+                }
+        }
+    }
+    double out[5] = {rs, 2.0 * gs[0], 2.0 * gs[1], 2.0 * gs[2], 0.5 * ts};
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        out[q] += __shfl_xor(out[q], 16);
+        out[q] += __shfl_xor(out[q], 32);
+    }
+    const int row = g0 + wave * 16 + lr;
+    if (lk == 0 && row < ngrid) {
+        rho[row] = out[0];
+        grho[row] = out[1];
+        grho[(size_t)ngrid + row] = out[2];
+        grho[2 * (size_t)ngrid + row] = out[3];
+        tau[row] = out[4];
+    }
+}
+
 template <bool GGA>
 static int launch_density_lr(int nrt, int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
                              int ngrid, int ld, const double *orb, const double *orbt, int ntile, int lda) {
@@ -693,6 +843,37 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
     int rc = launch_density<false>(nct, grid, st, d_out, nullptr, d_ao_a, ngrid, ld, d_dm, ntile, d_ao_b, lda);
     if (rc) return rc;
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+int dqc_grid_density_lr_tau(double *d_rho, double *d_grho, double *d_tau, const double *d_ao, int ncomp, int ngrid, int nao,
+                            const double *d_orb, int norb_pad, void *stream) {
+    // rho (ngrid), grad rho (3, ngrid) and tau = 1/2 sum |grad psi|^2 (ngrid) of D = L L^T from ONE pass over the four AO components
+    // (density_lr_tau_kernel); d_orb: the padded factor as for dqc_grid_density_lr, norb_pad <= 96.  Enqueues only.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ngrid <= 0) return DQC_OK;
+    if (ncomp < 4 || !d_grho || !d_tau) { set_error("dqc_grid_density_lr_tau: needs the four AO components and all three outputs"); return DQC_EINVAL; }
+    if (norb_pad <= 0 || dqc_padded_norb(norb_pad) != norb_pad) {
+        set_error("dqc_grid_density_lr_tau: norb_pad must be a value returned by dqc_padded_norb");
+        return DQC_EINVAL;
+    }
+    const int ld = dqc_padded_nao(nao), lda = dqc_ao_stride(nao);
+    dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
+#define DQC_LT_CASE(N)                                                                                                         \
+    case N: {                                                                                                                  \
+        constexpr size_t bytes = sizeof(double) * (4 * DEN_BM * DEN_SA + 2 * DEN_KC * LrGeom<N>::RPS);                         \
+        (void)hipFuncSetAttribute((const void *)density_lr_tau_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); \
+        hipLaunchKernelGGL((density_lr_tau_kernel<N>), grid, dim3(DEN_NT), bytes, st, d_rho, d_grho, d_tau, d_ao, ngrid, ld, d_orb, lda); \
+    } break;
+    switch (norb_pad / 16) {
+        DQC_LT_CASE(1) DQC_LT_CASE(2) DQC_LT_CASE(3) DQC_LT_CASE(4) DQC_LT_CASE(6)
+    default:  // (128 orbitals: three accumulator sets of 8 tiles spill -- the caller takes the separate passes)
+        set_error("dqc_grid_density_lr_tau: factors wider than 96 columns are not supported");
+        return DQC_EINVAL;
+    }
+#undef DQC_LT_CASE
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -665,6 +665,13 @@ class HamiltonMI355(_Base):
         # as in the reference, from the factor too (cross term by the polarisation identity, see below)
         use_factor = fac is not None and (self.xcfamily != 4 or self.is_lapl_ao_set)
         self.grid_path_counts["factor" if use_factor else "dense"] += 1
+        if use_factor and self.xcfamily == 4 and isinstance(self.xc, LibXC) and all(f[0].shape[1] <= 96 for f in fac):
+            # meta-GGA functional of the kernel set (no laplacian): rho, grad rho and tau from ONE pass over the AO components
+            rho, grho, kin = lib.grid_density_lr_tau(self._ao, self._nao_ao, fac[0])
+            for f in fac[1:]:
+                r2, g2, k2 = lib.grid_density_lr_tau(self._ao, self._nao_ao, f)
+                rho, grho, kin = rho + r2, grho + g2, kin + k2
+            return ValGrad(value=rho, grad=grho, lapl=None, kin=kin)
         if use_factor:
             # D = L L^T known: two chained rank-n_occ GEMMs instead of Phi . D
             rho, grho = lib.grid_density_lr(self._ao, self._nao_ao, fac[0], gga)
@@ -714,8 +721,10 @@ class HamiltonMI355(_Base):
             if lapl is not None:
                 vm = vm + lib.grid_vxc_pair(self._ao[0], self._ao[4], self._nao_ao, self.dvolume, (2.0 * lapl).contiguous())
             lk = ((2.0 * lapl if lapl is not None else 0.0) + 0.5 * kin).contiguous()
-            for d in (1, 2, 3):
-                vm = vm + lib.grid_vxc_pair(self._ao[d], self._ao[d], self._nao_ao, self.dvolume, lk)
+            # sum_d (d_d Phi)^T diag(w lk) (d_d Phi) = G^T diag(w lk, w lk, w lk) G with G the three gradient arrays stacked along the
+            # point axis (they are consecutive in memory): ONE symmetric rank update over 3 ngrid rows instead of three launches
+            g3 = self._ao[1:4].reshape(-1, self._ao.shape[-1])
+            vm = vm + lib.grid_vxc_pair(g3, g3, self._nao_ao, self.dvolume.repeat(3), lk.repeat(3), what="dqc_grid_vxc_pair[three gradient components]")
         return self._allsum(vm)
 
     def get_elrep_plus_vxc(self, dm):

@@ -107,6 +107,7 @@ def load():
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
+    lib.dqc_grid_density_lr_tau.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_int, c_vp]
     lib.dqc_grid_density_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_grid_vxc_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_vp]
     lib.dqc_grid_vxc.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, c_vp]
@@ -675,6 +676,19 @@ def grid_density_lr(ao, nao, factor, gga):
     return rho, grho
 
 
+def grid_density_lr_tau(ao, nao, factor):
+    """rho, grad rho (3, ngrid), tau of D = L L^T from ONE pass over the four AO components (factor width <= 96 columns)"""
+    orb = factor[0]
+    ngrid = ao.shape[-2]
+    rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
+    grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device)
+    tau = torch.empty(ngrid, dtype=torch.float64, device=ao.device)
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_density_lr_tau(_ptr(rho), _ptr(grho), _ptr(tau), _ptr(ao), ao.shape[0], ngrid, nao, _ptr(orb),
+                                              orb.shape[1], st_), "dqc_grid_density_lr_tau")
+    return rho, grho, tau
+
+
 def xc_eval(terms, rho, grho, want_e=True, want_v=True):
     """terms: list of (coef, name).  -> edens, vrho, vgrad(3,n) (None where not requested/applicable)"""
     n = rho.shape[0]
@@ -762,13 +776,12 @@ def grid_density_pair(ao_a, ao_b, nao, dm_pad):
     return out
 
 
-def grid_vxc_pair(ao_a, ao_b, nao, w, v):
-    """sym( sum_g w_g v_g a_ga b_gb ) -> (ld, ld)"""
+def grid_vxc_pair(ao_a, ao_b, nao, w, v, what="dqc_grid_vxc_pair"):
+    """sym( sum_g w_g v_g a_ga b_gb ) -> (ld, ld)   (`what`: the name this call is listed under by call_trace)"""
     ngrid, ld = ao_a.shape[0], padded_nao(nao)
     vm = torch.empty((ld, ld), dtype=torch.float64, device=ao_a.device)
     with _on(ao_a.device) as st_:
-        _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), st_),
-               "dqc_grid_vxc_pair")
+        _check(load().dqc_grid_vxc_pair(_ptr(vm), _ptr(ao_a), _ptr(ao_b), ngrid, nao, _ptr(w), _ptr(v), st_), what)
     return vm
 
 

@@ -288,6 +288,12 @@ int dqc_padded_norb(int norb);
 int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
                         const double *d_orb, const double *d_orbt, int norb_pad, void *stream);
 
+/* meta-GGA densities of D = L L^T from ONE pass over the four AO components: rho, grad rho (3, ngrid) and
+ * tau = 1/2 sum_d sum_r (d_d Phi . L)_r^2 (hcgto.py:398-438 with D in factor form) -- four rank-r GEMMs, no row-dot epilogue;
+ * replaces dqc_grid_density_lr + three value-only passes over the gradient components.  norb_pad <= 96. */
+int dqc_grid_density_lr_tau(double *d_rho, double *d_grho, double *d_tau, const double *d_ao, int ncomp, int ngrid, int nao,
+                            const double *d_orb, int norb_pad, void *stream);
+
 /* "pair" forms used by the meta-GGA branches (hcgto.py:420-438, 473-489), both on single-component (ngrid, lda)
  * arrays:  d_out_g = sum_ij a_gi D_ij b_gj   and   d_vmat = sym( sum_g w_g v_g a_ga b_gb ). */
 int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
