@@ -11,6 +11,7 @@
 //     launch reads: no host decision anywhere, the whole sequence is hipGraph-capturable.
 // `done` for iteration k = some earlier iteration reported max |X2 - X| < tol (the iterate is frozen from then on;
 // continuing would let the trace test pick the error-doubling branch at round-off level).
+#include <atomic>
 #include "common.hpp"
 
 namespace dqc {
@@ -144,8 +145,8 @@ constexpr int PST_WAVES = 8;  // waves (tiles) per worker block
 __global__ __launch_bounds__(64 * PST_WAVES) void purify_tc2_persist_kernel(double *__restrict__ x0, double *__restrict__ x1, int ld,
                                                                            double nocc, double tol, int iters,
                                                                            double *__restrict__ trace, double *__restrict__ idem,
-                                                                           unsigned *__restrict__ ctl, int nworker, double dsc) {
-    if (blockIdx.x & 7) return;  // workers = blocks 0, 8, 16, ...: one XCD under the round-robin dispatch
+                                                                           unsigned *__restrict__ ctl, int nworker, double dsc, int xsel) {
+    if ((int)(blockIdx.x & 7) != xsel) return;  // workers = blocks xsel, xsel + 8, ...: one XCD under the round-robin dispatch
     const int w = blockIdx.x >> 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
     const int T = ld >> 4, tile = w * PST_WAVES + wave;
@@ -286,8 +287,8 @@ __global__ __launch_bounds__(64 * PST_WAVES) void projector_persist_kernel(doubl
                                                                           double *__restrict__ bufs, double *__restrict__ rad,
                                                                           double *__restrict__ trace, double *__restrict__ idem,
                                                                           double *__restrict__ fin, unsigned *__restrict__ ctl,
-                                                                          int nworker, double dsc) {
-    if (blockIdx.x & 7) return;
+                                                                          int nworker, double dsc, int xsel) {
+    if ((int)(blockIdx.x & 7) != xsel) return;
     __shared__ double sred[KS == 1 ? 1 : PST_WAVES][256];
     const int w = blockIdx.x >> 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
@@ -646,6 +647,18 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(double *__restrict__ cou
 
 }  // namespace dqc
 
+// which XCD the next persistent projector runs on: round robin over the calls, so that the projectors of several molecules in flight
+// (batch.run_concurrent, one hipGraph per molecule: the choice is baked into the graph at capture) spread over the eight XCDs instead
+// of queueing on one.  Measured (tools/gpu_concurrent_projector_check.py, 16 C5 molecules, 8 / 16 in flight): 434 / 452 iterations/s
+// against 431 / 441 with every projector on XCD 0 -- within noise, the drivers are not bound there; kept because it costs nothing and
+// every one of the eight placements passes the kernel's own XCC check.  DQC_PROJECTOR_XCD = 0 ... 7 pins it (A/B runs).
+static int persist_next_xcd() {
+    static const int pin = [] { const char *e = getenv("DQC_PROJECTOR_XCD"); return e ? atoi(e) : -1; }();
+    static std::atomic<unsigned> next{0};
+    if (pin >= 0 && pin < 8) return pin;
+    return (int)(next.fetch_add(1u, std::memory_order_relaxed) & 7u);
+}
+
 extern "C" int dqc_diis_solve(double *d_c, const double *d_gram, int nmol, int nhist, int m, void *stream) {
     // d_gram (nmol, nhist, nhist) Gram matrices of the stored error vectors, the first m slots valid; d_c (nmol, nhist) Pulay
     // coefficients (zero for the unused slots).  Enqueues only.
@@ -690,6 +703,7 @@ extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_foc
     // (tried for n = 208 / 250, where a GEMM step takes 16 us: the block's eight waves sharing their tile row's A panel through LDS --
     // 44 % less L2 traffic, 0.555 -> 0.620 ms; so neither the L2 bandwidth nor the length of the load chain alone is the bound there)
     const int nworker = (T * T * ks + PST_WAVES - 1) / PST_WAVES;
+    const int xsel = persist_next_xcd();
     const size_t n2 = (size_t)ld * ld;
     double *bufs = d_work, *rad = bufs + 3 * n2, *trace = rad + ld, *idem = trace + (iters + 2), *fin = idem + (iters + 2);
     unsigned *ctl = (unsigned *)(fin + 4);
@@ -704,10 +718,10 @@ extern "C" int dqc_projector_tc2(double *d_p, double *d_err, const double *d_foc
     const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
     if (ks == 2)
         hipLaunchKernelGGL(projector_persist_kernel<2>, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
-                           bufs, rad, trace, idem, fin, ctl, nworker, dsc);
+                           bufs, rad, trace, idem, fin, ctl, nworker, dsc, xsel);
     else
         hipLaunchKernelGGL(projector_persist_kernel<1>, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_p, d_fock, n, ld, nocc, tol, iters,
-                           bufs, rad, trace, idem, fin, ctl, nworker, dsc);
+                           bufs, rad, trace, idem, fin, ctl, nworker, dsc, xsel);
     DQC_CHECK_LAUNCH();
     hipLaunchKernelGGL(projector_err_kernel, dim3(1), dim3(64), 0, st, d_err, fin, ctl);
     DQC_CHECK_LAUNCH();
@@ -736,8 +750,9 @@ extern "C" int dqc_purify_tc2_persist(double *d_x, double *d_tmp, int ld, double
     const double dsc = deterministic_mode() ? 70368744177664.0 : 0.0;
     hipLaunchKernelGGL(purify_trace_kernel, dim3(1), dim3(256), 0, st, d_x, ld, trace, (size_t)ld * ld, 2 * (iters + 2), dsc);
     DQC_CHECK_LAUNCH();
+    const int xsel = persist_next_xcd();
     hipLaunchKernelGGL(purify_tc2_persist_kernel, dim3(8 * nworker), dim3(64 * PST_WAVES), 0, st, d_x, d_tmp, ld, nocc, tol, iters,
-                       trace, idem, d_ctl, nworker, dsc);
+                       trace, idem, d_ctl, nworker, dsc, xsel);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
