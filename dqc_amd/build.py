@@ -67,9 +67,8 @@ GRID_SOURCES = ["grid_density.hip", "grid_vxc.hip"]
 
 
 def build_variant(name, defines, force=False):
-    """variant libraries: the grid sources recompiled with -D<define>, linked as libdqc_amd_<name>.so.  "fused"
-    (-DDQC_WITH_FUSED: the measured-negative fused grid pass, used by its own test only) is part of build_all(); the others are
-    perf-bisection builds selected with the DQC_AMD_LIB environment variable, never used by tests or bench defaults"""
+    """perf-bisection builds: the grid sources recompiled with -D<define>, linked as libdqc_amd_<name>.so and selected with the
+    DQC_AMD_LIB environment variable; never built by build_all(), never used by tests or bench defaults"""
     build()
     hipcc = _hipcc()
     out = os.path.join(HERE, "libdqc_amd_%s.so" % name)
@@ -85,10 +84,8 @@ def build_variant(name, defines, force=False):
 
 
 def build_all(force=False, verbose=False):
-    """the product library and the fused-pass variant its test loads"""
-    lib = build(force=force, verbose=verbose)
-    build_variant("fused", ["DQC_WITH_FUSED"], force=force)
-    return lib
+    """the product library (one .so)"""
+    return build(force=force, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -15,9 +15,6 @@
 // f64 MFMA fragment layout (gfx950): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // C[row = (lane>>4) + 4*reg][col = lane&15].
 #include "grid_common.hpp"
-#ifdef DQC_WITH_FUSED
-#include "grid_fused.h"
-#endif
 
 namespace dqc {
 
@@ -956,9 +953,6 @@ __global__ __launch_bounds__(VWU_NT, 3) void vxc_wsd_kernel(double *__restrict__
 }
 
 
-#ifdef DQC_WITH_FUSED  // the measured-negative fused grid pass: variant library only (libdqc_amd_fused.so, its own test)
-#include "grid_fused.inc"
-#endif
 
 // V = (M + M^T) / 2 on the (ld, ld) matrix (deterministic mode: M arrives as fixed-point integers).  Rows / columns nao .. ld - 1
 // are ZEROED: the kernels stage 16 T columns per AO row, and where the row stride of the AO arrays is below that
@@ -1253,8 +1247,5 @@ int dqc_debug_vwu_trace(long long *host_out) {
 }
 #endif
 
-#ifdef DQC_WITH_FUSED
-#include "grid_fused_entry.inc"
-#endif
 
 }  // extern "C"

@@ -120,24 +120,32 @@ DQC_DEV double coh_load(const double *p) {  // agent-scope relaxed: bypasses the
 // phase), not by where the stored line lives
 DQC_DEV void coh_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// wall_clock64() ticks at 100 MHz on gfx950: 5 ms
+constexpr unsigned long long PERSIST_TIMEOUT_TICKS = 500000ull;
 DQC_DEV bool persist_barrier(unsigned *ctl, unsigned target) {
-    // all of this worker's stores have been issued; wait for them, arrive, spin (bounded) until every worker has arrived
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // Every wave first waits for ITS OWN stores and atomics to be performed at the L2 (agent-scope release: s_waitcnt vmcnt(0) --
+    // a workgroup-scope fence only orders LDS/L1 traffic and left tile stores in flight when the arrival was published), then the
+    // block barrier, then one thread publishes the arrival (release) and polls (acquire) until every worker has arrived.  The
+    // spin is bounded by wall clock (s_memrealtime, 100 MHz): a few milliseconds, then the kernel gives up and the caller
+    // takes its eigh fallback.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     __shared__ int ok_;
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
-        for (int spin = 0; spin < (1 << 22); spin++) {  // ~ 0.1 us per probe: tens of milliseconds before giving up
-            if (__hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+        const unsigned long long t0 = wall_clock64();
+        for (;;) {
+            if (__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             if (__hip_atomic_load(&ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;  // somebody gave up
+            if (wall_clock64() - t0 > PERSIST_TIMEOUT_TICKS) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) __hip_atomic_store(&ctl[2], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok_ = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return ok_ != 0;
 }
 

@@ -159,7 +159,10 @@ class DeviceLoop:
         host-driven loop (a purification that did not converge: the step needs eigh)"""
         eng, n, S, dev = self.eng, self.n, self.S, self.eng.device
         f_tol, maxiter = float(opts["f_tol"]), int(opts["maxiter"])
+        if maxiter < 1:
+            raise RuntimeError("maxiter must be >= 1")
         trace = bool(os.environ.get("DQC_AMD_SCF_TRACE"))
+        qc._resume_dm = None
         # core guess (scf_qccalc.py:88-91): F0 = dm2scp(0), occupy its lowest orbitals -- the first step, eagerly
         z = torch.zeros((n, n), dtype=eng.dtype, device=dev)
         f0 = eng.dm2scp(SpinParam(u=z, d=z) if self.pol else z)
@@ -224,6 +227,11 @@ class DeviceLoop:
             done_at = maxiter - 1
         torch.cuda.synchronize(dev)
         if verdict == "fallback":
+            # the entering density of the failing iteration is the last good iterate (every earlier step passed its projector
+            # check): the host-driven loop resumes from it instead of the core guess
+            p = done_at % 2
+            if done_at >= 1:
+                qc._resume_dm = SpinParam(u=self.ring_d[p, 0].clone(), d=self.ring_d[p, 1].clone()) if self.pol else self.ring_d[p, 0].clone()
             return False
         # the entering pair of iteration `done_at` (the iteration launched after it wrote the other ring slot)
         p = done_at % 2

@@ -797,51 +797,6 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
     return vm
 
 
-_fused = None
-
-
-def load_fused():
-    """the VARIANT library with the fused density -> XC -> Vxc pass (libdqc_amd_fused.so, csrc/grid_fused.h): not part of the
-    product; built by dqc_amd.build.build_all() and loaded only by its test and by tools"""
-    global _fused
-    if _fused is None:
-        path = os.path.join(_HERE, "libdqc_amd_fused.so")
-        if not os.path.exists(path):
-            raise DqcAmdError("libdqc_amd_fused.so not found: python -m dqc_amd.build builds it")
-        so = ctypes.CDLL(path)
-        c_int, c_vp, c_dp = ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p
-        ip, dp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)
-        so.dqc_last_error.restype = ctypes.c_char_p
-        so.dqc_grid_fused_supported.argtypes = [c_int, c_int]
-        so.dqc_grid_fused.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_int, ip, dp, c_int, c_vp]
-        _fused = so
-    return _fused
-
-
-def grid_fused_supported(nao, norb_pad):
-    return bool(load_fused().dqc_grid_fused_supported(int(nao), int(norb_pad)))
-
-
-def grid_fused(ao, nao, w, factor, terms, want_dens=False, want_exc=False):
-    """(variant library) density -> XC -> Vxc from one read of the AO matrix (4, ngrid, ld); factor = pad_factor(...) pair; terms:
-    LDA / GGA list.  -> (vmat (ld, ld), rho or None, grho (3, ngrid) or None, exc (1,) or None)"""
-    orb, orbt = factor
-    ngrid, ld = ao.shape[-2], padded_nao(nao)
-    ids = (ctypes.c_int * len(terms))(*[XC_IDS[nm] for _, nm in terms])
-    cfs = (ctypes.c_double * len(terms))(*[float(c) for c, _ in terms])
-    vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
-    rho = torch.empty(ngrid, dtype=torch.float64, device=ao.device) if want_dens else None
-    grho = torch.empty((3, ngrid), dtype=torch.float64, device=ao.device) if want_dens else None
-    exc = torch.empty(1, dtype=torch.float64, device=ao.device) if want_exc else None
-    so = load_fused()
-    with _on(ao.device) as st_:
-        rc = so.dqc_grid_fused(_ptr(vm), _ptr(rho), _ptr(grho), _ptr(exc), _ptr(ao), ngrid, nao, _ptr(w), _ptr(orb), _ptr(orbt),
-                               orb.shape[1], ids, cfs, len(terms), st_)
-        if rc != 0:
-            raise DqcAmdError("dqc_grid_fused failed (%d): %s" % (rc, so.dqc_last_error().decode()))
-    return vm, rho, grho, exc
-
-
 def probe_stream_read(buf):
     out = torch.zeros(1, dtype=torch.float64, device=buf.device)
     with _on(buf.device) as st_:

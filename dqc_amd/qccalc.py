@@ -168,6 +168,9 @@ class SCF_QCCalc:
                 self.driver_used = "device"  # (which loop produced the result: diagnostics / tests)
                 return self
         self.driver_used = "host"
+        resume = getattr(self, "_resume_dm", None)  # the device loop's last good density (a projector failure mid-run)
+        if resume is not None:
+            dm0, self._resume_dm = resume, None
         gen = self._run_gen(dm0, fwd_options)
         # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
         # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives
