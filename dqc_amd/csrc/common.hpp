@@ -92,7 +92,14 @@ struct Basis {
     std::vector<double> exps, coefs;  // flat per-primitive arrays (coefs already radially normalised)
     int nao = 0, natm = 0;
     std::vector<double> atom_xyz, atom_z;
+    // grouped view (group_s_shells; eri_core.hpp "General contractions"): `shells` are then GROUPS -- an s group may hold a second
+    // member shell over the same exponents: its AO offset (-1: none) and its coefficients (same indexing as coefs; 0: none)
+    std::vector<int> ao_off1;
+    std::vector<double> coefs1;
+    bool grouped() const { return !ao_off1.empty(); }
 };
+// merge the s shells of one atom that share their exponent list, two per group (host.hip)
+void group_s_shells(const Basis &b, Basis &g);
 
 // returns 0 or DQC_EINVAL
 int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, const double *env,
@@ -101,6 +108,7 @@ int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, co
 // device mirror of the shell table (SoA, uploaded once per call)
 struct DevShells {
     int *l = nullptr, *nprim = nullptr, *ao_off = nullptr, *prim_off = nullptr;
+    int *ao_off1 = nullptr;  // grouped view only: AO offset of a group's second member (-1: none)
     double *xyz = nullptr;  // (nsh,3)
     double *exps = nullptr, *coefs = nullptr;
     int nsh = 0;

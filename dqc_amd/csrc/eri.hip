@@ -58,9 +58,25 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
 // ---------------------------------------------------------------------------------------------
 // class dispatch
 // ---------------------------------------------------------------------------------------------
+// depth bins of every pair class (the pairs of a class are sorted by primitive-pair count, descending: bins are ranges), host
+// and device copies, and the pool the per-launch wave maps are uploaded through
+struct WaveMaps {
+    std::vector<int> bins;  // (NCLS, SCREEN_NBIN + 1) bin starts relative to the class start
+    const int *d_bins = nullptr;
+    DevPool *pool = nullptr;
+};
+static void wave_map_bins(const HostPairs &hp, int ncls, std::vector<int> &bins) {
+    bins.assign((size_t)ncls * (SCREEN_NBIN + 1), 0);
+    for (int c = 0; c < ncls; c++) {
+        int *bs = bins.data() + (size_t)c * (SCREEN_NBIN + 1);
+        for (int i = 0; i < hp.cls_count[c]; i++) bs[screen_bin(hp.pp_off[hp.cls_start[c] + i + 1] - hp.pp_off[hp.cls_start[c] + i]) + 1]++;
+        for (int k = 0; k < SCREEN_NBIN; k++) bs[k + 1] += bs[k];
+    }
+}
+
 template <int LA, int LB, int LC, int LD>
 static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st,
-                        const EriOut &og) {
+                        const EriOut &og, const WaveMaps *wm = nullptr) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
@@ -68,10 +84,38 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     const int same = cb == ck;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
-    (void)hipFuncSetAttribute((const void *)eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)Cfg::LDS_BYTES);
-    hipLaunchKernelGGL((eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>), dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp,
-                       dp, hp.cls_start[cb], nb, hp.cls_start[ck], nk, same, ntask, og);
+    // grouped tables (general contractions merged: eri_core.hpp): the instantiation with the coefficient slots of the two pair classes
+    constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
+    auto kern = dp.stride == PP_STRIDE_G ? eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (Cfg::TPQ <= 16 && wm != nullptr) {
+        // lane groups of <= 16 lanes: depth-binned wave map (eri_core.hpp: eri_split_lanes) -- per (ket pair, bra depth bin) the
+        // waves that cover the bin's bra pairs (>= the ket pair in a diagonal class) with PS lane groups per quartet
+        std::vector<int2> wtab;
+        const int *bb = wm->bins.data() + (size_t)cb * (SCREEN_NBIN + 1);
+        for (int ik = 0; ik < nk; ik++) {
+            const int nkp = hp.pp_off[hp.cls_start[ck] + ik + 1] - hp.pp_off[hp.cls_start[ck] + ik];
+            for (int bin = 0; bin < SCREEN_NBIN; bin++) {
+                const int bs = (same && ik > bb[bin]) ? ik : bb[bin];
+                const int per = 64 / (eri_split_lanes(bin, nkp, Cfg::TPQ) * Cfg::TPQ);
+                for (int b1 = bs; b1 < bb[bin + 1]; b1 += per) wtab.push_back(make_int2(ik * 8 + bin, b1));
+            }
+        }
+        static_assert(SCREEN_NBIN == 8, "wave table packs the bin into three bits");
+        const long long nwave = (long long)wtab.size();
+        if (nwave == 0) return 0;
+        int2 *d_wtab = nullptr;
+        if (wm->pool->upload(&d_wtab, wtab, st)) { set_error("dqc_eri_fill_tiles: device upload failed"); return DQC_ENOMEM; }
+        EriOut o2 = og;
+        o2.wtab = d_wtab;
+        o2.wbin = wm->d_bins + (size_t)cb * (SCREEN_NBIN + 1);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nwave + 3) / 4)), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp, dp, hp.cls_start[cb], nb,
+                           hp.cls_start[ck], nk, same, nwave, o2);
+        DQC_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp, dp, hp.cls_start[cb], nb,
+                       hp.cls_start[ck], nk, same, ntask, og);
     DQC_CHECK_LAUNCH();
     return 0;
 }
@@ -79,13 +123,14 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
 // all classes with (LA>=LB), (LC>=LD), class(bra) >= class(ket)
 template <int CB, int CK>
 struct ClassLoop {
-    static int run(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st, const EriOut &og) {
+    static int run(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st, const EriOut &og,
+                   const WaveMaps *wm = nullptr) {
         constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
         constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
-        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, dp, hp, st, og);
+        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, dp, hp, st, og, wm);
         if (rc) return rc;
-        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, dp, hp, st, og);
-        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, dp, hp, st, og);
+        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, dp, hp, st, og, wm);
+        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, dp, hp, st, og, wm);
         else return 0;
     }
 };
@@ -587,11 +632,20 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     double *d_tiles = d_tiles_part - lo;  // virtual origin: the kernels address by offsets in the whole store
     DQC_HIP(hipMemsetAsync(d_tiles_part, 0, sizeof(double) * (size_t)(hi - lo), st));  // packed store (common.hpp)
     if ((rc = boys_table_ensure())) return rc;
+    // general contractions: s shells of one atom over the same exponents are evaluated together (eri_core.hpp).  The runtime
+    // kernel of the g-shell classes reads ungrouped tables: a basis with g shells (or DQC_ERI_GENERIC) is not grouped
+    // (DQC_ERI_GROUP=0: A/B runs)
+    static const bool group_env = [] { const char *e = getenv("DQC_ERI_GROUP"); return !(e && e[0] == '0'); }();
+    bool group = group_env && !hl_forced();
+    for (const HostShell &h : b.shells) group = group && h.l <= ERI_LMAX;
+    Basis bg;
+    if (group) group_s_shells(b, bg);
+    const Basis &bu = group ? bg : b;
     HostPairs hp;
-    build_pairs(b, hp);
+    build_pairs(bu, hp);
     DevPool pool(st);  // stream-ordered scratch: this call only enqueues
     DevShells ds;
-    if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
+    if ((rc = upload_shells(ds, bu, pool, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
     int *d_sh = nullptr, *d_off = nullptr;
     double *d_pp = nullptr;
     if ((rc = pool.upload(&d_sh, hp.sh, st)) || (rc = pool.upload(&d_off, hp.pp_off, st)) ||
@@ -599,13 +653,24 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
         set_error("dqc_eri_fill_tiles: device upload failed");
         return rc;
     }
-    DevPairs dp{d_sh, d_off, d_pp};
+    DevPairs dp{d_sh, d_off, d_pp, hp.stride};
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     EriOut og{0, 0, 0, 0};
     og.st_lo = lo;
     og.st_hi = hi;
     og.st_nao = b.nao;
-    rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og);
+    if (const char *e = getenv("DQC_ERI_DBG")) og.dbg = atoi(e);
+    // depth-binned wave maps of the one-lane classes (DQC_ERI_WMAP=0: the plain wave-transposed map, A/B runs)
+    static const bool wmap_env = [] { const char *e = getenv("DQC_ERI_WMAP"); return !(e && e[0] == '0'); }();
+    WaveMaps wm;
+    if (wmap_env) {
+        wave_map_bins(hp, NCLS, wm.bins);
+        int *d_bins = nullptr;
+        if ((rc = pool.upload(&d_bins, wm.bins, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
+        wm.d_bins = d_bins;
+        wm.pool = &pool;
+    }
+    rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og, wmap_env ? &wm : nullptr);
     if (rc) return rc;
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;
     return DQC_OK;

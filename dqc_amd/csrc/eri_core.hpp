@@ -59,7 +59,26 @@ DQC_DEV void boys01_lds(const __attribute__((address_space(3))) double *lt, doub
 struct DevPairs {
     const int *sh;       // (npair, 2): first shell has the higher (or equal) l
     const int *pp_off;   // (npair+1)
-    const double *pp;    // (npp, 5): p, Px, Py, Pz, ca*cb*Kab / p
+    const double *pp;    // (npp, stride): p, Px, Py, Pz, ca*cb*Kab / p  [grouped tables: four coefficient slots, see below]
+    int stride = 5;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// General contractions (round 5).  The reference splits a generally contracted shell into one shell per contraction
+// (dqc/api/loadbasis.py:72-82): a cc-pVDZ carbon arrives with TWO s shells over the same eight exponents (and a third, single
+// primitive one).  Every primitive integral over those exponents was evaluated once per contraction -- up to 16 times for an
+// (ss|ss) quartet of four such shells, and the deep s contractions are where a cc-pVDZ / cc-pVTZ fill spends its time.  The
+// fill therefore works on GROUPS: s shells of one atom with identical exponent lists are merged (at most two per group: a third
+// one starts a new group), a group pair carries up to FOUR coefficient products per primitive pair (slot 2 xa + xb for members
+// xa of the first and xb of the second group; c_a c_b K_ab / p, zero for an absent member), the primitive integral -- formed
+// WITHOUT coefficients -- is accumulated into NPB x NPK accumulator sets, and the output phase runs once per member
+// combination (each is an ordinary shell quartet).  Only l = 0 groups are merged (the accumulators of a class scale with the
+// number of combinations, and s shells are the ones the basis sets of the configs contract generally); a pair class (la, 0)
+// has two slots, (0, 0) four, every other one.  PP_STRIDE_G doubles per primitive pair: p, P, four coefficient slots.
+constexpr int PP_STRIDE_G = 8;
+template <int LA, int LB>
+struct PairSlots {  // coefficient slots of a grouped pair class
+    static constexpr int N = LB == 0 ? (LA == 0 ? 4 : 2) : 1;
 };
 
 __host__ __device__ constexpr int c_ncart(int l) { return (l + 1) * (l + 2) / 2; }
@@ -124,6 +143,37 @@ struct EriCfg {
     static constexpr int REGION_G = GSZ | 1;
     static constexpr size_t REG_DOUBLES_G = (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
     static constexpr size_t LDS_BYTES_G = sizeof(double) * (REG_DOUBLES_G + TAB_DOUBLES);
+};
+
+// positions of the Cartesian output n = ((ca NCB + cb) NCC + cc) NCD + cd in the three staged 2D-integral arrays, packed
+// ixx | iyy << 10 | izz << 20 -- a compile-time table per class (computing it in the kernel -- four cart_pow loops and three
+// divisions per output -- was most of the 18 ms a naphthalene / cc-pVTZ fill spent outside the primitive loops and the output phase)
+constexpr void c_cart_pow(int l, int c, int &lx, int &ly, int &lz) {
+    int row = 0, acc = 0;
+    while (acc + row + 1 <= c) { acc += row + 1; row++; }
+    lx = l - row;
+    const int k = c - acc;
+    ly = row - k;
+    lz = k;
+}
+template <int LA, int LB, int LC, int LD>
+struct OidxTab {
+    static constexpr int NCA = c_ncart(LA), NCB = c_ncart(LB), NCC = c_ncart(LC), NCD = c_ncart(LD), NOUT = NCA * NCB * NCC * NCD;
+    int v[NOUT];
+    constexpr OidxTab() : v{} {
+        for (int n = 0; n < NOUT; n++) {
+            const int cd = n % NCD, cc = (n / NCD) % NCC, cb = (n / (NCD * NCC)) % NCB, ca = n / (NCD * NCC * NCB);
+            int ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0, cx = 0, cy = 0, cz = 0, dx = 0, dy = 0, dz = 0;
+            c_cart_pow(LA, ca, ax, ay, az);
+            c_cart_pow(LB, cb, bx, by, bz);
+            c_cart_pow(LC, cc, cx, cy, cz);
+            c_cart_pow(LD, cd, dx, dy, dz);
+            const int ixx = ((ax * (LB + 1) + bx) * (LC + 1) + cx) * (LD + 1) + dx;
+            const int iyy = ((ay * (LB + 1) + by) * (LC + 1) + cy) * (LD + 1) + dy;
+            const int izz = ((az * (LB + 1) + bz) * (LC + 1) + cz) * (LD + 1) + dz;
+            v[n] = ixx | (iyy << 10) | (izz << 20);
+        }
+    }
 };
 
 // output modes of the kernel
@@ -191,6 +241,11 @@ struct EriOut {
     const int *pbin = nullptr;
     double tau = 0.0;
     int nsh = 0;
+    // ---- depth-binned wave map of the one-lane-per-quartet classes (fill; see eri_split_lanes): wtab = per wave (8 ket pair +
+    //      bra depth bin, first bra pair of the wave), wbin = the bra class's bin starts
+    const int2 *wtab = nullptr;
+    const int *wbin = nullptr;
+    int dbg = 0;  // timing experiments (DQC_ERI_DBG): 1 = skip the primitive loops, 2 = skip the output phase, 4 = skip the tile stores only
     // ---- one molecule sharded over GPUs (dqc_direct_jk_part): this launch is part `part` of `nparts` interleaved block sets
     int part = 0, nparts = 1;
     // ---- TILES mode: slice [st_lo, st_hi) (double offsets) of the store this launch fills (dqc_eri_fill_tiles_part)
@@ -201,6 +256,25 @@ constexpr int SCREEN_NBIN = 8;
 // contraction-depth bin of a pair with npp surviving primitive pairs: 0 = deepest (> 64) ... 7 = one primitive pair (or none)
 __host__ __device__ constexpr int screen_bin(int npp) {
     return npp > 64 ? 0 : (npp > 32 ? 1 : (npp > 16 ? 2 : (npp > 8 ? 3 : (npp > 4 ? 4 : (npp > 2 ? 5 : (npp > 1 ? 6 : 7))))));
+}
+
+// Lane GROUPS per shell quartet under the depth-binned wave map (round 5; classes whose lane group has <= 16 lanes).  A deep contraction -- two
+// 8-primitive s shells on each side: up to 4096 primitive quartets -- walked by ONE lane is a serial chain of dependent loads,
+// LDS lookups and fp64 divisions/rsqrt: the deepest waves of the (ss|ss) launch ran ~1 ms on their own while most of the
+// chip idled (the fill was latency-bound, not throughput-bound: merging the general contractions cut the primitive quartets of
+// that class 5x and its time not at all).  The PRIMITIVE quartets of a quartet are therefore spread over PS = 2^k lane groups
+// (of TPQ lanes each, every group with its own LDS region), the partial sums combined by a butterfly of shuffles, and the member
+// combinations of the output phase dealt to the same groups.  PS is uniform per wave: a wave takes ONE ket pair and
+// 64 / (PS TPQ) bra pairs of ONE depth bin (pairs are sorted by depth inside a class), so it follows from the bin's bound and
+// the ket pair's primitive count: ~8 primitive quartets per lane group.
+__host__ __device__ constexpr int screen_bin_bound(int bin) {  // largest primitive-pair count of the bin (bin 0: open, 128 stands in)
+    return bin == 0 ? 128 : (128 >> bin);
+}
+__host__ __device__ inline int eri_split_lanes(int bin, int nkp, int tpq) {  // tpq: lanes of one lane group (EriCfg::TPQ <= 16)
+    const int depth = screen_bin_bound(bin) * nkp;
+    int ps = 1;
+    while (ps * tpq < 64 && ps * 8 < depth) ps <<= 1;
+    return ps;
 }
 
 // largest i in [0, n) with off[i] <= t (off has n + 1 non-decreasing entries, off[0] = 0 <= t < off[n])
@@ -243,10 +317,46 @@ DQC_DEV void eri_group_sync() {
     }
 }
 
-template <int LA, int LB, int LC, int LD, int MODE>
+// compile-time copy of the solid-harmonic tables: the fibre transform below unrolls over it and keeps the non-zero terms only
+namespace c2s_ce {
+#define C2S_QUAL constexpr
+#include "cart2sph.inc"
+#undef C2S_QUAL
+}  // namespace c2s_ce
+
+// one Cartesian -> solid-harmonic transform of the output phase: src [NOUTER][NC][NINNER] -> dst [NOUTER][NS][NINNER], the fibres
+// (outer, inner) dealt to the TPQ lanes of the quartet's lane group
+template <int L, int NOUTER, int NINNER, int TPQ>
+DQC_DEV void c2s_fibres(const double *__restrict__ src, double *__restrict__ dst, int s) {
+    constexpr int NC = (L + 1) * (L + 2) / 2, NS = 2 * L + 1;
+    for (int f = s; f < NOUTER * NINNER; f += TPQ) {
+        const int o = f / NINNER, in = f - o * NINNER;
+        double x[NC], y[NS];
+#pragma unroll
+        for (int c = 0; c < NC; c++) x[c] = src[(o * NC + c) * NINNER + in];
+#pragma unroll
+        for (int m = 0; m < NS; m++) {
+            y[m] = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                constexpr int off = c2s_ce::C2S_OFF[L];
+                const double cf = c2s_ce::C2S[off + m * NC + c];
+                if (cf != 0.0) y[m] += cf * x[c];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NS; m++) dst[(o * NS + m) * NINNER + in] = y[m];
+    }
+}
+
+template <int LA, int LB, int LC, int LD, int MODE, int NPB = 1, int NPK = 1>
 __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, DevShells sh, DevPairs prs, DevPairs prk,
                                                   int b0, int nb, int k0, int nk, int same, long long ntask, EriOut og) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
+    // member combinations of a grouped quartet (1: ordinary shell quartets, the tables may have any stride)
+    constexpr int NE = NPB * NPK;
+    static_assert(NE == 1 || MODE == ERI_OUT_TILES || MODE == ERI_OUT_JK || MODE == ERI_OUT_SCHWARZ, "grouped tables: fill / direct modes only");
+    static_assert((NPB == 1 || NPB == PairSlots<LA, LB>::N) && (NPK == 1 || NPK == PairSlots<LC, LD>::N), "slot count of the pair class");
     constexpr int NR = Cfg::NR, TPQ = Cfg::TPQ, QPB = Cfg::QPB, NPT = Cfg::NPT, G1 = Cfg::G1, NOUT = Cfg::NOUT;
     constexpr int NMAX = LA + LB, MMAX = LC + LD;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -260,9 +370,6 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     typedef __attribute__((address_space(3))) double lds_double_t;
     lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G
                                                  : (MODE == ERI_OUT_JK ? Cfg::REG_DOUBLES_JK : Cfg::REG_DOUBLES));
-    if constexpr (MODE == ERI_OUT_JK) {  // the quartet's partial J / K sums start at zero (synchronised by the phases below)
-        for (int e = s; e < Cfg::NJK; e += TPQ) reg[Cfg::REG0 + e] = 0.0;
-    }
     if constexpr (TAB_LDS) {
         if constexpr (Cfg::BOYS01) boys_stage_lds(ltab, tid, 256);
         else rys_stage_lds<NR>(ltab, tid, 256);
@@ -275,6 +382,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     bool active = task < ntask;
     if (!active) task = ntask - 1;
     int ib, ik;
+    int psl = 1, psj = 0;  // lane groups that share this lane's quartet (wave map) and this lane's group among them
     if (same == 2) {  // diagonal quartets (ab|ab) only (Schwarz bounds): ntask = nb
         ib = ik = (int)task;
     } else if (og.toff != nullptr) {
@@ -297,6 +405,22 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             ib = e / SCREEN_NBIN;
             ik = og.pbin[e % SCREEN_NBIN] + (int)(task - og.toff[e]);
         }
+    } else
+    if (TPQ <= 16 && og.wtab != nullptr) {
+        // depth-binned wave map: the host's table names every wave's (ket pair, bra depth bin) and first bra pair -- PS lane groups
+        // per quartet, 64 / (PS TPQ) bra pairs per wave (a bisection over prefix offsets here cost 9 us of dependent loads per wave)
+        const long long wv = bidx * 4 + (tid >> 6);
+        const bool inr = wv < ntask;
+        const int2 we = og.wtab[inr ? wv : ntask - 1];
+        const int ikl = we.x >> 3, bin = we.x & 7;
+        const int nkp_ = prk.pp_off[k0 + ikl + 1] - prk.pp_off[k0 + ikl];
+        psl = eri_split_lanes(bin, nkp_, TPQ);
+        const int grp = (tid & 63) / TPQ;  // lane group inside the wave
+        const int ibl = we.y + grp / psl;
+        psj = grp % psl;
+        active = inr && ibl < og.wbin[bin + 1];
+        ib = ibl < nb ? ibl : nb - 1;
+        ik = ikl;
     } else
     if constexpr (TPQ == 1) {
         // one lane per shell quartet: WAVE-TRANSPOSED task map -- the 64 lanes of a wave take 64 consecutive BRA pairs and ONE
@@ -336,7 +460,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     }
     const int pb0 = prs.pp_off[ib], nbp = prs.pp_off[ib + 1] - pb0;
     const int pk0 = prk.pp_off[ik], nkp = prk.pp_off[ik + 1] - pk0;
-    const int nq = active ? nbp * nkp : 0;
+    const bool loops_on = active && !(og.dbg & 1);
+    const int nq = loops_on ? nbp * nkp : 0;
 
     int maxq = nq;  // groups inside a wave: the wave simply runs until its longest quartet is done (`on` masks the others)
     if (TPQ > 64) {  // the group is the block: block-uniform trip count so that the barriers below are legal
@@ -348,24 +473,16 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     }
 
     // output ownership: lane s owns Cartesian outputs n = s + TPQ*m
+    static constexpr OidxTab<LA, LB, LC, LD> c_oidx{};
     int oidx[NPT];
-    double acc[NPT];
+    double acc[NE][NPT];
 #pragma unroll
     for (int m = 0; m < NPT; m++) {
-        acc[m] = 0.0;
+#pragma unroll
+        for (int e = 0; e < NE; e++) acc[e][m] = 0.0;
         int n = s + TPQ * m;
         if (n >= NOUT) n = NOUT - 1;
-        const int cd = n % Cfg::NCD, cc = (n / Cfg::NCD) % Cfg::NCC, cb = (n / (Cfg::NCD * Cfg::NCC)) % Cfg::NCB,
-                  ca = n / (Cfg::NCD * Cfg::NCC * Cfg::NCB);
-        int ax, ay, az, bx, by, bz, cx, cy, cz, dx, dy, dz;
-        cart_pow(LA, ca, ax, ay, az);
-        cart_pow(LB, cb, bx, by, bz);
-        cart_pow(LC, cc, cx, cy, cz);
-        cart_pow(LD, cd, dx, dy, dz);
-        const int ixx = ((ax * (LB + 1) + bx) * (LC + 1) + cx) * (LD + 1) + dx;
-        const int iyy = ((ay * (LB + 1) + by) * (LC + 1) + cy) * (LD + 1) + dy;
-        const int izz = ((az * (LB + 1) + bz) * (LC + 1) + cz) * (LD + 1) + dz;
-        oidx[m] = ixx | (iyy << 10) | (izz << 20);
+        oidx[m] = c_oidx.v[n];
     }
 
     if constexpr (Cfg::BOYS01 && TAB_LDS) {
@@ -373,20 +490,34 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         // (the general path below stages three 2D integrals per primitive quartet in LDS and reads them back; these deep s
         // contractions -- up to 4096 primitive quartets per shell quartet in cc-pVDZ -- were 27 % of a 20-atom fill)
         static_assert(TPQ == 1, "closed-form classes run one lane per shell quartet");
-        for (int ipb = 0; ipb < (active ? nbp : 0); ipb++) {
-            const double *pb = prs.pp + (size_t)(pb0 + ipb) * 5;
-            const double p = pb[0], P0 = pb[1], P1 = pb[2], P2 = pb[3], kb = pb[4] * 34.986836655249725;  // 2 pi^(5/2) K_ab / p
-            for (int ipk = 0; ipk < nkp; ipk++) {
-                const double *pk = prk.pp + (size_t)(pk0 + ipk) * 5;
+        // the psl lanes of the quartet tile its primitive pairs: psk lanes along the ket list (wave-uniform), the rest along the bra list
+        int psk = 1;
+        while (psk < psl && psk < nkp) psk <<= 1;
+        const int psb = psl / psk, jb = psj / psk, jk = psj % psk;
+        for (int ipb = jb; ipb < (loops_on ? nbp : 0); ipb += psb) {
+            const double *pb = prs.pp + (size_t)(pb0 + ipb) * prs.stride;
+            // NE == 1: the coefficient rides in the prefactor; grouped: the primitive integral is formed without coefficients,
+            // summed over the ket primitives per ket slot (tk) and spread over the bra slots once per bra primitive pair
+            const double p = pb[0], P0 = pb[1], P1 = pb[2], P2 = pb[3], kb = (NE == 1 ? pb[4] : 1.0) * 34.986836655249725;  // 2 pi^(5/2) K_ab / p
+            double tk[NPK][NPT];
+            if constexpr (NE > 1) {
+#pragma unroll
+                for (int k = 0; k < NPK; k++)
+#pragma unroll
+                    for (int m = 0; m < NPT; m++) tk[k][m] = 0.0;
+            }
+            for (int ipk = jk; ipk < nkp; ipk += psk) {
+                const double *pk = prk.pp + (size_t)(pk0 + ipk) * prk.stride;
                 const double qq = pk[0];
                 const double d0 = P0 - pk[1], d1 = P1 - pk[2], d2 = P2 - pk[3];
                 const double rs_ = rsqrt(p + qq), ipq = rs_ * rs_;  // no division in this loop: the pair table carries K / p
                 const double X = p * qq * ipq * (d0 * d0 + d1 * d1 + d2 * d2);
-                const double pref = kb * pk[4] * rs_;  // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q))
+                const double pref = kb * (NE == 1 ? pk[4] : 1.0) * rs_;  // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q))
                 double f0, f1;
                 boys01_lds(ltab, X, f0, f1);
+                double val[NPT];
                 if constexpr (LA == 0) {
-                    acc[0] += pref * f0;
+                    val[0] = pref * f0;
                 } else {
                     const double w0 = pref * f0, w1 = pref * f1 * qq * ipq;
                     const double v[3] = {w0 * (P0 - A[0]) - w1 * d0, w0 * (P1 - A[1]) - w1 * d1, w0 * (P2 - A[2]) - w1 * d2};
@@ -394,18 +525,39 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                     for (int m = 0; m < NPT; m++) {
                         int ax, ay, az;
                         cart_pow(1, m, ax, ay, az);
-                        acc[m] += ax ? v[0] : (ay ? v[1] : v[2]);
+                        val[m] = ax ? v[0] : (ay ? v[1] : v[2]);
                     }
+                }
+                if constexpr (NE == 1) {
+#pragma unroll
+                    for (int m = 0; m < NPT; m++) acc[0][m] += val[m];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPK; k++) {
+                        const double ck = pk[4 + k];
+#pragma unroll
+                        for (int m = 0; m < NPT; m++) tk[k][m] += ck * val[m];
+                    }
+                }
+            }
+            if constexpr (NE > 1) {
+#pragma unroll
+                for (int b = 0; b < NPB; b++) {
+                    const double cb = pb[4 + b];
+#pragma unroll
+                    for (int k = 0; k < NPK; k++)
+#pragma unroll
+                        for (int m = 0; m < NPT; m++) acc[b * NPK + k][m] += cb * tk[k][m];
                 }
             }
         }
     } else
-    for (int iq = 0; iq < maxq; iq++) {
+    for (int iq = psj; iq < maxq; iq += psl) {  // (psl = 1, psj = 0 except under the wave map)
         const bool on = iq < nq;
         // ---------------- phase A: 2D integrals for every (direction, root) ----------------
+        const int ipb = on ? iq / nkp : 0, ipk = on ? iq - ipb * nkp : 0;
+        const double *pb = prs.pp + (size_t)(pb0 + ipb) * prs.stride, *pk = prk.pp + (size_t)(pk0 + ipk) * prk.stride;
         if (on) {
-            const int ipb = iq / nkp, ipk = iq - ipb * nkp;
-            const double *pb = prs.pp + (size_t)(pb0 + ipb) * 5, *pk = prk.pp + (size_t)(pk0 + ipk) * 5;
             const double p = pb[0], qq = pk[0];
             const double P[3] = {pb[1], pb[2], pb[3]}, Q[3] = {pk[1], pk[2], pk[3]};
             const double pq = p + qq, rho = p * qq / pq;
@@ -413,7 +565,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
             // reciprocals once per primitive quartet: the recurrence coefficients below were five fp64 divisions per item
             const double ipq = 1.0 / pq, ip = 1.0 / p, iqq = 1.0 / qq;
-            const double pref = pb[4] * pk[4] * 34.986836655249725 * sqrt(ipq);  // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q)): the table holds K / p
+            // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q)): the table holds K / p (grouped: coefficients applied in phase B)
+            const double pref = (NE == 1 ? pb[4] * pk[4] : 1.0) * 34.986836655249725 * sqrt(ipq);
             // the NR roots depend on X only, not on the direction: lane s of the quartet's group evaluates root s % NR ONCE and
             // the (direction, root) items fetch theirs by shuffle (a one-lane group loops over all roots) -- per item this
             // was a Clenshaw evaluation of its own, i.e. three times the work in groups of 1 or 4 lanes
@@ -502,6 +655,13 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         eri_group_sync<TPQ>();
         // ---------------- phase B: accumulate the Cartesian outputs ----------------
         if (on) {
+            double cbk[NE];
+            if constexpr (NE > 1) {
+#pragma unroll
+                for (int b = 0; b < NPB; b++)
+#pragma unroll
+                    for (int k = 0; k < NPK; k++) cbk[b * NPK + k] = pb[4 + b] * pk[4 + k];
+            }
 #pragma unroll
             for (int m = 0; m < NPT; m++) {
                 const int ixx = oidx[m] & 1023, iyy = (oidx[m] >> 10) & 1023, izz = oidx[m] >> 20;
@@ -509,12 +669,24 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 #pragma unroll
                 for (int r = 0; r < NR; r++)
                     v += reg[r * G1 + ixx] * reg[(NR + r) * G1 + iyy] * reg[(2 * NR + r) * G1 + izz];
-                acc[m] += v;
+                if constexpr (NE == 1) acc[0][m] += v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < NE; e++) acc[e][m] += cbk[e] * v;
+                }
             }
         }
         eri_group_sync<TPQ>();
     }
 
+    if constexpr (TPQ <= 16) {
+        // the lane groups that shared the quartet's primitive quartets combine their partial sums (every group ends with the total)
+        for (int o = 1; o < psl; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+#pragma unroll
+                for (int m = 0; m < NPT; m++) acc[e][m] += __shfl_xor(acc[e][m], o * TPQ);
+    }
     if constexpr (MODE == ERI_OUT_GRAD) {
         // ---------------- gradient contraction straight from the Cartesian accumulators ----------------
         const int a = ish % og.norig;             // original shell behind the up / down companion
@@ -557,7 +729,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                         f = 2.0 * D[ia * nc + ib] * og.ccart[ic];
                     else
                         f = -og.ccart[ia] * og.ccart[ic];
-                    g[dir] += coef * acc[m] * f;
+                    g[dir] += coef * acc[0][m] * f;
                 }
             }
         }
@@ -589,61 +761,71 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         }
         return;
     }
+    if (og.dbg & 2) return;
     // ---------------- phase C: Cartesian -> solid harmonics (LDS), scatter to tiles ----------------
+    // once per member combination of a grouped quartet (NE == 1: the shell quartet itself).  Members: bra slot eb = 2 xa + xb
+    // ((s s| pairs; xb alone for (l s|), ket alike; a combination is an ordinary shell quartet with its own AO offsets.  Of the
+    // combinations that are the same integrals -- (xa, xb) and (xb, xa) inside one group, (eb, ek) and (ek, eb) when bra and ket
+    // are the same group pair -- one is kept, so every shell quartet is visited exactly once
     double *buf0 = reg, *buf1 = reg + NOUT;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+    const int eb = e / NPK, ek = e % NPK;
+    const int xa = NPB == 4 ? eb >> 1 : 0, xb = NPB == 4 ? eb & 1 : eb, xc = NPK == 4 ? ek >> 1 : 0, xd = NPK == 4 ? ek & 1 : ek;
+    int ai = sh.ao_off[ish], aj = sh.ao_off[jsh], ak = sh.ao_off[ksh], al = sh.ao_off[lsh];
+    bool act = active && (e & (psl - 1)) == psj;  // (the combinations dealt to the lane groups that shared the quartet)
+    if constexpr (NE > 1) {
+        if (xa) ai = sh.ao_off1[ish];
+        if (xb) aj = sh.ao_off1[jsh];
+        if (xc) ak = sh.ao_off1[ksh];
+        if (xd) al = sh.ao_off1[lsh];
+        act = act && ai >= 0 && aj >= 0 && ak >= 0 && al >= 0 && !(ish == jsh && xa < xb) && !(ksh == lsh && xc < xd) &&
+              !(ib == ik && eb < ek);
+        if constexpr (TPQ > 64) {  // (the group is the block: the barriers below stay block-uniform)
+            if (!act) continue;
+        } else if (!__any(act)) continue;
+        eri_group_sync<TPQ>();  // the previous combination's last stage has read buf1
+    }
+    if constexpr (MODE == ERI_OUT_JK) {  // the combination's partial J / K sums start at zero (synchronised by the stages below)
+        for (int x = s; x < Cfg::NJK; x += TPQ) reg[Cfg::REG0 + x] = 0.0;
+    }
 #pragma unroll
     for (int m = 0; m < NPT; m++) {
         const int n = s + TPQ * m;
-        if (n < NOUT) buf0[n] = acc[m];
+        if (n < NOUT) buf0[n] = acc[e][m];
     }
     eri_group_sync<TPQ>();
-    {
-        // index a: buf0[ca][rest] -> buf1[ma][rest]
-        constexpr int R0 = Cfg::NCB * Cfg::NCC * Cfg::NCD;
-        const double *C = C2S + C2S_OFF[LA];
-        for (int e = s; e < Cfg::SA * R0; e += TPQ) {
-            const int ma = e / R0, rest = e - ma * R0;
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCA; c++) v += C[ma * Cfg::NCA + c] * buf0[c * R0 + rest];
-            buf1[e] = v;
-        }
+    // four fibre transforms (c2s_fibres: a lane takes whole Cartesian fibres -- NC LDS reads, NS writes, compile-time sparse
+    // coefficients -- where every output element used to read its NC inputs and global coefficients), ping-pong between the buffers;
+    // an s index has nothing to transform: its constant factor is applied with the last pass
+    double *cur = buf0, *oth = buf1;
+    if constexpr (LA > 0) {  // [ca][rest] -> [ma][rest]
+        c2s_fibres<LA, 1, Cfg::NCB * Cfg::NCC * Cfg::NCD, TPQ>(cur, oth, s);
+        double *t_ = cur; cur = oth; oth = t_;
+        eri_group_sync<TPQ>();
     }
-    eri_group_sync<TPQ>();
-    {
-        // index b: buf1[ma][cb][rest] -> buf0[ma][mb][rest]
-        constexpr int R1 = Cfg::NCC * Cfg::NCD;
-        const double *C = C2S + C2S_OFF[LB];
-        for (int e = s; e < Cfg::SA * Cfg::SB * R1; e += TPQ) {
-            const int rest = e % R1, mb = (e / R1) % Cfg::SB, ma = e / (R1 * Cfg::SB);
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCB; c++) v += C[mb * Cfg::NCB + c] * buf1[(ma * Cfg::NCB + c) * R1 + rest];
-            buf0[e] = v;
-        }
+    if constexpr (LB > 0) {  // [ma][cb][rest] -> [ma][mb][rest]
+        c2s_fibres<LB, Cfg::SA, Cfg::NCC * Cfg::NCD, TPQ>(cur, oth, s);
+        double *t_ = cur; cur = oth; oth = t_;
+        eri_group_sync<TPQ>();
     }
-    eri_group_sync<TPQ>();
-    {
-        // index c: buf0[mab][cc][cd] -> buf1[mab][mc][cd]
-        const double *C = C2S + C2S_OFF[LC];
-        for (int e = s; e < Cfg::SA * Cfg::SB * Cfg::SC * Cfg::NCD; e += TPQ) {
-            const int cd = e % Cfg::NCD, mc = (e / Cfg::NCD) % Cfg::SC, mab = e / (Cfg::NCD * Cfg::SC);
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCC; c++) v += C[mc * Cfg::NCC + c] * buf0[(mab * Cfg::NCC + c) * Cfg::NCD + cd];
-            buf1[e] = v;
-        }
+    if constexpr (LC > 0) {  // [mab][cc][cd] -> [mab][mc][cd]
+        c2s_fibres<LC, Cfg::SA * Cfg::SB, Cfg::NCD, TPQ>(cur, oth, s);
+        double *t_ = cur; cur = oth; oth = t_;
+        eri_group_sync<TPQ>();
     }
-    eri_group_sync<TPQ>();
-    if (active) {
-        // index d and scatter: value (ma, mb, mc, md) -> all block-canonical images
-        const double *C = C2S + C2S_OFF[LD];
-        const int ai = sh.ao_off[ish], aj = sh.ao_off[jsh], ak = sh.ao_off[ksh], al = sh.ao_off[lsh];
-        for (int e = s; e < Cfg::SA * Cfg::SB * Cfg::SC * Cfg::SD; e += TPQ) {
-            const int md = e % Cfg::SD, mabc = e / Cfg::SD;
-            double v = 0;
-#pragma unroll
-            for (int c = 0; c < Cfg::NCD; c++) v += C[md * Cfg::NCD + c] * buf1[mabc * Cfg::NCD + c];
+    if constexpr (LD > 0) {  // [mabc][cd] -> [mabc][md]
+        c2s_fibres<LD, Cfg::SA * Cfg::SB * Cfg::SC, 1, TPQ>(cur, oth, s);
+        double *t_ = cur; cur = oth; oth = t_;
+        eri_group_sync<TPQ>();
+    }
+    if (act) {
+        // scatter: value (ma, mb, mc, md) -> all block-canonical images (md fastest over the lanes: runs of consecutive addresses)
+        constexpr double S0 = 0.28209479177387864;  // the l = 0 solid harmonic
+        constexpr double SCALE = (LA == 0 ? S0 : 1.0) * (LB == 0 ? S0 : 1.0) * (LC == 0 ? S0 : 1.0) * (LD == 0 ? S0 : 1.0);
+        for (int e_ = s; e_ < Cfg::SA * Cfg::SB * Cfg::SC * Cfg::SD; e_ += TPQ) {
+            const int md = e_ % Cfg::SD, mabc = e_ / Cfg::SD;
+            const double v = cur[e_] * SCALE;
             const int mc = mabc % Cfg::SC, mb = (mabc / Cfg::SC) % Cfg::SB, ma = mabc / (Cfg::SC * Cfg::SB);
             const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
             if constexpr (MODE == ERI_OUT_SCHWARZ) {
@@ -670,7 +852,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
             } else
             if (MODE == ERI_OUT_TILES) {
-                tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
+                if (!(og.dbg & 4) || v == 12345.678) tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
             } else if (MODE == ERI_OUT_3C) {
                 const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                 tiles[(io * og.nao + jo) * og.naux + kx] = v;
@@ -685,27 +867,28 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         // bra pair >= ket pair): the eight permutational images are covered by accumulating A_ab, A_cd (J = (A + A^T) / 2)
         // and B_ac, B_ad, B_bc, B_bd (K = B + B^T) with 1/2 per coincidence a == b, c == d, (ab) == (cd)
         eri_group_sync<TPQ>();
-        if (active) {
-            const double deg = (ish == jsh ? 0.5 : 1.0) * (ksh == lsh ? 0.5 : 1.0) * ((ish == ksh && jsh == lsh) ? 0.5 : 1.0);
-            const int ai = sh.ao_off[ish], aj = sh.ao_off[jsh], ak = sh.ao_off[ksh], al = sh.ao_off[lsh];
+        if (act) {
+            // (grouped: two members of one group are different shells -- the coincidences are those of the AO offsets)
+            const double deg = (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0);
             const size_t n = og.nao;
             const double *jk = reg + Cfg::REG0;
             constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
                           OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
             const int nend = og.kacc ? Cfg::NJK : OK1;
-            for (int e = s; e < nend; e += TPQ) {
+            for (int e_ = s; e_ < nend; e_ += TPQ) {
                 double *dst;
                 double f = deg;
-                if (e < OJ2) { dst = og.jacc + (size_t)(ai + e / Cfg::SB) * n + aj + e % Cfg::SB; f *= 4.0; }
-                else if (e < OK1) { const int x = e - OJ2; dst = og.jacc + (size_t)(ak + x / Cfg::SD) * n + al + x % Cfg::SD; f *= 4.0; }
-                else if (e < OK2) { const int x = e - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
-                else if (e < OK3) { const int x = e - OK2; dst = og.kacc + (size_t)(ai + x / Cfg::SD) * n + al + x % Cfg::SD; }
-                else if (e < OK4) { const int x = e - OK3; dst = og.kacc + (size_t)(aj + x / Cfg::SC) * n + ak + x % Cfg::SC; }
-                else { const int x = e - OK4; dst = og.kacc + (size_t)(aj + x / Cfg::SD) * n + al + x % Cfg::SD; }
-                atomicAdd(dst, f * jk[e]);
+                if (e_ < OJ2) { dst = og.jacc + (size_t)(ai + e_ / Cfg::SB) * n + aj + e_ % Cfg::SB; f *= 4.0; }
+                else if (e_ < OK1) { const int x = e_ - OJ2; dst = og.jacc + (size_t)(ak + x / Cfg::SD) * n + al + x % Cfg::SD; f *= 4.0; }
+                else if (e_ < OK2) { const int x = e_ - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
+                else if (e_ < OK3) { const int x = e_ - OK2; dst = og.kacc + (size_t)(ai + x / Cfg::SD) * n + al + x % Cfg::SD; }
+                else if (e_ < OK4) { const int x = e_ - OK3; dst = og.kacc + (size_t)(aj + x / Cfg::SC) * n + ak + x % Cfg::SC; }
+                else { const int x = e_ - OK4; dst = og.kacc + (size_t)(aj + x / Cfg::SD) * n + al + x % Cfg::SD; }
+                atomicAdd(dst, f * jk[e_]);
             }
         }
     }
+    }  // member combinations
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -714,6 +897,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 struct HostPairs {
     std::vector<int> sh, pp_off;
     std::vector<double> pp;
+    int stride = 5;  // doubles per primitive pair (PP_STRIDE_G for a grouped basis)
     int cls_start[48], cls_count[48];  // class c(la,lb) = la(la+1)/2+lb  (grad.hip: la*8+lb... see there)
 };
 
@@ -736,6 +920,10 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
     struct P { int a, b, cls, npp; std::vector<double> pp; };
     std::vector<P> all;
     all.reserve((size_t)(s1 - s0) * (s1 - s0 + 1) / 2);
+    // grouped view (Basis::grouped): PP_STRIDE_G doubles per primitive pair -- four coefficient slots 2 xa + xb over the members
+    // of the two groups (only s groups have a second member); otherwise five doubles, one coefficient
+    const bool grp = b.grouped();
+    const int stride = grp ? PP_STRIDE_G : 5;
     for (int i = s0; i < s1; i++)
         for (int j = (unit >= 0 ? unit : s0); j <= (unit >= 0 ? unit : i); j++) {
             int a = i, c = j;
@@ -751,12 +939,27 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
                     const double arg = ea * eb / p * ab2;
                     if (arg > 100.0) continue;  // exp(-100) ~ 4e-44: numerically zero contribution
                     const double K = std::exp(-arg);
-                    if (prim_pair_negligible(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K / p, ab2, A.l + B.l)) continue;
+                    const double ca0 = b.coefs[A.prim_off + ip], cb0 = b.coefs[B.prim_off + jp];
+                    double cf[4] = {ca0 * cb0 * K / p, 0.0, 0.0, 0.0};  // c_a c_b K_ab / p
+                    if (grp) {
+                        const double ca1 = b.coefs1[A.prim_off + ip], cb1 = b.coefs1[B.prim_off + jp];
+                        cf[1] = ca0 * cb1 * K / p;
+                        cf[2] = ca1 * cb0 * K / p;
+                        cf[3] = ca1 * cb1 * K / p;
+                    }
+                    const double cmax = std::max(std::max(std::fabs(cf[0]), std::fabs(cf[1])), std::max(std::fabs(cf[2]), std::fabs(cf[3])));
+                    if (prim_pair_negligible(cmax, ab2, A.l + B.l)) continue;
                     pr.pp.push_back(p);
                     for (int d = 0; d < 3; d++) pr.pp.push_back((ea * A.r[d] + eb * B.r[d]) / p);
-                    pr.pp.push_back(b.coefs[A.prim_off + ip] * b.coefs[B.prim_off + jp] * K / p);  // c_a c_b K_ab / p
+                    pr.pp.push_back(cf[0]);
+                    if (grp) {
+                        // slots of an (l > 0, s) pair: xb alone (the s group is the SECOND one: slot 2 xa + xb with xa = 0)
+                        pr.pp.push_back(cf[1]);
+                        pr.pp.push_back(cf[2]);
+                        pr.pp.push_back(cf[3]);
+                    }
                 }
-            pr.npp = (int)pr.pp.size() / 5;
+            pr.npp = (int)pr.pp.size() / stride;
             all.push_back(std::move(pr));
         }
     std::stable_sort(all.begin(), all.end(), [](const P &x, const P &y) {
@@ -772,8 +975,9 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
         hp.sh.push_back(pr.a);
         hp.sh.push_back(pr.b);
         hp.pp.insert(hp.pp.end(), pr.pp.begin(), pr.pp.end());
-        hp.pp_off.push_back((int)hp.pp.size() / 5);
+        hp.pp_off.push_back((int)hp.pp.size() / stride);
     }
+    hp.stride = stride;
 }
 
 }  // namespace dqc

@@ -128,6 +128,39 @@ int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, co
     return 0;
 }
 
+void group_s_shells(const Basis &b, Basis &g) {
+    g = Basis();
+    g.nao = b.nao;
+    g.natm = b.natm;
+    g.atom_xyz = b.atom_xyz;
+    g.atom_z = b.atom_z;
+    for (const HostShell &h : b.shells) {
+        int hit = -1;
+        if (h.l == 0)
+            for (size_t k = 0; k < g.shells.size() && hit < 0; k++) {
+                const HostShell &o = g.shells[k];
+                if (o.l != 0 || o.atom != h.atom || o.nprim != h.nprim || g.ao_off1[k] >= 0) continue;
+                bool same = true;
+                for (int p = 0; p < h.nprim && same; p++) same = g.exps[o.prim_off + p] == b.exps[h.prim_off + p];
+                if (same) hit = (int)k;
+            }
+        if (hit >= 0) {
+            g.ao_off1[hit] = h.ao_off;
+            for (int p = 0; p < h.nprim; p++) g.coefs1[g.shells[hit].prim_off + p] = b.coefs[h.prim_off + p];
+            continue;
+        }
+        HostShell n = h;
+        n.prim_off = (int)g.exps.size();
+        for (int p = 0; p < h.nprim; p++) {
+            g.exps.push_back(b.exps[h.prim_off + p]);
+            g.coefs.push_back(b.coefs[h.prim_off + p]);
+            g.coefs1.push_back(0.0);
+        }
+        g.shells.push_back(n);
+        g.ao_off1.push_back(-1);
+    }
+}
+
 int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st) {
     int n = (int)b.shells.size();
     std::vector<int> l(n), np(n), ao(n), po(n);
@@ -144,6 +177,7 @@ int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st) {
     if ((rc = pool.upload(&d.xyz, xyz, st))) return rc;
     if ((rc = pool.upload(&d.exps, b.exps, st))) return rc;
     if ((rc = pool.upload(&d.coefs, b.coefs, st))) return rc;
+    if (b.grouped() && (rc = pool.upload(&d.ao_off1, b.ao_off1, st))) return rc;
     d.nsh = n;
     return 0;
 }

@@ -602,6 +602,101 @@ void orc_int2e_s4(double *out, const int *atm, int natm, const int *bas, int nba
     free(pps); free(hb); free(npp); free(ao_loc);
 }
 
+/* Packed s8 ERI for bases whose s4 matrix does not fit the host (naphthalene / cc-pVTZ: 58 GB as s4, 29 GB here):
+ * out[P (P + 1) / 2 + Q] = (ij|kl), P = i(i+1)/2+j >= Q = k(k+1)/2+l over AO pairs -- the lower triangle of the matrix
+ * orc_int2e_s4 produces, the same numbers (eri_quartet), no screening. */
+void orc_int2e_s8(double *out, const int *atm, int natm, const int *bas, int nbas, const double *env)
+{
+    (void)natm;
+    init_herm();
+    int *ao_loc = (int *)malloc(sizeof(int) * (nbas + 1));
+    make_ao_loc(nbas, bas, ao_loc);
+    int nshp = nbas * (nbas + 1) / 2;
+    PrimPair **pps = (PrimPair **)calloc(nshp, sizeof(PrimPair *));
+    double **hb = (double **)calloc(nshp, sizeof(double *));
+    int *npp = (int *)calloc(nshp, sizeof(int));
+#pragma omp parallel for schedule(dynamic)
+    for (int ij = 0; ij < nshp; ij++) {
+        int i = (int)((sqrt(8.0 * ij + 1) - 1) / 2);
+        while (i * (i + 1) / 2 > ij) i--;
+        while ((i + 1) * (i + 2) / 2 <= ij) i++;
+        int j = ij - i * (i + 1) / 2;
+        Shell A = get_shell(i, atm, bas, env), B = get_shell(j, atm, bas, env);
+        int np = A.nprim * B.nprim;
+        size_t sz = (size_t)np * NCART(A.l) * NCART(B.l) * NHERM(A.l + B.l);
+        pps[ij] = (PrimPair *)malloc(sizeof(PrimPair) * np);
+        hb[ij] = (double *)malloc(sizeof(double) * sz);
+        npp[ij] = np;
+        build_prim_pairs(A, B, pps[ij], hb[ij]);
+    }
+#pragma omp parallel
+    {
+        size_t wsz = (size_t)MAXCART * MAXCART * MAXCART * MAXCART;
+        double *work = (double *)malloc(sizeof(double) * (2 * wsz + (size_t)MAXHERM * MAXCART * MAXCART));
+        double *sph = (double *)malloc(sizeof(double) * wsz);
+#pragma omp for schedule(dynamic)
+        for (int ij = nshp - 1; ij >= 0; ij--) {
+            int i = (int)((sqrt(8.0 * ij + 1) - 1) / 2);
+            while (i * (i + 1) / 2 > ij) i--;
+            while ((i + 1) * (i + 2) / 2 <= ij) i++;
+            int j = ij - i * (i + 1) / 2;
+            Shell A = get_shell(i, atm, bas, env), B = get_shell(j, atm, bas, env);
+            int sa = 2 * A.l + 1, sb = 2 * B.l + 1;
+            for (int kl = 0; kl <= ij; kl++) {
+                int k = (int)((sqrt(8.0 * kl + 1) - 1) / 2);
+                while (k * (k + 1) / 2 > kl) k--;
+                while ((k + 1) * (k + 2) / 2 <= kl) k++;
+                int l = kl - k * (k + 1) / 2;
+                Shell C = get_shell(k, atm, bas, env), D = get_shell(l, atm, bas, env);
+                int sc = 2 * C.l + 1, sd = 2 * D.l + 1;
+                eri_quartet(A, B, C, D, pps[ij], npp[ij], pps[kl], npp[kl], sph, work);
+                for (int a = 0; a < sa; a++)
+                    for (int b = 0; b < sb; b++) {
+                        size_t ia = ao_loc[i] + a, ib = ao_loc[j] + b;
+                        if (ib > ia) continue;
+                        size_t pij = ia * (ia + 1) / 2 + ib;
+                        for (int c = 0; c < sc; c++)
+                            for (int d = 0; d < sd; d++) {
+                                size_t ic = ao_loc[k] + c, id = ao_loc[l] + d;
+                                if (id > ic) continue;
+                                size_t pkl = ic * (ic + 1) / 2 + id;
+                                size_t hi = pij > pkl ? pij : pkl, lo = pij > pkl ? pkl : pij;
+                                out[hi * (hi + 1) / 2 + lo] = sph[((a * sb + b) * sc + c) * sd + d];
+                            }
+                    }
+            }
+        }
+        free(work); free(sph);
+    }
+    for (int ij = 0; ij < nshp; ij++) { free(pps[ij]); free(hb[ij]); }
+    free(pps); free(hb); free(npp); free(ao_loc);
+}
+
+/* y = M x for the symmetric matrix held as the packed lower triangle above (the J contraction of the s8 store:
+ * x = packed density with doubled off-diagonals, y = packed J; hcgto.py:204-214 on the packed form) */
+void orc_symv_s8(double *y, const double *packed, const double *x, long long npair)
+{
+    for (long long p = 0; p < npair; p++) y[p] = 0.0;
+#pragma omp parallel
+    {
+        double *acc = (double *)calloc((size_t)npair, sizeof(double));
+#pragma omp for schedule(dynamic, 64)
+        for (long long hi = 0; hi < npair; hi++) {
+            const double *row = packed + (size_t)hi * (hi + 1) / 2;
+            const double xh = x[hi];
+            double s = 0.0;
+            for (long long lo = 0; lo < hi; lo++) {
+                s += row[lo] * x[lo];
+                acc[lo] += row[lo] * xh;
+            }
+            acc[hi] += s + row[hi] * xh;
+        }
+#pragma omp critical
+        for (long long p = 0; p < npair; p++) y[p] += acc[p];
+        free(acc);
+    }
+}
+
 /* Listed shell quartets (test infrastructure for bases whose packed matrix does not fit the host: naphthalene /
  * cc-pVTZ is 58 GB packed).  quartets: (nq, 4) shell indices (i, j, k, l); the spherical block
  * [sa][sb][sc][sd] of quartet q is written row-major at out + offs[q] -- the same numbers orc_int2e_s4 scatters. */

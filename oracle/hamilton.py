@@ -98,6 +98,8 @@ class Hamilton:
             el = torch.einsum("mnkl,kp->mnpl", el, X)
             el = torch.einsum("mnpl,lq->mnpq", el, X)
             self.el_mat = el.contiguous()
+        elif self.eri_mode == "s8":  # packed lower triangle of the s4 matrix (bases whose s4 matrix does not fit the host)
+            self.el_s8 = natives.int2e_s8(t)
         else:
             self.el_s4 = torch.as_tensor(natives.int2e_s4(t))
         return self
@@ -135,7 +137,7 @@ class Hamilton:
         else:  # packed-s4 variant (same numbers, different storage)
             dao = self.unconvert_dm(dm)
             d, iu = self._pack_dm(dao)
-            jp = self.el_s4 @ d
+            jp = torch.as_tensor(natives.symv_s8(self.el_s8, d.numpy())) if self.eri_mode == "s8" else self.el_s4 @ d
             n = dao.shape[0]
             J = torch.zeros((n, n), dtype=dm.dtype)
             J[iu[0], iu[1]] = jp

@@ -62,6 +62,22 @@ def int2e_s4(t):
     return out
 
 
+def int2e_s8(t):
+    """packed lower triangle of the s4 matrix: out[P (P + 1) / 2 + Q], P >= Q AO-pair indices (29 GB for nao 412)"""
+    npair = t.nao * (t.nao + 1) // 2
+    out = np.zeros(npair * (npair + 1) // 2)
+    lib().orc_int2e_s8(_p(out), *_tab(t))
+    return out
+
+
+def symv_s8(packed, x):
+    """y = M x with M the symmetric matrix held as the packed lower triangle of int2e_s8"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros_like(x)
+    lib().orc_symv_s8(_p(y), _p(packed), _p(x), ctypes.c_longlong(x.size))
+    return y
+
+
 def fills4(packed, nao):
     out = np.empty((nao, nao, nao, nao))
     lib().orc_fills4(_p(out), _p(np.ascontiguousarray(packed)), ctypes.c_int(nao))
