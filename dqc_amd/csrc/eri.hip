@@ -58,21 +58,10 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
 // ---------------------------------------------------------------------------------------------
 // class dispatch
 // ---------------------------------------------------------------------------------------------
-// depth bins of every pair class (the pairs of a class are sorted by primitive-pair count, descending: bins are ranges), host
-// and device copies, and the pool the per-launch wave maps are uploaded through
+// the pool the per-launch wave tables of a fill are uploaded through
 struct WaveMaps {
-    std::vector<int> bins;  // (NCLS, SCREEN_NBIN + 1) bin starts relative to the class start
-    const int *d_bins = nullptr;
     DevPool *pool = nullptr;
 };
-static void wave_map_bins(const HostPairs &hp, int ncls, std::vector<int> &bins) {
-    bins.assign((size_t)ncls * (SCREEN_NBIN + 1), 0);
-    for (int c = 0; c < ncls; c++) {
-        int *bs = bins.data() + (size_t)c * (SCREEN_NBIN + 1);
-        for (int i = 0; i < hp.cls_count[c]; i++) bs[screen_bin(hp.pp_off[hp.cls_start[c] + i + 1] - hp.pp_off[hp.cls_start[c] + i]) + 1]++;
-        for (int k = 0; k < SCREEN_NBIN; k++) bs[k + 1] += bs[k];
-    }
-}
 
 template <int LA, int LB, int LC, int LD>
 static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st,
@@ -88,27 +77,30 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
     constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
     auto kern = dp.stride == PP_STRIDE_G ? eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-    if (Cfg::TPQ <= 16 && wm != nullptr) {
-        // lane groups of <= 16 lanes: depth-binned wave map (eri_core.hpp: eri_split_lanes) -- per (ket pair, bra depth bin) the
-        // waves that cover the bin's bra pairs (>= the ket pair in a diagonal class) with PS lane groups per quartet
-        std::vector<int2> wtab;
-        const int *bb = wm->bins.data() + (size_t)cb * (SCREEN_NBIN + 1);
-        for (int ik = 0; ik < nk; ik++) {
-            const int nkp = hp.pp_off[hp.cls_start[ck] + ik + 1] - hp.pp_off[hp.cls_start[ck] + ik];
-            for (int bin = 0; bin < SCREEN_NBIN; bin++) {
-                const int bs = (same && ik > bb[bin]) ? ik : bb[bin];
-                const int per = 64 / (eri_split_lanes(bin, nkp, Cfg::TPQ) * Cfg::TPQ);
-                for (int b1 = bs; b1 < bb[bin + 1]; b1 += per) wtab.push_back(make_int2(ik * 8 + bin, b1));
-            }
-        }
-        static_assert(SCREEN_NBIN == 8, "wave table packs the bin into three bits");
-        const long long nwave = (long long)wtab.size();
-        if (nwave == 0) return 0;
-        int2 *d_wtab = nullptr;
-        if (wm->pool->upload(&d_wtab, wtab, st)) { set_error("dqc_eri_fill_tiles: device upload failed"); return DQC_ENOMEM; }
+    // lane groups of <= 16 lanes: depth-binned wave map (eri_core.hpp: eri_split_lanes, eri_wave_table) -- where the class pair has
+    // contractions deep enough to be split at all (pairs are sorted by depth: the first pair of a class is its deepest); the
+    // single-primitive classes of a cc-pVTZ fill are 1-2 % faster under the flat map
+    const int dmax = (hp.pp_off[hp.cls_start[cb] + 1] - hp.pp_off[hp.cls_start[cb]]) * (hp.pp_off[hp.cls_start[ck] + 1] - hp.pp_off[hp.cls_start[ck]]);
+    if (Cfg::TPQ <= 16 && wm != nullptr && dmax > 16) {
         EriOut o2 = og;
-        o2.wtab = d_wtab;
-        o2.wbin = wm->d_bins + (size_t)cb * (SCREEN_NBIN + 1);
+        long long nwave;
+        if (same) {  // diagonal class (bra pair >= ket pair): one table entry per wave
+            std::vector<int2> wtab;
+            eri_wave_table(wtab, o2.wbin, hp, hp.cls_start[cb], nb, hp, hp.cls_start[ck], nk, true, Cfg::TPQ);
+            nwave = (long long)wtab.size();
+            if (nwave == 0) return 0;
+            int2 *d_wtab = nullptr;
+            if (wm->pool->upload(&d_wtab, wtab, st)) { set_error("dqc_eri_fill_tiles: device upload failed"); return DQC_ENOMEM; }
+            o2.wtab = d_wtab;
+        } else {     // runs of ket pairs of equal depth
+            std::vector<WaveRun> runs;
+            nwave = eri_wave_runs(runs, o2.wbin, hp, hp.cls_start[cb], nb, hp, hp.cls_start[ck], nk, Cfg::TPQ);
+            if (nwave == 0) return 0;
+            WaveRun *d_runs = nullptr;
+            if (wm->pool->upload(&d_runs, runs, st)) { set_error("dqc_eri_fill_tiles: device upload failed"); return DQC_ENOMEM; }
+            o2.wruns = d_runs;
+            o2.nruns = (int)runs.size();
+        }
         hipLaunchKernelGGL(kern, dim3((unsigned)((nwave + 3) / 4)), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp, dp, hp.cls_start[cb], nb,
                            hp.cls_start[ck], nk, same, nwave, o2);
         DQC_CHECK_LAUNCH();
@@ -663,13 +655,7 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     // depth-binned wave maps of the one-lane classes (DQC_ERI_WMAP=0: the plain wave-transposed map, A/B runs)
     static const bool wmap_env = [] { const char *e = getenv("DQC_ERI_WMAP"); return !(e && e[0] == '0'); }();
     WaveMaps wm;
-    if (wmap_env) {
-        wave_map_bins(hp, NCLS, wm.bins);
-        int *d_bins = nullptr;
-        if ((rc = pool.upload(&d_bins, wm.bins, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
-        wm.d_bins = d_bins;
-        wm.pool = &pool;
-    }
+    wm.pool = &pool;
     rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og, wmap_env ? &wm : nullptr);
     if (rc) return rc;
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;

@@ -203,6 +203,15 @@ inline long long eri_num_blocks(int nb, int nk, long long ntask) {
     return (ntask + Cfg::QPB - 1) / Cfg::QPB;
 }
 
+// a run of consecutive ket pairs with the same primitive-pair count under the depth-binned wave map of an off-diagonal class
+// launch: every ket pair of the run owns W waves, cum[bin] of them in front of the bra depth bin `bin` (eri_wave_runs)
+struct WaveRun {
+    long long off;  // first wave of the run
+    int k0, W;      // first ket pair (relative to the class start), waves per ket pair
+    int cum[9];     // prefix of the waves per bra depth bin inside one ket pair's W
+    int pad_;
+};
+
 struct EriOut {
     int nao;      // orbital AOs (3C: leading dimensions)
     int naux;     // auxiliary AOs (3C / 2C: fastest dimension)
@@ -243,8 +252,12 @@ struct EriOut {
     int nsh = 0;
     // ---- depth-binned wave map of the one-lane-per-quartet classes (fill; see eri_split_lanes): wtab = per wave (8 ket pair +
     //      bra depth bin, first bra pair of the wave), wbin = the bra class's bin starts
+    //      Off-diagonal class launches describe the same map by RUNS of ket pairs with equal primitive-pair count (wruns, nruns:
+    //      a few dozen entries instead of one per wave -- the gradient's ordered pair lists made per-wave tables of 40 MB)
     const int2 *wtab = nullptr;
-    const int *wbin = nullptr;
+    const WaveRun *wruns = nullptr;
+    int nruns = 0;
+    int wbin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int dbg = 0;  // timing experiments (DQC_ERI_DBG): 1 = skip the primitive loops, 2 = skip the output phase, 4 = skip the tile stores only
     // ---- one molecule sharded over GPUs (dqc_direct_jk_part): this launch is part `part` of `nparts` interleaved block sets
     int part = 0, nparts = 1;
@@ -266,7 +279,9 @@ __host__ __device__ constexpr int screen_bin(int npp) {
 // (of TPQ lanes each, every group with its own LDS region), the partial sums combined by a butterfly of shuffles, and the member
 // combinations of the output phase dealt to the same groups.  PS is uniform per wave: a wave takes ONE ket pair and
 // 64 / (PS TPQ) bra pairs of ONE depth bin (pairs are sorted by depth inside a class), so it follows from the bin's bound and
-// the ket pair's primitive count: ~8 primitive quartets per lane group.
+// the ket pair's primitive count: ~8 primitive quartets per lane group.  (Measured the other way round -- bra pair uniform, ket
+// pairs over the lanes, so that a wave writes one row range of the store: C5 fill 8.4 -> 8.9 ms, gradient 0.16 -> 0.22 s.
+// The gradient's class launches keep the flat task map: under this map they run 0.16 s against 0.11 s.)
 __host__ __device__ constexpr int screen_bin_bound(int bin) {  // largest primitive-pair count of the bin (bin 0: open, 128 stands in)
     return bin == 0 ? 128 : (128 >> bin);
 }
@@ -406,9 +421,30 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             ik = og.pbin[e % SCREEN_NBIN] + (int)(task - og.toff[e]);
         }
     } else
+    if (TPQ <= 16 && og.wruns != nullptr) {
+        // depth-binned wave map by runs (off-diagonal classes): wave -> run of ket pairs (scan), ket pair, bra depth bin (scan), chunk
+        const long long wv = bidx * 4 + (tid >> 6);
+        const bool inr = wv < ntask;
+        const long long w2 = inr ? wv : ntask - 1;
+        int r = 0;
+        for (int t = 1; t < og.nruns; t++) r = og.wruns[t].off <= w2 ? t : r;
+        const WaveRun &wr = og.wruns[r];
+        const int rel = (int)(w2 - wr.off), ikl = wr.k0 + rel / wr.W, rem = rel % wr.W;
+        int bin = 0;
+#pragma unroll
+        for (int t = 1; t < SCREEN_NBIN; t++) bin = wr.cum[t] <= rem ? t : bin;
+        const int nkp_ = prk.pp_off[k0 + ikl + 1] - prk.pp_off[k0 + ikl];
+        psl = eri_split_lanes(bin, nkp_, TPQ);
+        const int grp = (tid & 63) / TPQ;
+        const int ibl = og.wbin[bin] + (rem - wr.cum[bin]) * (64 / (psl * TPQ)) + grp / psl;
+        psj = grp % psl;
+        active = inr && ibl < og.wbin[bin + 1];
+        ib = ibl < nb ? ibl : nb - 1;
+        ik = ikl;
+    } else
     if (TPQ <= 16 && og.wtab != nullptr) {
-        // depth-binned wave map: the host's table names every wave's (ket pair, bra depth bin) and first bra pair -- PS lane groups
-        // per quartet, 64 / (PS TPQ) bra pairs per wave (a bisection over prefix offsets here cost 9 us of dependent loads per wave)
+        // depth-binned wave map, one table entry per wave (diagonal classes: bra pair >= ket pair): (8 ket pair + bra depth bin,
+        // first bra pair of the wave) -- PS lane groups per quartet, 64 / (PS TPQ) bra pairs per wave
         const long long wv = bidx * 4 + (tid >> 6);
         const bool inr = wv < ntask;
         const int2 we = og.wtab[inr ? wv : ntask - 1];
@@ -700,7 +736,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 #pragma unroll
         for (int m = 0; m < NPT; m++) {
             const int n = s + TPQ * m;
-            if (n < NOUT && active) {
+            // (lane groups that shared the quartet's primitive quartets hold the same totals: they split the outputs)
+            if (n < NOUT && active && (m & (psl - 1)) == psj) {
                 const int cd = n % Cfg::NCD, cc = (n / Cfg::NCD) % Cfg::NCC, cb = (n / (Cfg::NCD * Cfg::NCC)) % Cfg::NCB,
                           cu = n / (Cfg::NCD * Cfg::NCC * Cfg::NCB);
                 int u[3];
@@ -978,6 +1015,57 @@ static void build_pairs(const Basis &b, HostPairs &hp, int s0 = 0, int s1 = -1, 
         hp.pp_off.push_back((int)hp.pp.size() / stride);
     }
     hp.stride = stride;
+}
+
+// depth-binned wave table of one DIAGONAL class launch (eri_split_lanes; kernel branch og.wtab): per (ket pair, bra depth bin) the
+// waves that cover the bin's bra pairs (>= the ket pair) with PS lane groups per quartet.  The pairs of a class are sorted by
+// primitive-pair count, descending, so the bins are ranges: wbin = the starts of the BRA class's bins relative to the class start
+static_assert(SCREEN_NBIN == 8, "wave table packs the bin into three bits");
+static void eri_wave_bins(int wbin[SCREEN_NBIN + 1], const HostPairs &hb, int b0, int nb) {
+    for (int k = 0; k <= SCREEN_NBIN; k++) wbin[k] = 0;
+    for (int i = 0; i < nb; i++) wbin[screen_bin(hb.pp_off[b0 + i + 1] - hb.pp_off[b0 + i]) + 1]++;
+    for (int k = 0; k < SCREEN_NBIN; k++) wbin[k + 1] += wbin[k];
+}
+static void eri_wave_table(std::vector<int2> &wtab, int wbin[SCREEN_NBIN + 1], const HostPairs &hb, int b0, int nb, const HostPairs &hk,
+                           int k0, int nk, bool same, int tpq) {
+    eri_wave_bins(wbin, hb, b0, nb);
+    wtab.clear();
+    for (int ik = 0; ik < nk; ik++) {
+        const int nkp = hk.pp_off[k0 + ik + 1] - hk.pp_off[k0 + ik];
+        for (int bin = 0; bin < SCREEN_NBIN; bin++) {
+            const int bs = (same && ik > wbin[bin]) ? ik : wbin[bin];
+            const int per = 64 / (eri_split_lanes(bin, nkp, tpq) * tpq);
+            for (int b1 = bs; b1 < wbin[bin + 1]; b1 += per) wtab.push_back(make_int2(ik * 8 + bin, b1));
+        }
+    }
+}
+
+// the same map for an OFF-DIAGONAL class launch as runs of ket pairs with equal primitive-pair count (the pairs of a class are
+// sorted by that count): returns the number of waves
+static long long eri_wave_runs(std::vector<WaveRun> &runs, int wbin[SCREEN_NBIN + 1], const HostPairs &hb, int b0, int nb,
+                               const HostPairs &hk, int k0, int nk, int tpq) {
+    eri_wave_bins(wbin, hb, b0, nb);
+    runs.clear();
+    long long nwave = 0;
+    int prev = -1;
+    for (int ik = 0; ik < nk; ik++) {
+        const int nkp = hk.pp_off[k0 + ik + 1] - hk.pp_off[k0 + ik];
+        if (nkp != prev) {
+            WaveRun r;
+            r.off = nwave; r.k0 = ik; r.pad_ = 0;
+            r.cum[0] = 0;
+            for (int bin = 0; bin < SCREEN_NBIN; bin++) {
+                const int per = 64 / (eri_split_lanes(bin, nkp, tpq) * tpq), cnt = wbin[bin + 1] - wbin[bin];
+                r.cum[bin + 1] = r.cum[bin] + (cnt + per - 1) / per;
+            }
+            r.W = r.cum[SCREEN_NBIN];
+            if (r.W == 0) r.W = 1;  // (no bra pairs: never launched)
+            runs.push_back(r);
+            prev = nkp;
+        }
+        nwave += runs.back().W;
+    }
+    return nb > 0 ? nwave : 0;
 }
 
 }  // namespace dqc

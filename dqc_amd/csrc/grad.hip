@@ -88,6 +88,7 @@ struct GradCtx {
     DevPairs dbra, dket;
     const HostPairs *hbra, *hket;
     EriOut og;
+    DevPool *pool = nullptr;  // stream-ordered pool for the wave tables (nullptr: flat task maps)
 };
 
 template <int LA, int LB, int LC, int LD>
@@ -100,6 +101,22 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_G);
+    if (Cfg::TPQ <= 16 && c.pool != nullptr) {
+        // depth-binned wave map (eri_core.hpp: eri_split_lanes, eri_wave_table): the deep (companion, s) x (s, s) contractions were
+        // serial chains in single lane groups
+        std::vector<WaveRun> runs;
+        EriOut o2 = c.og;
+        const long long nwave = eri_wave_runs(runs, o2.wbin, *c.hbra, c.hbra->cls_start[cb], nb, *c.hket, c.hket->cls_start[ck], nk, Cfg::TPQ);
+        if (nwave == 0) return 0;
+        WaveRun *d_runs = nullptr;
+        if (c.pool->upload(&d_runs, runs, st)) { set_error("dqc_eri_grad: device upload failed"); return DQC_ENOMEM; }
+        o2.wruns = d_runs;
+        o2.nruns = (int)runs.size();
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nwave + 3) / 4)), dim3(256), Cfg::LDS_BYTES_G, st, (double *)nullptr, c.ds, c.dbra, c.dket,
+                           c.hbra->cls_start[cb], nb, c.hket->cls_start[ck], nk, 0, nwave, o2);
+        DQC_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_G, st, (double *)nullptr, c.ds, c.dbra, c.dket,
                        c.hbra->cls_start[cb], nb, c.hket->cls_start[ck], nk, 0, ntask, c.og);
     DQC_CHECK_LAUNCH();
@@ -374,6 +391,11 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     if ((rc = boys_table_ensure())) return rc;
     DevPool pool;
     GradCtx c;
+    // the depth-binned wave map of the fill (eri_core.hpp) is OFF here by default: measured 0.16 s against 0.11 s for the flat
+    // task maps on a 20-atom cc-pVDZ gradient (DQC_GRAD_WMAP=1 turns it on for A/B runs)
+    DevPool wpool(st);
+    static const bool wmap_env = [] { const char *e = getenv("DQC_GRAD_WMAP"); return e && e[0] == '1'; }();
+    if (wmap_env) c.pool = &wpool;
     if ((rc = upload_shells(c.ds, b, pool, st))) { set_error("dqc_eri_grad: device upload failed"); return rc; }
     auto up = [&](HostPairs &hp, DevPairs &dp) {
         int *d_sh = nullptr, *d_off = nullptr;
