@@ -63,30 +63,44 @@ struct WaveMaps {
     DevPool *pool = nullptr;
 };
 
+// One class launch of the fill.  Bra and ket pairs come from their own tables: the same one (a whole-store fill: diagonal classes
+// keep bra pair >= ket pair) or, for a slice of a store spread over several GPUs (dqc_eri_fill_tiles_part), the pairs whose block
+// pairs lie inside / below the slice's rows -- then every (bra, ket) combination of the two lists is wanted (pairing FILL_CROSS)
+// and the diagonal classes of the second cross launch are left out (FILL_CROSS_OFFDIAG: the first one covered them)
+enum { FILL_SAME_TABLE = 0, FILL_CROSS = 1, FILL_CROSS_OFFDIAG = 2 };
+struct FillTables {
+    const DevPairs *dpb, *dpk;
+    const HostPairs *hpb, *hpk;
+    int pairing;
+};
+
 template <int LA, int LB, int LC, int LD>
-static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st,
-                        const EriOut &og, const WaveMaps *wm = nullptr) {
+static int launch_class(double *tiles, const DevShells &ds, const FillTables &ft, hipStream_t st, const EriOut &og,
+                        const WaveMaps *wm = nullptr) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
-    const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
+    const HostPairs &hpb = *ft.hpb, &hpk = *ft.hpk;
+    const DevPairs &dpb = *ft.dpb, &dpk = *ft.dpk;
+    const int nb = hpb.cls_count[cb], nk = hpk.cls_count[ck];
     if (nb == 0 || nk == 0 || hl_forced()) return 0;
-    const int same = cb == ck;
+    if (ft.pairing == FILL_CROSS_OFFDIAG && cb == ck) return 0;
+    const int same = (cb == ck && ft.pairing == FILL_SAME_TABLE) ? 1 : 0;
     const long long ntask = same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     // grouped tables (general contractions merged: eri_core.hpp): the instantiation with the coefficient slots of the two pair classes
     constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
-    auto kern = dp.stride == PP_STRIDE_G ? eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>;
+    auto kern = dpb.stride == PP_STRIDE_G ? eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     // lane groups of <= 16 lanes: depth-binned wave map (eri_core.hpp: eri_split_lanes, eri_wave_table) -- where the class pair has
     // contractions deep enough to be split at all (pairs are sorted by depth: the first pair of a class is its deepest); the
     // single-primitive classes of a cc-pVTZ fill are 1-2 % faster under the flat map
-    const int dmax = (hp.pp_off[hp.cls_start[cb] + 1] - hp.pp_off[hp.cls_start[cb]]) * (hp.pp_off[hp.cls_start[ck] + 1] - hp.pp_off[hp.cls_start[ck]]);
+    const int dmax = (hpb.pp_off[hpb.cls_start[cb] + 1] - hpb.pp_off[hpb.cls_start[cb]]) * (hpk.pp_off[hpk.cls_start[ck] + 1] - hpk.pp_off[hpk.cls_start[ck]]);
     if (Cfg::TPQ <= 16 && wm != nullptr && dmax > 16) {
         EriOut o2 = og;
         long long nwave;
         if (same) {  // diagonal class (bra pair >= ket pair): one table entry per wave
             std::vector<int2> wtab;
-            eri_wave_table(wtab, o2.wbin, hp, hp.cls_start[cb], nb, hp, hp.cls_start[ck], nk, true, Cfg::TPQ);
+            eri_wave_table(wtab, o2.wbin, hpb, hpb.cls_start[cb], nb, hpk, hpk.cls_start[ck], nk, true, Cfg::TPQ);
             nwave = (long long)wtab.size();
             if (nwave == 0) return 0;
             int2 *d_wtab = nullptr;
@@ -94,20 +108,20 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
             o2.wtab = d_wtab;
         } else {     // runs of ket pairs of equal depth
             std::vector<WaveRun> runs;
-            nwave = eri_wave_runs(runs, o2.wbin, hp, hp.cls_start[cb], nb, hp, hp.cls_start[ck], nk, Cfg::TPQ);
+            nwave = eri_wave_runs(runs, o2.wbin, hpb, hpb.cls_start[cb], nb, hpk, hpk.cls_start[ck], nk, Cfg::TPQ);
             if (nwave == 0) return 0;
             WaveRun *d_runs = nullptr;
             if (wm->pool->upload(&d_runs, runs, st)) { set_error("dqc_eri_fill_tiles: device upload failed"); return DQC_ENOMEM; }
             o2.wruns = d_runs;
             o2.nruns = (int)runs.size();
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)((nwave + 3) / 4)), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp, dp, hp.cls_start[cb], nb,
-                           hp.cls_start[ck], nk, same, nwave, o2);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((nwave + 3) / 4)), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dpb, dpk, hpb.cls_start[cb], nb,
+                           hpk.cls_start[ck], nk, same, nwave, o2);
         DQC_CHECK_LAUNCH();
         return 0;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dp, dp, hp.cls_start[cb], nb,
-                       hp.cls_start[ck], nk, same, ntask, og);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, tiles, ds, dpb, dpk, hpb.cls_start[cb], nb,
+                       hpk.cls_start[ck], nk, same, ntask, og);
     DQC_CHECK_LAUNCH();
     return 0;
 }
@@ -115,14 +129,13 @@ static int launch_class(double *tiles, const DevShells &ds, const DevPairs &dp, 
 // all classes with (LA>=LB), (LC>=LD), class(bra) >= class(ket)
 template <int CB, int CK>
 struct ClassLoop {
-    static int run(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, hipStream_t st, const EriOut &og,
-                   const WaveMaps *wm = nullptr) {
+    static int run(double *tiles, const DevShells &ds, const FillTables &ft, hipStream_t st, const EriOut &og, const WaveMaps *wm = nullptr) {
         constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
         constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
-        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, dp, hp, st, og, wm);
+        int rc = launch_class<LA, LB, LC, LD>(tiles, ds, ft, st, og, wm);
         if (rc) return rc;
-        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, dp, hp, st, og, wm);
-        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, dp, hp, st, og, wm);
+        if constexpr (CK > 0) return ClassLoop<CB, CK - 1>::run(tiles, ds, ft, st, og, wm);
+        else if constexpr (CB > 0) return ClassLoop<CB - 1, CB - 1>::run(tiles, ds, ft, st, og, wm);
         else return 0;
     }
 };
@@ -656,8 +669,80 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     static const bool wmap_env = [] { const char *e = getenv("DQC_ERI_WMAP"); return !(e && e[0] == '0'); }();
     WaveMaps wm;
     wm.pool = &pool;
-    rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, dp, hp, st, og, wmap_env ? &wm : nullptr);
-    if (rc) return rc;
+    const WaveMaps *wmp = wmap_env ? &wm : nullptr;
+    if (tile_begin == 0 && tile_end == nt_all) {
+        const FillTables ft{&dp, &dp, &hp, &hp, FILL_SAME_TABLE};
+        rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, ft, st, og, wmp);
+        if (rc) return rc;
+    } else {
+        // A slice [tile_begin, tile_end) of a store spread over several GPUs.  Tiles follow each other in the order (IJ, KL <= IJ)
+        // of their block pairs, so the slice is the block-pair rows IJ in [r_lo, r_hi] (its first and last row partly).  An integral
+        // (ab|cd) lands in the row max(P_ab, P_cd) of its pairs' block pairs: only quartets with one pair IN the rows of the slice
+        // and the other in or below them can write into it.  Round 4 evaluated every quartet on every rank (109 ms x N for
+        // naphthalene / cc-pVTZ); now the pair table is split into the pairs inside (h1) and below (h0) the rows -- a shell that
+        // straddles two AO blocks counts for every block pair it touches -- and the rank evaluates h1 x h1, h1 x h0 and h0 x h1.
+        auto row_of = [](long long t) {
+            long long r = (long long)((std::sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while (r * (r + 1) / 2 > t) r--;
+            while ((r + 1) * (r + 2) / 2 <= t) r++;
+            return r;
+        };
+        const long long r_lo = row_of(tile_begin), r_hi = row_of(tile_end - 1);
+        const size_t np = hp.sh.size() / 2;
+        HostPairs h1, h0;
+        for (HostPairs *h : {&h1, &h0}) {
+            h->stride = hp.stride;
+            h->pp_off.push_back(0);
+            for (int c = 0; c < 48; c++) { h->cls_start[c] = 0; h->cls_count[c] = 0; }
+        }
+        auto blocks_of = [&](int g, int out[4]) {  // AO blocks the members of group / shell g touch -> count
+            int n = 0;
+            const int w = 2 * bu.shells[g].l;
+            for (int m = 0; m < 2; m++) {
+                const int a0 = m == 0 ? bu.shells[g].ao_off : (bu.grouped() ? bu.ao_off1[g] : -1);
+                if (a0 < 0) continue;
+                out[n++] = a0 >> 3;
+                if (((a0 + w) >> 3) != (a0 >> 3)) out[n++] = (a0 + w) >> 3;
+            }
+            return n;
+        };
+        for (int c = 0; c < NCLS; c++)
+            for (int i = 0; i < hp.cls_count[c]; i++) {
+                const size_t x = (size_t)hp.cls_start[c] + i;
+                int ba[4], bb[4];
+                const int na = blocks_of(hp.sh[2 * x], ba), nb_ = blocks_of(hp.sh[2 * x + 1], bb);
+                long long pmin = 0x7fffffffffffffffLL, pmax = -1;
+                for (int u = 0; u < na; u++)
+                    for (int v = 0; v < nb_; v++) {
+                        const long long I = std::max(ba[u], bb[v]), J = std::min(ba[u], bb[v]), P = I * (I + 1) / 2 + J;
+                        pmin = std::min(pmin, P);
+                        pmax = std::max(pmax, P);
+                    }
+                if (pmin > r_hi) continue;  // above the rows of the slice: every image of its quartets lies above it
+                HostPairs &h = pmax >= r_lo ? h1 : h0;
+                if (h.cls_count[c] == 0) h.cls_start[c] = (int)(h.sh.size() / 2);
+                h.cls_count[c]++;
+                h.sh.push_back(hp.sh[2 * x]);
+                h.sh.push_back(hp.sh[2 * x + 1]);
+                h.pp.insert(h.pp.end(), hp.pp.begin() + (size_t)hp.pp_off[x] * hp.stride, hp.pp.begin() + (size_t)hp.pp_off[x + 1] * hp.stride);
+                h.pp_off.push_back((int)(h.pp.size() / hp.stride));
+            }
+        (void)np;
+        DevPairs d1{nullptr, nullptr, nullptr, hp.stride}, d0{nullptr, nullptr, nullptr, hp.stride};
+        auto up = [&](HostPairs &h, DevPairs &d) {
+            int *q_sh = nullptr, *q_off = nullptr;
+            double *q_pp = nullptr;
+            int r;
+            if ((r = pool.upload(&q_sh, h.sh, st)) || (r = pool.upload(&q_off, h.pp_off, st)) || (r = pool.upload(&q_pp, h.pp, st))) return r;
+            d = DevPairs{q_sh, q_off, q_pp, h.stride};
+            return 0;
+        };
+        if ((rc = up(h1, d1)) || (rc = up(h0, d0))) { set_error("dqc_eri_fill_tiles_part: device upload failed"); return rc; }
+        const FillTables f11{&d1, &d1, &h1, &h1, FILL_SAME_TABLE}, f10{&d1, &d0, &h1, &h0, FILL_CROSS}, f01{&d0, &d1, &h0, &h1, FILL_CROSS_OFFDIAG};
+        if ((rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f11, st, og, wmp)) || (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f10, st, og, wmp)) ||
+            (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f01, st, og, wmp)))
+            return rc;
+    }
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;
     return DQC_OK;
 }

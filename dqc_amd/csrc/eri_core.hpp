@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         if (xc) ak = sh.ao_off1[ksh];
         if (xd) al = sh.ao_off1[lsh];
         act = act && ai >= 0 && aj >= 0 && ak >= 0 && al >= 0 && !(ish == jsh && xa < xb) && !(ksh == lsh && xc < xd) &&
-              !(ib == ik && eb < ek);
+              !(ib == ik && prs.sh == prk.sh && eb < ek);  // (bra and ket pairs may come from different tables: a sliced fill)
         if constexpr (TPQ > 64) {  // (the group is the block: the barriers below stay block-uniform)
             if (!act) continue;
         } else if (!__any(act)) continue;
