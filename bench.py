@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+UBENCH_READ_GBS = 6450.0  # bare-process streaming read, non-temporal 16-byte loads (profiles/r02a_read_bw_ubench.txt)
 F64_MFMA_PEAK_TF = 78.6  # MI355X dense fp64 matrix peak (vendor figure; the guide lists no fp64 row)
 XC = "gga_x_pbe+gga_c_pbe"
 
@@ -469,9 +470,23 @@ def main():
             return {"bound": "hbm", "kernel": k, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(k), "algorithmic_bytes_per_launch": alg_bytes[k],
                     "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": gbs / hbm_ceiling,
+                    "standalone_read_ceiling_gbs": UBENCH_READ_GBS, "frac_of_standalone_ceiling": gbs / UBENCH_READ_GBS,
                     "avg_launch_ms": ktime[k]}
 
         dom = max(alg_bytes, key=lambda k: ktime[k])
+        # the whole molecule-iteration against the HBM roof: algorithmic bytes of ALL its kernels x the rate the timed region achieved
+        # (with several streams the kernels of different molecules share the chip and each one's own duration stretches: this entry
+        # is the figure that does not depend on how the launches overlap)
+        it_bytes = sum(alg_bytes.values())
+        it_rate = nmol * passes / elapsed / world
+        whole_iteration = {"bound": "hbm", "kernel": "whole_iteration", "achieved": it_bytes * it_rate / 1e9, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": it_bytes * it_rate / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_molecule_iteration": it_bytes, "iterations_per_s_per_gpu": it_rate,
+                           "measured_hbm_read_ceiling_gbs": hbm_ceiling, "frac_of_measured_ceiling": it_bytes * it_rate / 1e9 / hbm_ceiling,
+                           "standalone_read_ceiling_gbs": UBENCH_READ_GBS, "frac_of_standalone_ceiling": it_bytes * it_rate / 1e9 / UBENCH_READ_GBS,
+                           "streams_per_gpu": nstreams,
+                           "note": "sum of the kernels' algorithmic bytes per molecule-iteration x the timed region's rate; the per-kernel "
+                                   "entries are HIP-event durations of one molecule at a time on one stream"}
         out = {
             "metric": "SCF iterations/sec (Fock build + XC grid) per GPU, cc-pVDZ 20-atom",
             "value": nmol * passes / elapsed,
@@ -503,7 +518,13 @@ def main():
                           "ERI fill, grid, AO, two Fock builds) without those two",
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),
-            "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom],
+            "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom] + [whole_iteration],
+            "measured_ceilings_note": "measured_hbm_read_ceiling_gbs = dqc_probe_stream_read: contiguous 32 KB tiles per block, 16-byte "
+                                      "non-temporal loads, four tiles in flight (the fastest shape of tools/ubench/read_bw.hip; the "
+                                      "grid-stride cached-load probe of rounds 1-4 read 5.2-5.3 TB/s).  Inside THIS process -- 141 GB of the "
+                                      "288 resident -- the new shape reads no faster than the old one (5.3 TB/s); the same kernel in a bare "
+                                      "process reads 6.45 TB/s (profiles/r02a_read_bw_ubench.txt, tile U=4 nt=1): standalone_read_ceiling_gbs "
+                                      "is that figure, the stricter of the two yardsticks",
             "traffic_note": traffic_note,
             "sources": source_sha16(),
         }

@@ -253,15 +253,36 @@ size_t dqc_eri_tile_count(int nao) {
     return np * (np + 1) / 2;
 }
 
-// streaming-read probe: sum of a buffer, used by bench.py to measure achievable HBM bandwidth
-__global__ void probe_read_kernel(const double2 *__restrict__ buf, size_t n2, double *out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t stride = (size_t)gridDim.x * blockDim.x;
+// streaming-read probe used by bench.py as the MEASURED HBM read ceiling.  Round 5: the access shape of tools/ubench/read_bw.hip
+// that reads fastest on this chip -- contiguous 32 KB tiles per 256-thread block, 16-byte NON-TEMPORAL loads, four tiles' worth of
+// loads in flight before the first use (6.5 TB/s; the grid-stride loop of cached 16-byte loads used until round 4 stops at 5.2-5.3
+// and made the J and density kernels look like 0.95 of "the ceiling")
+typedef double probe_v2d __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void probe_read_kernel(const probe_v2d *__restrict__ buf, long long ntile, size_t n2, double *out) {
+    constexpr int U = 4;
     double s = 0;
-    for (; i < n2; i += stride) {
-        double2 v = buf[i];
-        s += v.x + v.y;
+    const int t = threadIdx.x;
+    for (long long T = (long long)blockIdx.x * U; T < ntile; T += (long long)gridDim.x * U) {
+        probe_v2d g[U][8];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long long TT = T + u < ntile ? T + u : T;
+            const probe_v2d *tp = buf + TT * 2048;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const probe_v2d *p = tp + ((4 * (t >> 4) + r) * 32 + 2 * (t & 15));
+                g[u][2 * r] = __builtin_nontemporal_load(p);
+                g[u][2 * r + 1] = __builtin_nontemporal_load(p + 1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (T + u < ntile)
+#pragma unroll
+                for (int q = 0; q < 8; q++) s += g[u][q].x + g[u][q].y;
     }
+    // (the tail that does not fill a tile)
+    for (size_t i = (size_t)ntile * 2048 + (size_t)blockIdx.x * blockDim.x + t; i < n2; i += (size_t)gridDim.x * blockDim.x) s += buf[i].x + buf[i].y;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
@@ -294,7 +315,7 @@ int dqc_probe_mfma_f64(double *d_out, int iters, void *stream) {
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     DQC_HIP(hipMemsetAsync(d_out, 0, sizeof(double), st));
-    hipLaunchKernelGGL(probe_read_kernel, dim3(2048), dim3(256), 0, st, (const double2 *)d_buf, n / 2, d_out);
+    hipLaunchKernelGGL(probe_read_kernel, dim3(4096), dim3(256), 0, st, (const probe_v2d *)d_buf, (long long)(n / 4096), n / 2, d_out);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }
