@@ -127,6 +127,36 @@ DQC_DEV void rowdot_epilogue_paired(const v4d (&acc)[NCT], double (&p)[4][GGA ? 
     }
 }
 
+// the paired row dots for TWO accumulator sets that share their loads (spin-fused factor-form density: the gradient arrays of
+// the AO matrix are read once for both spins); gradient components only (Q0 = 1)
+template <int NCT>
+DQC_DEV void rowdot_epilogue_paired2(const v4d (&acc)[2][NCT], double (&p)[2][4][4], const double *__restrict__ blkg, size_t cs,
+                                     const int (&roff)[4], int lr, int col0) {
+    constexpr int NQ = 3, NB = 4 * NQ, NP = NCT / 2, ODD = NCT & 1, DP = 2;
+    double2 t2[DP][NP > 0 ? NP : 1];
+    double t1[DP];
+    auto issue = [&](int bt, double2 (&d2)[NP > 0 ? NP : 1], double &d1) {
+        const int r = bt / NQ, q = bt % NQ + 1;
+        const double *base = blkg + q * cs + col0;
+#pragma unroll
+        for (int m = 0; m < NP; m++) d2[m] = *reinterpret_cast<const double2 *>(base + roff[r] + m * 32);
+        if (ODD) d1 = base[(roff[r] - lr) + (NCT - 1) * 16];
+    };
+    issue(0, t2[0], t1[0]);
+#pragma unroll
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt + 1 < NB) issue(bt + 1, t2[(bt + 1) % DP], t1[(bt + 1) % DP]);
+        const int r = bt / NQ, q = bt % NQ + 1;
+#pragma unroll
+        for (int sp = 0; sp < 2; sp++) {
+#pragma unroll
+            for (int m = 0; m < NP; m++) p[sp][r][q] += acc[sp][2 * m][r] * t2[bt % DP][m].x + acc[sp][2 * m + 1][r] * t2[bt % DP][m].y;
+            if (ODD) p[sp][r][q] += acc[sp][NCT - 1][r] * t1[bt % DP];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NCT, bool GGA>
 __global__ __launch_bounds__(256, 2) void density_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                          const double *__restrict__ ao, int ngrid, int ld,
@@ -351,7 +381,11 @@ struct LrGeom {
     static constexpr int RPS = (RP & 31) == 16 ? RP : RP + 16;  // LDS row stride of the L chunk
 };
 
-template <int NRT, int NCT, bool GGA>
+// NS = 2: the factor holds TWO spin channels of NRT / 2 tiles each, [L_u | L_d] (orbt: their transposes stacked).  Phase 1 is the
+// same GEMM; rho_s comes from the s-th half of its accumulators; phase 2 keeps one accumulator set per spin (chunk kc of the
+// stacked L^T belongs to spin kc / (NRT / 2)) and the row-dot epilogue forms both spins' gradients from ONE read of the gradient
+// arrays.  Outputs: rho (NS, ngrid), grho (NS, 3, ngrid).  An unrestricted Kohn-Sham build read the AO matrix twice before.
+template <int NRT, int NCT, bool GGA, int NS = 1>
 __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__ rho, double *__restrict__ grho,
                                                             const double *__restrict__ ao, int ngrid, int ld,
                                                             const double *__restrict__ orb,
@@ -458,24 +492,29 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
 
     // rho_g = sum_r A'[g][r]^2 straight from the phase-1 accumulators (lane (lr = point, lk) holds r = 16 ct + 4 reg + lk):
     // Phi is never read a second time
-    {
+    static_assert(NS == 1 || (NS == 2 && NRT % 2 == 0), "two spin channels of equal padded width");
+    constexpr int NRU = NRT / NS;  // factor tiles per spin channel
+#pragma unroll
+    for (int sp = 0; sp < NS; sp++) {
         double rs = 0.0;
 #pragma unroll
-        for (int ct = 0; ct < NRT; ct++)
+        for (int ct = sp * NRU; ct < (sp + 1) * NRU; ct++)
 #pragma unroll
             for (int q = 0; q < 4; q++) rs += a1[ct][q] * a1[ct][q];
         rs += __shfl_xor(rs, 16);
         rs += __shfl_xor(rs, 32);
         const int row = g0 + wave * 16 + lr;
-        if (lk == 0 && row < ngrid) rho[row] = rs;
+        if (lk == 0 && row < ngrid) rho[(size_t)sp * ngrid + row] = rs;
     }
     if (!GGA) return;
 
-    double p[4][GGA ? 4 : 1];
+    double p[NS][4][GGA ? 4 : 1];
+#pragma unroll
+    for (int sp = 0; sp < NS; sp++)
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int q = 0; q < (GGA ? 4 : 1); q++) p[r][q] = 0.0;
+        for (int q = 0; q < (GGA ? 4 : 1); q++) p[sp][r][q] = 0.0;
     int roff[4];  // block-local element offsets of this lane's four accumulator rows
 #pragma unroll
     for (int r = 0; r < 4; r++) roff[r] = min(wave * 16 + lk + 4 * r, rmax) * lda + (DEN_PAIRED ? 2 : 1) * lr;
@@ -485,9 +524,11 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
     // columns, so nothing is counted twice and nothing is read past ld.
     for (int jnew = 0; jnew < ntile; jnew += NCT) {
         const int jc = min(jnew, ntile - NCT);
-        v4d acc[NCT];
+        v4d acc[NS][NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ct++) acc[ct] = v4d{0, 0, 0, 0};
+        for (int sp = 0; sp < NS; sp++)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) acc[sp][ct] = v4d{0, 0, 0, 0};
         double2 pb[NB2];
         int boff[NB2];
         bool bzero[NB2];
@@ -541,36 +582,45 @@ __global__ __launch_bounds__(256, 2) void density_lr_kernel(double *__restrict__
                 for (int ct = 0; ct < NCT; ct++) {
                     const double bv = (DEN_PAIRED && ct < 2 * (NCT / 2)) ? b2[kk * 4 * LSBP + 32 * (ct >> 1) + (ct & 1)]
                                                                         : b[kk * 4 * LSBP + ct * 16];
-                    acc[ct] = mfma_f64(av, bv, acc[ct]);
+                    if (NS == 1 || kc < NRU) acc[0][ct] = mfma_f64(av, bv, acc[0][ct]);  // (kc is wave-uniform)
+                    else acc[NS - 1][ct] = mfma_f64(av, bv, acc[NS - 1][ct]);
                 }
             }
             if (kc + 1 < NRT) stage(buf ^ 1);
             __syncthreads();
         }
         DEN_TRACE_POINT(1);
-        if constexpr (!DEN_PAIRED) rowdot_epilogue<NCT, GGA, 1>(acc, p, aoblk, aoblk, cs, roff, jc * 16);
-        else if constexpr (GGA) rowdot_epilogue_paired<NCT, true, 1>(acc, p, aoblk, aoblk, cs, roff, lr, jc * 16);
+        if constexpr (NS == 2) {
+            static_assert(NS == 1 || (DEN_PAIRED && GGA), "spin-fused form: paired epilogue only");
+            rowdot_epilogue_paired2<NCT>(acc, p, aoblk, cs, roff, lr, jc * 16);
+        } else if constexpr (!DEN_PAIRED) rowdot_epilogue<NCT, GGA, 1>(acc[0], p[0], aoblk, aoblk, cs, roff, jc * 16);
+        else if constexpr (GGA) rowdot_epilogue_paired<NCT, true, 1>(acc[0], p[0], aoblk, aoblk, cs, roff, lr, jc * 16);
         DEN_TRACE_POINT(2);
     }
+#pragma unroll
+    for (int sp = 0; sp < NS; sp++)
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int q = 0; q < (GGA ? 4 : 1); q++) {
-            double v = p[r][q];
+            double v = p[sp][r][q];
             v += __shfl_xor(v, 1);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 8);
-            p[r][q] = v;
+            p[sp][r][q] = v;
         }
     if (lr == 0) {
+#pragma unroll
+        for (int sp = 0; sp < NS; sp++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = g0 + wave * 16 + lk + 4 * r;
             if (row < ngrid) {
-                grho[row] = 2.0 * p[r][1];
-                grho[(size_t)ngrid + row] = 2.0 * p[r][2];
-                grho[2 * (size_t)ngrid + row] = 2.0 * p[r][3];
+                double *gs = grho + (size_t)sp * 3 * ngrid;
+                gs[row] = 2.0 * p[sp][r][1];
+                gs[(size_t)ngrid + row] = 2.0 * p[sp][r][2];
+                gs[2 * (size_t)ngrid + row] = 2.0 * p[sp][r][3];
             }
         }
     }
@@ -762,6 +812,32 @@ __global__ __launch_bounds__(256, 2) void density_lr_tau_kernel(double *__restri
     }
 }
 
+// spin-fused form: two accumulator sets in phase 2 -- panels of at most this many tiles (8 NRT + 16 NCT + 4 NCT + 48 registers)
+constexpr int lr2_max_nct(int nrt) { return nrt <= 4 ? 6 : (nrt <= 6 ? 5 : 4); }
+
+template <int NRT>
+static int launch_density_lr2_n(int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao, int ngrid, int ld,
+                                const double *orb, const double *orbt, int ntile, int lda) {
+#define DQC_DLR2_CASE(N)                                                                                         \
+    case N:                                                                                                      \
+        if constexpr (N <= lr2_max_nct(NRT)) {                                                                   \
+            constexpr size_t shm = density_lr_lds_bytes<NRT, N>();                                               \
+            auto kern = density_lr_kernel<NRT, N, true, 2>;                                                      \
+            (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
+            hipLaunchKernelGGL(kern, grid, dim3(DEN_NT), shm, st, rho, grho, ao, ngrid, ld, orb, orbt, ntile, lda); \
+            return 0;                                                                                            \
+        }                                                                                                        \
+        break;
+    switch (nct) {
+        DQC_DLR2_CASE(1) DQC_DLR2_CASE(2) DQC_DLR2_CASE(3) DQC_DLR2_CASE(4) DQC_DLR2_CASE(5) DQC_DLR2_CASE(6) DQC_DLR2_CASE(7)
+    default:
+        break;
+    }
+#undef DQC_DLR2_CASE
+    set_error("density_lr (two spins): internal tile-count dispatch error");
+    return DQC_EINVAL;
+}
+
 template <bool GGA>
 static int launch_density_lr(int nrt, int nct, dim3 grid, hipStream_t st, double *rho, double *grho, const double *ao,
                              int ngrid, int ld, const double *orb, const double *orbt, int ntile, int lda) {
@@ -827,6 +903,37 @@ int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int n
     dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
     int rc = gga ? launch_density_lr<true>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda)
                  : launch_density_lr<false>(norb_pad / 16, nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda);
+    if (rc) return rc;
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+int dqc_grid_density_lr_pol(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
+                            const double *d_orb, const double *d_orbt, int norb_pad_spin, void *stream) {
+    // both spin densities of an unrestricted calculation from ONE pass over the AO matrix: d_orb (ld, 2 norb_pad_spin) = [L_u | L_d]
+    // row-major, d_orbt (2 norb_pad_spin, ld) its transpose; d_rho (2, ngrid), d_grho (2, 3, ngrid) -- GGA only (d_grho != NULL);
+    // norb_pad_spin in {16, 32, 48, 64}.  Enqueues only.
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    if (ngrid <= 0) return DQC_OK;
+    if (!d_grho || ncomp < 4) { set_error("dqc_grid_density_lr_pol: needs the four AO components and the gradient output"); return DQC_EINVAL; }
+    if (norb_pad_spin != 16 && norb_pad_spin != 32 && norb_pad_spin != 48 && norb_pad_spin != 64) {
+        set_error("dqc_grid_density_lr_pol: norb_pad_spin must be 16, 32, 48 or 64");
+        return DQC_EINVAL;
+    }
+    const int ld = dqc_padded_nao(nao), ntile = ld / 16, lda = dqc_ao_stride(nao);
+    const int nrt = 2 * norb_pad_spin / 16;
+    const int lim = lr2_max_nct(nrt);
+    const int nchunk = (ntile + lim - 1) / lim;
+    const int nct = (ntile + nchunk - 1) / nchunk;
+    dim3 grid((ngrid + DEN_BM - 1) / DEN_BM);
+    int rc;
+    switch (nrt) {
+    case 2: rc = launch_density_lr2_n<2>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda); break;
+    case 4: rc = launch_density_lr2_n<4>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda); break;
+    case 6: rc = launch_density_lr2_n<6>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda); break;
+    default: rc = launch_density_lr2_n<8>(nct, grid, st, d_rho, d_grho, d_ao, ngrid, ld, d_orb, d_orbt, ntile, lda); break;
+    }
     if (rc) return rc;
     DQC_CHECK_LAUNCH();
     return DQC_OK;

@@ -200,7 +200,7 @@ class DeviceLoop:
             qc.niter, qc.scf_error = j + 1, emax
             if trace:
                 print("scf it %2d  max|[F,D]| %.2e  (device loop)" % (j, emax), flush=True)
-            if not pe < 1e-9:
+            if not pe < 1e-9 or not emax == emax or emax == float("inf"):  # (a non-finite error: the host-driven loop sorts it out)
                 return "fallback"
             if emax < best_err * 0.9:
                 best_err, best_it = emax, j

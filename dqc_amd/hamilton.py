@@ -535,7 +535,7 @@ class HamiltonMI355(_Base):
         assert self.xc is not None, "Please call .setup_grid with the xc object"
         if isinstance(dm, SpinParam):  # polarised branch of hcgto.py:260-269
             assert dm.u.dim() == 2, "batched polarised densities are not supported"
-            densinfo = SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
+            densinfo = self._dm2densinfo_pol(dm)
             potinfo = self.xc.get_vxc(densinfo)
             return SpinParam(u=LinearOperator.m(self._get_vxc_from_potinfo(potinfo.u), is_hermitian=True),
                              d=LinearOperator.m(self._get_vxc_from_potinfo(potinfo.d), is_hermitian=True))
@@ -630,7 +630,7 @@ class HamiltonMI355(_Base):
     def get_e_xc(self, dm):
         assert self.xc is not None, "Please call .setup_grid with the xc object"
         if isinstance(dm, SpinParam):  # hcgto.py:320-328 with SpinParam densinfo
-            densinfo = SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
+            densinfo = self._dm2densinfo_pol(dm)
             return self._allsum(torch.sum(self.dvolume * self.xc.get_edensityxc(densinfo), dim=-1))
 
         e = self._memo_energy(dm, 3)
@@ -705,6 +705,20 @@ class HamiltonMI355(_Base):
         gg = sum(lib.grid_density_pair(self._ao[d], self._ao[d], self._nao_ao, dao) for d in (1, 2, 3))
         lb = lib.grid_density_pair(self._ao[0], self._ao[4], self._nao_ao, dao)
         return ValGrad(value=rho, grad=grho, lapl=(lb + gg) * 2, kin=gg * 0.5)
+
+    def _dm2densinfo_pol(self, dm: SpinParam) -> SpinParam:
+        """both spin channels' densities (SpinParam.apply_fcn over _dm2densinfo in the reference, hcgto.py:260-269).  GGA with both
+        factors known: ONE pass over the AO matrix for the two spins (dqc_grid_density_lr_pol) instead of one per spin"""
+        if self.xcfamily == 2 and self.is_ao_set and self.is_grad_ao_set:
+            fu, fd = self._factor_of(dm.u), self._factor_of(dm.d)
+            if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
+                out = lib.grid_density_lr_pol(self._ao, self._nao_ao, fu[0], fd[0])
+                if out is not None:
+                    self.grid_path_counts["factor"] += 2
+                    self.grid_path_counts["factor_spin_fused"] = self.grid_path_counts.get("factor_spin_fused", 0) + 1
+                    rho, grho = out
+                    return SpinParam(u=ValGrad(value=rho[0], grad=grho[0]), d=ValGrad(value=rho[1], grad=grho[1]))
+        return SpinParam(u=self._dm2densinfo(dm.u), d=self._dm2densinfo(dm.d))
 
     def _get_vxc_from_potinfo(self, potinfo: ValGrad):
         vm = self._vxc_ao_from_potinfo(potinfo)

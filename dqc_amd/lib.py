@@ -107,6 +107,7 @@ def load():
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
+    lib.dqc_grid_density_lr_pol.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
     lib.dqc_grid_density_lr_tau.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_int, c_vp]
     lib.dqc_grid_density_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_grid_vxc_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_vp]
@@ -673,6 +674,33 @@ def grid_density_lr(ao, nao, factor, gga):
     with _on(ao.device) as st_:
         _check(load().dqc_grid_density_lr(_ptr(rho), _ptr(grho), _ptr(ao), ncomp, ngrid, nao, _ptr(orb), _ptr(orbt),
                                           orb.shape[1], st_), "dqc_grid_density_lr" if gga else "dqc_grid_density_lr[value only]")
+    return rho, grho
+
+
+def grid_density_lr_pol(ao, nao, factor_u, factor_d):
+    """both spin densities of D_u = L_u L_u^T, D_d = L_d L_d^T from ONE pass over the AO matrix (GGA form): padded factor pairs of
+    `pad_factor`, brought to the same padded width (<= 64 columns each) -> rho (2, ngrid), grho (2, 3, ngrid); None when the
+    widths do not fit"""
+    rp = max(factor_u[0].shape[1], factor_d[0].shape[1])
+    if rp > 64 or ao.dim() != 3 or ao.shape[0] < 4:
+        return None
+
+    def widen(f):
+        orb, orbt = f
+        if orb.shape[1] == rp:
+            return orb, orbt
+        o2 = torch.zeros((orb.shape[0], rp), dtype=orb.dtype, device=orb.device)
+        o2[:, :orb.shape[1]] = orb
+        return o2, o2.t().contiguous()
+    (ou, otu), (od, otd) = widen(factor_u), widen(factor_d)
+    orb = torch.cat([ou, od], dim=1).contiguous()
+    orbt = torch.cat([otu, otd], dim=0).contiguous()
+    ngrid = ao.shape[-2]
+    rho = torch.empty((2, ngrid), dtype=torch.float64, device=ao.device)
+    grho = torch.empty((2, 3, ngrid), dtype=torch.float64, device=ao.device)
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_density_lr_pol(_ptr(rho), _ptr(grho), _ptr(ao), ao.shape[0], ngrid, nao, _ptr(orb), _ptr(orbt), rp, st_),
+               "dqc_grid_density_lr_pol")
     return rho, grho
 
 

@@ -257,6 +257,23 @@ class SCF_QCCalc:
                 ev = err.reshape(-1)
                 h2 = yield torch.cat([err.abs().max().reshape(1), (torch.stack(hist + [ev]) * ev).sum(-1)])
                 emax, grow = float(h2[0]), h2[1:]
+            if purified is not None and (not np.isfinite(emax) or (it - best_it >= 40 and emax > 1e-6)):
+                # The purification step has no preferred basis inside a degenerate Fermi level (open p shells, ...): every step then
+                # lands on another rotation of the degenerate orbitals, the iteration wanders for ever and the DIIS system eventually
+                # blows up (UKS SCAN on the oxygen triplet: NaN after 88 steps, or -26 Ha).  The reference diagonalises (hf.py:105-113),
+                # which fixes the orbitals: after 40 steps without progress -- or at the first non-finite error -- the loop drops the
+                # purification and starts again from the core guess with eigh steps and a fresh history
+                self.purification_dropped = True
+                purified, graphed, perr, fprev = None, None, None, None
+                fs, es, gram = [], [], np.zeros((0, 0))
+                # (from the core guess again: continued from the best wandering iterate the eigh steps did not settle in 160 more
+                # iterations on that system, from the core guess they converge in 23)
+                n_ = eng.shape[-1]
+                z_ = torch.zeros((n_, n_), dtype=eng.dtype, device=eng.device)
+                dm = eng.scp2dm(eng.dm2scp(SpinParam(u=z_, d=z_) if pol else z_))
+                fock = eng.dm2scp(dm)
+                best_err, best_it = float("inf"), it
+                continue
             self.scf_error = emax  # max |[F, D]| of the last iterate
             # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,
             # growing with the matrix size): an iterate that is within 100 f_tol and has not improved for 8 steps ends the

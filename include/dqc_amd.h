@@ -287,6 +287,12 @@ int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int n
 int dqc_padded_norb(int norb);
 int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
                         const double *d_orb, const double *d_orbt, int norb_pad, void *stream);
+/* Both spin densities of an unrestricted Kohn-Sham build from ONE pass over the AO matrix (reference: SpinParam.apply_fcn over
+ * HamiltonCGTO._dm2densinfo, dqc/hamilton/hcgto.py:260-269, 371-418 -- one pass per spin there).  d_orb (ld, 2 norb_pad_spin) =
+ * [L_u | L_d] row-major with every channel zero padded to norb_pad_spin columns (16, 32, 48 or 64), d_orbt its transpose;
+ * d_rho (2, ngrid), d_grho (2, 3, ngrid); GGA form only.  Enqueues only. */
+int dqc_grid_density_lr_pol(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
+                            const double *d_orb, const double *d_orbt, int norb_pad_spin, void *stream);
 
 /* meta-GGA densities of D = L L^T from ONE pass over the four AO components: rho, grad rho (3, ngrid) and
  * tau = 1/2 sum_d sum_r (d_d Phi . L)_r^2 (hcgto.py:398-438 with D in factor form) -- four rank-r GEMMs, no row-dot epilogue;
