@@ -48,6 +48,109 @@ __global__ __launch_bounds__(256) void becke_weights_kernel(double *__restrict__
     w[g] = pown / psum;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// derivative of the partition weights (nuclear gradients of E_xc: the grid response term).  Given c_g = dL/dw_g it forms
+//     gpos[B] += sum_g c_g dw_g/dR_B (explicit dependence on the nuclei),   gxyz[g] = c_g dw_g/dr_g = -sum_B c_g dw_g/dR_B
+// (w is invariant under a common translation of the point and all nuclei).  The reference gets this by autograd through its
+// torch expression (dqc/grid/multiatoms_scheme.py:9-67): ~30 ms of element-wise launches on (natm, natm, ngrid_atom) arrays for
+// a 20-atom sg3 grid, the largest single item of the XC gradient.  With nu_ij = mu_ij - a_ij (mu_ij^2 - 1), s = (1 - f3(nu)) / 2,
+// t_ij = (s'/s)(nu_ij) (1 - 2 a_ij mu_ij) / R_ij, u_i = (r - R_i) / |r - R_i|, e_ij = (R_j - R_i) / R_ij:
+//     d ln P_j / dR_B = t_Bj (u_B + mu_Bj e_Bj)                       (B != j: only the factor i = B depends on R_B)
+//     d ln P_j / dR_j = sum_{i != j} t_ij (-u_j - mu_ij e_ij)
+//     dw / dR_B       = w sum_j (delta_{j, own} - P_j / sum P) d ln P_j / dR_B
+// The cut (columns with some mu_ij >= cut are dropped) is a constant mask, as under autograd.  pcol: (natm, ngrid) scratch.
+// ---------------------------------------------------------------------------------------------
+DQC_DEV void becke_pair(double ri, double rj, double inv_r, double a, double &mu, double &s, double &t, double *nu_out = nullptr) {
+    mu = (rj - ri) * inv_r;
+    const double nu = mu - a * (mu * mu - 1.0);
+    if (nu_out) *nu_out = nu;
+    const double f1 = -0.5 * (nu * (nu * nu - 3.0)), f2 = -0.5 * (f1 * (f1 * f1 - 3.0)), f3 = -0.5 * (f2 * (f2 * f2 - 3.0));
+    s = -0.5 * (f3 - (1.0 + 1e-12));
+    const double d3 = 1.5 * (1.0 - f2 * f2) * 1.5 * (1.0 - f1 * f1) * 1.5 * (1.0 - nu * nu);  // d f3 / d nu
+    t = (-0.5 * d3 / s) * (1.0 - 2.0 * a * mu) * inv_r;
+}
+
+__global__ __launch_bounds__(256) void becke_weights_grad_kernel(double *__restrict__ gpos, double *__restrict__ gxyz,
+                                                                 double *__restrict__ pcol, const double *__restrict__ cw,
+                                                                 const double *__restrict__ xyz, const int *__restrict__ atom_off,
+                                                                 const double *__restrict__ pos, const double *__restrict__ inv_rij,
+                                                                 const double *__restrict__ aij, int natm, int ngrid, double cut) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = g < ngrid;
+    const int gg = in ? g : ngrid - 1;
+    const double x = xyz[3 * (size_t)gg], y = xyz[3 * (size_t)gg + 1], z = xyz[3 * (size_t)gg + 2];
+    int own = 0;
+    while (own + 1 < natm && gg >= atom_off[own + 1]) own++;
+    const double sdiag = 0.5 * (1.0 + 1e-12) + 0.5;
+    auto dist = [&](int i) {
+        const double dx = x - pos[3 * i], dy = y - pos[3 * i + 1], dz = z - pos[3 * i + 2];
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    // ---- pass 1: the cell products P_j (0 for dropped columns)
+    double psum = 0.0, pown = 0.0;
+    for (int j = 0; j < natm; j++) {
+        const double rj = dist(j);
+        double p = 1.0;
+        bool keep = true;
+        for (int i = 0; i < natm; i++) {
+            if (i == j) { p *= sdiag; continue; }
+            double mu, s_, t_, nu;
+            becke_pair(dist(i), rj, inv_rij[i * natm + j], aij[i * natm + j], mu, s_, t_, &nu);
+            keep = keep && (nu < cut);  // (the size-adjusted value is the one the cut looks at)
+            p *= s_;
+        }
+        if (!keep) p = 0.0;
+        pcol[(size_t)j * ngrid + gg] = p;
+        psum += p;
+        if (j == own) pown = p;
+    }
+    const double wgt = pown / psum, scale = in ? cw[gg] * wgt : 0.0;  // c_g w_g
+    // ---- pass 2: V_B = sum_j (delta_{j, own} - P_j / sum P) d ln P_j / dR_B for every nucleus B
+    double tot[3] = {0.0, 0.0, 0.0};
+    const int lane = threadIdx.x & 63;
+    for (int B = 0; B < natm; B++) {
+        const double dxB = x - pos[3 * B], dyB = y - pos[3 * B + 1], dzB = z - pos[3 * B + 2];
+        const double rB = sqrt(dxB * dxB + dyB * dyB + dzB * dzB), irB = rB > 0.0 ? 1.0 / rB : 0.0;
+        const double uB[3] = {dxB * irB, dyB * irB, dzB * irB};
+        const double pB = pcol[(size_t)B * ngrid + gg];
+        const double coefB = ((B == own) ? 1.0 : 0.0) - pB / psum;
+        double v[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < natm; k++) {
+            if (k == B) continue;
+            const double rk = dist(k);
+            const double ir = inv_rij[B * natm + k];
+            const double e[3] = {(pos[3 * k] - pos[3 * B]) * ir, (pos[3 * k + 1] - pos[3 * B + 1]) * ir, (pos[3 * k + 2] - pos[3 * B + 2]) * ir};  // e_Bk
+            double mu, s_, t_;
+            // column k, factor i = B: d ln P_k / dR_B = t_Bk (u_B + mu_Bk e_Bk)
+            const double pk = pcol[(size_t)k * ngrid + gg];
+            if (pk != 0.0) {
+                becke_pair(rB, rk, ir, aij[B * natm + k], mu, s_, t_);
+                const double cf = (((k == own) ? 1.0 : 0.0) - pk / psum) * t_;
+#pragma unroll
+                for (int d = 0; d < 3; d++) v[d] += cf * (uB[d] + mu * e[d]);
+            }
+            // column B, factor i = k: d ln P_B / dR_B gets t_kB (-u_B - mu_kB e_kB), e_kB = -e_Bk
+            if (pB != 0.0) {
+                becke_pair(rk, rB, ir, aij[k * natm + B], mu, s_, t_);
+                const double cf = coefB * t_;
+#pragma unroll
+                for (int d = 0; d < 3; d++) v[d] += cf * (-uB[d] + mu * e[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double c = scale * v[d];
+            tot[d] += c;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == 0 && c != 0.0) atomicAdd(&gpos[3 * B + d], c);
+        }
+    }
+    if (in)
+        for (int d = 0; d < 3; d++) gxyz[3 * (size_t)g + d] = -tot[d];
+}
+
 }  // namespace dqc
 
 extern "C" int dqc_becke_weights(double *d_w, const double *d_xyz, const int *d_atom_off, const double *d_pos,
@@ -59,6 +162,19 @@ extern "C" int dqc_becke_weights(double *d_w, const double *d_xyz, const int *d_
     if (ngrid <= 0 || natm <= 0) return DQC_OK;
     hipLaunchKernelGGL(becke_weights_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_w, d_xyz, d_atom_off,
                        d_pos, d_inv_rij, d_aij, natm, ngrid, cut);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+extern "C" int dqc_becke_weights_grad(double *d_gpos, double *d_gxyz, double *d_scratch, const double *d_cw, const double *d_xyz,
+                                      const int *d_atom_off, const double *d_pos, const double *d_inv_rij, const double *d_aij,
+                                      int natm, int ngrid, double cut, void *stream) {
+    // backward of dqc_becke_weights: d_cw (ngrid) = dL/dw; d_gpos (natm, 3) += sum_g cw dw/dR (explicit), d_gxyz (ngrid, 3) = cw dw/dr_g;
+    // d_scratch: natm * ngrid doubles.  Enqueues only.
+    using namespace dqc;
+    if (ngrid <= 0 || natm <= 0) return DQC_OK;
+    hipLaunchKernelGGL(becke_weights_grad_kernel, dim3((ngrid + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_gpos, d_gxyz, d_scratch,
+                       d_cw, d_xyz, d_atom_off, d_pos, d_inv_rij, d_aij, natm, ngrid, cut);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -577,6 +577,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     og.kacc = d_K ? c.d_b : nullptr;
     og.part = part;
     og.nparts = nparts;
+    if (const char *e = getenv("DQC_ERI_DBG")) og.dbg = atoi(e);  // timing experiments (eri_core.hpp)
     ScreenPlan sp;
     const ScreenPlan *spp = nullptr;
     int rc;

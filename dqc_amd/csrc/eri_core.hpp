@@ -879,8 +879,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                     if constexpr (TPQ == 1) *p_ += x;   // the lane owns its quartet's sums
                     else atomicAdd(p_, x);              // ds_add_f64
                 };
-                ladd(&jk[ma * Cfg::SB + mb], v * D[(size_t)k * n + l]);
-                ladd(&jk[OJ2 + mc * Cfg::SD + md], v * D[(size_t)i * n + j]);
+                // (the two Coulomb products are matrix-vector passes over the block below: no LDS atomics)
                 if (og.kacc) {
                     ladd(&jk[OK1 + ma * Cfg::SC + mc], v * D[(size_t)j * n + l]);
                     ladd(&jk[OK2 + ma * Cfg::SD + md], v * D[(size_t)j * n + k]);
@@ -900,7 +899,36 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         }
     }
     if constexpr (MODE == ERI_OUT_JK) {
-        // one atomic per element of the six shell-pair blocks.  Every unique quartet is visited once (pairs a >= b, c >= d,
+        // Coulomb products of the block V[ab][cd] (in `cur`): J_ab += sum_cd V D_cd (a lane per row, the density element uniform
+        // over the lanes) and J_cd += sum_ab V D_ab (a lane per column, stride-1 LDS reads), one global atomic per result.  Round 4
+        // added v D to LDS accumulators element by element: two ds_add_f64 per integral, up to 49 lanes on one address -- the
+        // output phase of an unscreened naphthalene / cc-pVTZ pass took 66 of 121 ms.
+        if (act) {
+            constexpr double S0_ = 0.28209479177387864;
+            constexpr double SCALE_ = (LA == 0 ? S0_ : 1.0) * (LB == 0 ? S0_ : 1.0) * (LC == 0 ? S0_ : 1.0) * (LD == 0 ? S0_ : 1.0);
+            constexpr int NAB = Cfg::SA * Cfg::SB, NCDS = Cfg::SC * Cfg::SD;
+            const double degj = 4.0 * SCALE_ * (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0);
+            const double *D = og.dmat;
+            const size_t n = og.nao;
+            for (int ab = s; ab < NAB; ab += TPQ) {
+                const double *row = cur + ab * NCDS;
+                double a_ = 0.0;
+#pragma unroll
+                for (int mc = 0; mc < Cfg::SC; mc++)
+#pragma unroll
+                    for (int md = 0; md < Cfg::SD; md++) a_ += row[mc * Cfg::SD + md] * D[(size_t)(ak + mc) * n + al + md];
+                atomicAdd(og.jacc + (size_t)(ai + ab / Cfg::SB) * n + aj + ab % Cfg::SB, degj * a_);
+            }
+            for (int cd = s; cd < NCDS; cd += TPQ) {
+                double a_ = 0.0;
+#pragma unroll
+                for (int ma = 0; ma < Cfg::SA; ma++)
+#pragma unroll
+                    for (int mb = 0; mb < Cfg::SB; mb++) a_ += cur[(ma * Cfg::SB + mb) * NCDS + cd] * D[(size_t)(ai + ma) * n + aj + mb];
+                atomicAdd(og.jacc + (size_t)(ak + cd / Cfg::SD) * n + al + cd % Cfg::SD, degj * a_);
+            }
+        }
+        // one atomic per element of the four exchange blocks.  Every unique quartet is visited once (pairs a >= b, c >= d,
         // bra pair >= ket pair): the eight permutational images are covered by accumulating A_ab, A_cd (J = (A + A^T) / 2)
         // and B_ac, B_ad, B_bc, B_bd (K = B + B^T) with 1/2 per coincidence a == b, c == d, (ab) == (cd)
         eri_group_sync<TPQ>();
@@ -912,12 +940,10 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
                           OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
             const int nend = og.kacc ? Cfg::NJK : OK1;
-            for (int e_ = s; e_ < nend; e_ += TPQ) {
+            for (int e_ = OK1 + s; e_ < nend; e_ += TPQ) {
                 double *dst;
                 double f = deg;
-                if (e_ < OJ2) { dst = og.jacc + (size_t)(ai + e_ / Cfg::SB) * n + aj + e_ % Cfg::SB; f *= 4.0; }
-                else if (e_ < OK1) { const int x = e_ - OJ2; dst = og.jacc + (size_t)(ak + x / Cfg::SD) * n + al + x % Cfg::SD; f *= 4.0; }
-                else if (e_ < OK2) { const int x = e_ - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
+                if (e_ < OK2) { const int x = e_ - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
                 else if (e_ < OK3) { const int x = e_ - OK2; dst = og.kacc + (size_t)(ai + x / Cfg::SD) * n + al + x % Cfg::SD; }
                 else if (e_ < OK4) { const int x = e_ - OK3; dst = og.kacc + (size_t)(aj + x / Cfg::SC) * n + ak + x % Cfg::SC; }
                 else { const int x = e_ - OK4; dst = og.kacc + (size_t)(aj + x / Cfg::SD) * n + al + x % Cfg::SD; }

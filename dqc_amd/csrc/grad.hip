@@ -277,7 +277,9 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(double *__restrict__ gra
                 return -2.0 * b * b * s[d][i][j + 2] + b * (2 * j + 1) * s[d][i][j] - (j >= 2 ? 0.5 * j * (j - 1) * s[d][i][j - 2] : 0.0);
             };
             int ca = 0;
-            for (int ax = la; ax >= 0; ax--)
+            // (the launch is split over the nuclei along grid.y -- one thread per shell pair walked all primitive pairs and all
+            // nuclei alone: 9 ms for a 20-atom molecule on 144 waves; the overlap / kinetic part belongs to split 0)
+            for (int ax = (blockIdx.y == 0 ? la : -1); ax >= 0; ax--)
                 for (int ay = la - ax; ay >= 0; ay--, ca++) {
                     const int az = la - ax - ay;
                     const int av[3] = {ax, ay, az};
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(double *__restrict__ gra
                 }
             // ---- nuclear attraction, nucleus by nucleus (operator derivative by translational invariance)
             const int nroots = (la + 1 + lb) / 2 + 1;
-            for (int ic = 0; ic < natm; ic++) {
+            for (int ic = blockIdx.y; ic < natm; ic += gridDim.y) {
                 const double prn = -atom_z[ic] * cc * K * 2.0 * M_PI / p;
                 const double *C = atom_xyz + ic * 3;
                 double g3[3] = {0.0, 0.0, 0.0};
@@ -464,7 +466,7 @@ int dqc_int1e_grad(double *d_grad, const double *d_dcart, const double *d_wcart,
         return rc;
     }
     const int npair = nbas * nbas;
-    hipLaunchKernelGGL(int1e_grad_kernel, dim3((npair + 63) / 64), dim3(64), 0, st, d_grad, ds, d_cao, d_atom, d_dcart, d_wcart,
+    hipLaunchKernelGGL(int1e_grad_kernel, dim3((npair + 63) / 64, natm < 32 ? natm : 32), dim3(64), 0, st, d_grad, ds, d_cao, d_atom, d_dcart, d_wcart,
                        ncart, natm, d_xyz, d_z);
     DQC_CHECK_LAUNCH();
     DQC_HIP(hipStreamSynchronize(st));

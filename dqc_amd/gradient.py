@@ -143,11 +143,16 @@ def _xc_gradient(eng, d_aos):
     pots = [pot] if len(infos) == 1 else [pot.u, pot.d]
     w = h.dvolume
     natm = len(mol.atomzs)
-    owner = _grid_owner(mol, h.rgrid.shape[0], dev)
     ao_atom = _ao_owner(h, dev)
     g = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
     for info, b, c, pt in zip(infos, bs, cs_, pots):
         vrho, u, vtau = pt.value, pt.grad, pt.kin
+        if gga and ao.shape[0] == 10 and nao <= 512:
+            # one fused pass over the ten derivative arrays (dqc_grid_xc_gradient_terms) instead of ~40 element-wise passes
+            q, per_ao = lib.grid_xc_gradient_terms(ao, nao, b, c, w, vrho, u, info.grad, vtau if fam == 4 else None)
+            g += _sum_by_owner(mol, q)             # (ii)
+            g.index_add_(0, ao_atom, -2.0 * per_ao)  # (iii)
+            continue
         q = torch.empty((h.rgrid.shape[0], 3), dtype=torch.float64, device=dev)
         per_ao = torch.empty((nao, 3), dtype=torch.float64, device=dev)
         if gga:
@@ -165,7 +170,7 @@ def _xc_gradient(eng, d_aos):
             else:
                 q[:, j] = w * vrho * _grad_rho(ao, b, j)
                 per_ao[:, j] = (ao[1 + j] * t1 * w.unsqueeze(-1)).sum(0)[:nao]
-        g.index_add_(0, owner, q)              # (ii)
+        g += _sum_by_owner(mol, q)             # (ii)
         g.index_add_(0, ao_atom, -2.0 * per_ao)  # (iii)
     # (i) Becke-weight derivative, energy density held fixed
     pos = mol.atompos.to(dtype=torch.float64, device=dev).clone().requires_grad_(True)
@@ -182,8 +187,8 @@ def _grad_rho(ao, b, j):
 _ATOM_GRID_SIZE = {}
 
 
-def _grid_owner(mol, ngrid, dev):
-    """parent atom of every grid point: the atomic grids are concatenated atom by atom (dqc_amd.grid.get_grid)"""
+def _grid_sizes(mol, ngrid):
+    """grid points of every atom: the atomic grids are concatenated atom by atom (dqc_amd.grid.get_grid)"""
     sizes = []
     for z in mol.atomzs.tolist():
         key = (str(mol._grid_inp), int(z))
@@ -192,7 +197,17 @@ def _grid_owner(mol, ngrid, dev):
             _ATOM_GRID_SIZE[key] = one.get_rgrid().shape[0]
         sizes.append(_ATOM_GRID_SIZE[key])
     assert sum(sizes) == ngrid
-    return torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+    return sizes
+
+
+def _sum_by_owner(mol, q):
+    """(ngrid, 3) per-point terms -> (natm, 3): every atom's points are one contiguous range (index_add_ over 350 000 rows into
+    20 took 8 ms of same-address atomics)"""
+    out, off = [], 0
+    for n in _grid_sizes(mol, q.shape[0]):
+        out.append(q[off:off + n].sum(0))
+        off += n
+    return torch.stack(out)
 
 
 def _ao_owner(h, dev):

@@ -190,6 +190,25 @@ def _atom_grid(atz, nr, prec, integrator, tf, truncate, radii_list):
 _BECKE_CUT = 0.74
 
 
+class _BeckeWeightsFn(torch.autograd.Function):
+    """Becke partition weights with an analytic backward on the device (dqc_becke_weights / dqc_becke_weights_grad).  The
+    size-adjustment coefficients a_ij depend on the elements only and 1 / R_ij enters as data: its own dependence on the nuclei
+    is part of the kernel's derivative (mu_ij = (r_j - r_i) / R_ij is differentiated as a whole)"""
+
+    @staticmethod
+    def forward(ctx, xyz, atompos, atom_off, inv_rij, aij):
+        from . import lib
+        ctx.save_for_backward(xyz.detach(), atompos.detach(), atom_off, inv_rij, aij)
+        return lib.becke_weights(xyz.detach(), atom_off, atompos.detach().contiguous(), inv_rij, aij, _BECKE_CUT)
+
+    @staticmethod
+    def backward(ctx, gw):
+        from . import lib
+        xyz, pos, atom_off, inv_rij, aij = ctx.saved_tensors
+        gpos, gxyz = lib.becke_weights_grad(gw.contiguous(), xyz, atom_off, pos, inv_rij, aij, _BECKE_CUT)
+        return gxyz, gpos, None, None, None
+
+
 def _becke_weights(rgrids, atompos, atomradii, ratom_adjust):
     """Becke partition weights, atom by atom like the reference (bounds the temporaries to
     natoms^2 x ngrid_atom)."""
@@ -201,15 +220,19 @@ def _becke_weights(rgrids, atompos, atomradii, ratom_adjust):
     rad = atomradii if ratom_adjust == "becke" else atomradii ** 0.5
     uij = (rad - rad.unsqueeze(1)) / (rad + rad.unsqueeze(1))
     aij = torch.clamp(uij / (uij * uij - 1), min=-0.45, max=0.45).unsqueeze(-1)
-    if device.type == "cuda" and not atompos.requires_grad and dtype == torch.float64:
+    if device.type == "cuda" and dtype == torch.float64:
         # one lane per grid point in the HIP kernel (csrc/becke.hip) instead of ~25 elementwise launches per atom on
-        # (natoms, natoms, ngrid_atom) temporaries; autograd callers (nuclear gradients) keep the torch expression below
+        # (natoms, natoms, ngrid_atom) temporaries; autograd callers (nuclear gradients: the grid-response term) get the
+        # analytic backward kernel through _BeckeWeightsFn
         from . import lib
         off = [0]
         for g in rgrids:
             off.append(off[-1] + g.shape[0])
         atom_off = torch.tensor(off, dtype=torch.int32).to(device)
-        return lib.becke_weights(torch.cat(rgrids, 0).contiguous(), atom_off, atompos.contiguous(), (1.0 / ratoms).contiguous(),
+        xyz = torch.cat(rgrids, 0).contiguous()
+        if atompos.requires_grad or xyz.requires_grad:
+            return _BeckeWeightsFn.apply(xyz, atompos, atom_off, (1.0 / ratoms).detach().contiguous(), aij.squeeze(-1).detach().contiguous())
+        return lib.becke_weights(xyz, atom_off, atompos.contiguous(), (1.0 / ratoms).contiguous(),
                                  aij.squeeze(-1).contiguous(), _BECKE_CUT)
     eye = torch.eye(natoms, dtype=dtype, device=device).unsqueeze(-1)
     out = []

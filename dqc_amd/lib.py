@@ -80,6 +80,7 @@ def load():
     lib.dqc_eri_grad.argtypes = [c_dp, c_dp, ctypes.c_double, ctypes.c_double] + tab + [c_vp]
     lib.dqc_df_grad.argtypes = [c_dp, c_dp, c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_becke_weights.argtypes = [c_dp, c_dp, c_vp, c_dp, c_dp, c_dp, c_int, c_int, ctypes.c_double, c_vp]
+    lib.dqc_becke_weights_grad.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_vp, c_dp, c_dp, c_dp, c_int, c_int, ctypes.c_double, c_vp]
     lib.dqc_purify_tc2.argtypes = [c_dp, c_dp, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
     lib.dqc_orth_factor.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_vp]
     lib.dqc_purify_tc2_batched.argtypes = [c_dp, c_dp, c_int, c_int, ctypes.c_double, c_int, ctypes.c_double, c_dp, c_vp]
@@ -108,6 +109,7 @@ def load():
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
     lib.dqc_grid_density_lr_pol.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
+    lib.dqc_grid_xc_gradient_terms.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_vp]
     lib.dqc_grid_density_lr_tau.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_int, c_vp]
     lib.dqc_grid_density_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_vp]
     lib.dqc_grid_vxc_pair.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_dp, c_dp, c_vp]
@@ -359,6 +361,19 @@ def becke_weights(xyz, atom_off, pos, inv_rij, aij, cut):
                                         _ptr(inv_rij.contiguous()), _ptr(aij.contiguous()), natm, ngrid, float(cut), st_),
                "dqc_becke_weights")
     return w
+
+
+def becke_weights_grad(cw, xyz, atom_off, pos, inv_rij, aij, cut):
+    """backward of becke_weights: cw (ngrid,) = dL/dw -> (gpos (natm, 3) explicit nuclear part, gxyz (ngrid, 3) point part)"""
+    ngrid, natm = xyz.shape[0], pos.shape[0]
+    gpos = torch.zeros((natm, 3), dtype=torch.float64, device=xyz.device)
+    gxyz = torch.empty((ngrid, 3), dtype=torch.float64, device=xyz.device)
+    scratch = torch.empty((natm, ngrid), dtype=torch.float64, device=xyz.device)
+    with _on(xyz.device) as st_:
+        _check(load().dqc_becke_weights_grad(_ptr(gpos), _ptr(gxyz), _ptr(scratch), _ptr(cw.contiguous()), _ptr(xyz.contiguous()),
+                                             ctypes.c_void_p(atom_off.data_ptr()), _ptr(pos.contiguous()), _ptr(inv_rij.contiguous()),
+                                             _ptr(aij.contiguous()), natm, ngrid, float(cut), st_), "dqc_becke_weights_grad")
+    return gpos, gxyz
 
 
 def xc_eval_mgga_pol2(terms, rho_u, rho_d, grho_u, grho_d, tau_u, tau_d, want_e=True, want_v=True):
@@ -702,6 +717,22 @@ def grid_density_lr_pol(ao, nao, factor_u, factor_d):
         _check(load().dqc_grid_density_lr_pol(_ptr(rho), _ptr(grho), _ptr(ao), ao.shape[0], ngrid, nao, _ptr(orb), _ptr(orbt), rp, st_),
                "dqc_grid_density_lr_pol")
     return rho, grho
+
+
+def grid_xc_gradient_terms(ao, nao, b, c, w, vrho, u, grho, vtau=None):
+    """per-point (ngrid, 3) and per-basis-function (nao, 3) grid sums of the XC nuclear gradient (dqc_amd/gradient.py) from one
+    pass over the deriv-3 AO array `ao` (10, ngrid, lda); b, c[0..2]: (ngrid, ldb) = Phi D, d_i Phi D"""
+    ngrid = ao.shape[-2]
+    q = torch.empty((ngrid, 3), dtype=torch.float64, device=ao.device)
+    per_ao = torch.empty((nao, 3), dtype=torch.float64, device=ao.device)
+    b, c0, c1, c2 = b.contiguous(), c[0].contiguous(), c[1].contiguous(), c[2].contiguous()
+    u, grho, w, vrho = u.contiguous(), grho.contiguous(), w.contiguous(), vrho.contiguous()
+    vt = None if vtau is None else vtau.contiguous()
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_xc_gradient_terms(_ptr(q), _ptr(per_ao), _ptr(ao), ngrid, nao, _ptr(b), _ptr(c0), _ptr(c1), _ptr(c2),
+                                                 b.shape[-1], _ptr(w), _ptr(vrho), _ptr(u), _ptr(grho), _ptr(vt), st_),
+               "dqc_grid_xc_gradient_terms")
+    return q, per_ao
 
 
 def grid_density_lr_tau(ao, nao, factor):

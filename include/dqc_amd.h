@@ -231,6 +231,12 @@ int dqc_df_grad(double *d_grad, const double *d_dcart, const double *d_ccart, co
  * mu >= cut are dropped (the reference's 0.74).  d_w (ngrid) <- P_own / sum_j P_j.  Enqueues only. */
 int dqc_becke_weights(double *d_w, const double *d_xyz, const int *d_atom_off, const double *d_pos,
                       const double *d_inv_rij, const double *d_aij, int natm, int ngrid, double cut, void *stream);
+/* Backward of dqc_becke_weights (the grid-response term of an XC nuclear gradient; the reference differentiates its torch expression
+ * dqc/grid/multiatoms_scheme.py:9-67 by autograd): d_cw (ngrid) = dL/dw; d_gpos (natm, 3) += sum_g cw dw_g/dR (explicit dependence
+ * on the nuclei), d_gxyz (ngrid, 3) = cw dw_g/dr_g; d_scratch natm * ngrid doubles.  Enqueues only. */
+int dqc_becke_weights_grad(double *d_gpos, double *d_gxyz, double *d_scratch, const double *d_cw, const double *d_xyz,
+                           const int *d_atom_off, const double *d_pos, const double *d_inv_rij, const double *d_aij,
+                           int natm, int ngrid, double cut, void *stream);
 
 /* ---- occupied-space projector without an eigensolver  (the `diagonalize` + `ao_orb2dm` step, hf.py:105-113, 227-247) --
  * Trace-correcting purification X <- X^2 | 2X - X^2 (by the sign of tr X - nocc), one fused fp64-MFMA launch per
@@ -293,6 +299,15 @@ int dqc_grid_density_lr(double *d_rho, double *d_grho, const double *d_ao, int n
  * d_rho (2, ngrid), d_grho (2, 3, ngrid); GGA form only.  Enqueues only. */
 int dqc_grid_density_lr_pol(double *d_rho, double *d_grho, const double *d_ao, int ncomp, int ngrid, int nao,
                             const double *d_orb, const double *d_orbt, int norb_pad_spin, void *stream);
+
+/* Grid sums of the XC part of a nuclear gradient, GGA / meta-GGA, one pass over the deriv-3 AO array (reference: autograd through
+ * eval_gradgto and _dm2densinfo, dqc/hamilton/intor/gtoeval.py:173-193, dqc/hamilton/hcgto.py:371-443; written out in
+ * dqc_amd/gradient.py).  d_ao (10, ngrid, lda): value, 3 gradients, xx xy xz yy yz zz; d_b = Phi D and d_c0..2 = d_i Phi D, (ngrid, ldb)
+ * each; d_u (3, ngrid) the gradient part of the potential, d_grho (3, ngrid), d_vtau (ngrid) or NULL.  Outputs: d_q (ngrid, 3) the
+ * per-point term of the atoms that carry the points, d_perao (nao, 3) the per-basis-function term (zeroed here).  Enqueues only. */
+int dqc_grid_xc_gradient_terms(double *d_q, double *d_perao, const double *d_ao, int ngrid, int nao, const double *d_b,
+                               const double *d_c0, const double *d_c1, const double *d_c2, int ldb, const double *d_w,
+                               const double *d_vrho, const double *d_u, const double *d_grho, const double *d_vtau, void *stream);
 
 /* meta-GGA densities of D = L L^T from ONE pass over the four AO components: rho, grad rho (3, ngrid) and
  * tau = 1/2 sum_d sum_r (d_d Phi . L)_r^2 (hcgto.py:398-438 with D in factor form) -- four rank-r GEMMs, no row-dot epilogue;
