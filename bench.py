@@ -874,7 +874,46 @@ def f_row_legs(dev, K=10):
         torch.cuda.synchronize()
         out["gradient"] = {"seconds": time.perf_counter() - t0, "sum_of_forces_abs_max": float(g.sum(0).abs().max()),
                            "what": "C5 molecule 0, analytic nuclear gradient of the converged RKS PBE energy (derivative ERIs, int1e, XC terms)"}
-        del qg
+        # its parts, each timed on its own (HIP events on the launch stream), with the roof that bounds the XC grid pass
+        from dqc_amd import gradient as G
+        eg, hg = qg._engine, qg._engine.hamilton
+        Xg = hg._orthozer
+        dg = Xg @ qg._dm @ Xg.T
+        dg = (dg + dg.T) * 0.5
+        Tg = lib.cart2sph_matrix(hg._tab, dev)
+        dcg = (Tg.T @ dg @ Tg).contiguous()
+        gacc = torch.zeros((len(geo[0]), 3), dtype=torch.float64, device=dev)
+
+        def ev_ms(fn, k=3):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / k
+        parts = {"eri_grad_ms": ev_ms(lambda: lib.eri_grad(gacc, dcg, 0.0, hg._tab)),
+                 "int1e_grad_ms": ev_ms(lambda: lib.int1e_grad(gacc, dcg, dcg, hg._tab, hg._zs)),
+                 "xc_gradient_ms": ev_ms(lambda: G._xc_gradient(eg, [dg]))}
+        ao3 = lib.eval_gto(hg._tab, hg.rgrid, 3)
+        dpg = lib.pad_matrix(dg, hg._ld)
+        ldg = ao3.shape[-1]
+        bg = ao3[0] @ dpg[:ldg, :ldg]
+        cg = [ao3[1 + i] @ dpg[:ldg, :ldg] for i in range(3)]
+        rg, grg = lib.grid_density(ao3[:4], hg._nao_ao, dpg, True)
+        from dqc_amd.utils.datastruct import ValGrad
+        pg = hg.xc.get_vxc(ValGrad(value=rg, grad=grg))
+        tk = ev_ms(lambda: lib.grid_xc_gradient_terms(ao3, hg._nao_ao, bg, cg, hg.dvolume, pg.value, pg.grad, grg))
+        kb = 8.0 * hg.rgrid.shape[0] * (9 * hg._nao_ao + 4 * hg._nao_ao + 12)  # nine derivative arrays + b, c0..2 + per-point in/out
+        parts["xc_terms_kernel"] = {"ms": tk, "algorithmic_bytes": kb, "bound": "hbm", "achieved": kb / (tk * 1e-3) / 1e9, "unit": "GB/s",
+                                    "peak": HBM_PEAK_GBS, "frac": kb / (tk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        parts["note"] = ("eri_grad: derivative shell quartets (one launch per class, up / down companions of every bra shell: a "
+                         "VALU / LDS recurrence kernel like the fill, no stream roof -- ~8x the fill's quartets at one unit of angular "
+                         "momentum more); xc_gradient: deriv-3 AO evaluation, Phi D and d Phi D GEMMs, the fused grid-sum kernel "
+                         "(xc_terms_kernel) and the analytic Becke-weight derivative")
+        out["gradient"]["parts"] = parts
+        del qg, ao3, bg, cg
     except Exception as e:  # noqa: BLE001
         import traceback
         out["error"] = repr(e)[:300] + " | " + traceback.format_exc()[-600:]

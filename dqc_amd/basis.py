@@ -206,11 +206,15 @@ def product_etb_aux(atomz: int, orb_bases: List[CGTOBasis], beta: float = 2.0, d
 _FIT_NAMES = ("jkfit", "jfit", "rifit", "ri", "autoaux")
 
 
-def make_aux_atombases(atomzs, atompos, auxbasis, orb_atombases=None) -> List[AtomCGTOBasis]:
+def make_aux_atombases(atomzs, atompos, auxbasis, orb_atombases=None, info=None) -> List[AtomCGTOBasis]:
     """auxbasis: per-atom lists of CGTOBasis, a basis name with Gaussian94 tables under dqc_amd/data/basis or $DQC_AMD_BASIS_PATH,
     "etb[:beta]" (fixed even-tempered rows) or "autoaux[:beta]" (generated from the orbital basis, product_etb_aux).  A NAMED
     fitting set ("cc-pvtz-jkfit", the reference's default, mol.py:190-193; "def2-universal-jkfit", ...) whose tables are not
     there falls back to "autoaux" with a warning -- the reference would download it from basis_set_exchange."""
+    # info (a dict, optional) receives "auxbasis_used": the set the shells really come from -- a named fitting set without tables is
+    # replaced by the generated one, and a benchmark or test has to be able to assert on that
+    if info is not None:
+        info["auxbasis_used"] = auxbasis if isinstance(auxbasis, str) else "explicit shells"
     if isinstance(auxbasis, str):
         name = auxbasis.lower()
         if name.startswith("etb"):
@@ -226,6 +230,8 @@ def make_aux_atombases(atomzs, atompos, auxbasis, orb_atombases=None) -> List[At
                                   "fitting sets are external data, not shipped); using the generated set auxbasis='autoaux' instead"
                                   % (auxbasis, sorted(set(missing))))
                     gen = True
+                    if info is not None:
+                        info["auxbasis_used"] = "autoaux (generated: no tables for %r)" % auxbasis
             if gen:
                 if orb_atombases is None:
                     raise RuntimeError("auxbasis='autoaux' is generated from the orbital basis: pass the orbital atom bases")

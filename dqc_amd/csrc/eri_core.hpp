@@ -744,7 +744,11 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 cart_pow(LA, cu, u[0], u[1], u[2]);
                 const size_t ib = cb0 + cb, ic = cc0 + cc, id = cd0 + cd;
                 double dcd = 0.0, dbd = 0.0, dbc = 0.0;
-                if (og.gmode == 0) { dcd = D[ic * nc + id]; dbd = D[ib * nc + id]; dbc = D[ib * nc + ic]; }
+                const bool with_k = og.kscale != 0.0;  // (Kohn-Sham: Coulomb-type product only -- four density loads per output fewer)
+                if (og.gmode == 0) {
+                    dcd = D[ic * nc + id];
+                    if (with_k) { dbd = D[ib * nc + id]; dbc = D[ib * nc + ic]; }
+                }
 #pragma unroll
                 for (int dir = 0; dir < 3; dir++) {
                     int o[3] = {u[0], u[1], u[2]};
@@ -759,9 +763,10 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                     }
                     const size_t ia = ca0 + cart_index(la, o[0], o[2]);
                     double f;
-                    if (og.gmode == 0)
-                        f = jfac * D[ia * nc + ib] * dcd -
-                            og.kscale * (D[ia * nc + ic] * dbd + (same_cd ? 0.0 : D[ia * nc + id] * dbc));
+                    if (og.gmode == 0) {
+                        f = jfac * D[ia * nc + ib] * dcd;
+                        if (with_k) f -= og.kscale * (D[ia * nc + ic] * dbd + (same_cd ? 0.0 : D[ia * nc + id] * dbc));
+                    }
                     else if (og.gmode == 1)
                         f = 2.0 * D[ia * nc + ib] * og.ccart[ic];
                     else

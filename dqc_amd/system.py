@@ -136,11 +136,14 @@ class Mol:
             method = "coulomb"
         if auxbasis is None:
             auxbasis = "cc-pvtz-jkfit"
-        auxbases = make_aux_atombases(self._atomzs, self._atompos, auxbasis, self._atombases)
+        info = {}
+        auxbases = make_aux_atombases(self._atomzs, self._atompos, auxbasis, self._atombases, info)
+        self.auxbasis_used = info["auxbasis_used"]  # (what the fit really uses: "autoaux (generated ...)" when the named set has no tables)
         df = DensityFitInfo(method=method, auxbases=auxbases)
         self._hamilton = HamiltonMI355(self._atombases, spherical=True, df=df, efield=self._efield, vext=self._vext,
                                        orthozer=self._orthogonalize_basis, aoparamzer=self._aoparamzer,
                                        device=self._device)
+        self._hamilton.auxbasis_used = self.auxbasis_used
         return self
 
     def get_hamiltonian(self):
