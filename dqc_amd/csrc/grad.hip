@@ -89,6 +89,7 @@ struct GradCtx {
     const HostPairs *hbra, *hket;
     EriOut og;
     DevPool *pool = nullptr;  // stream-ordered pool for the wave tables (nullptr: flat task maps)
+    int wmap_depth = 1 << 30;  // class pairs whose deepest contraction has at least this many primitive quartets take the wave map
 };
 
 template <int LA, int LB, int LC, int LD>
@@ -101,7 +102,10 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_G);
-    if (Cfg::TPQ <= 16 && c.pool != nullptr) {
+    // (only where the class pair's deepest contraction -- first pair of each class: the lists are sorted by depth -- is worth splitting)
+    const int dmax = (c.hbra->pp_off[c.hbra->cls_start[cb] + 1] - c.hbra->pp_off[c.hbra->cls_start[cb]]) *
+                     (c.hket->pp_off[c.hket->cls_start[ck] + 1] - c.hket->pp_off[c.hket->cls_start[ck]]);
+    if (Cfg::TPQ <= 16 && c.pool != nullptr && dmax >= c.wmap_depth) {
         // depth-binned wave map (eri_core.hpp: eri_split_lanes, eri_wave_table): the deep (companion, s) x (s, s) contractions were
         // serial chains in single lane groups
         std::vector<WaveRun> runs;
@@ -393,11 +397,12 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     if ((rc = boys_table_ensure())) return rc;
     DevPool pool;
     GradCtx c;
-    // the depth-binned wave map of the fill (eri_core.hpp) is OFF here by default: measured 0.16 s against 0.11 s for the flat
-    // task maps on a 20-atom cc-pVDZ gradient (DQC_GRAD_WMAP=1 turns it on for A/B runs)
+    // the depth-binned wave map of the fill (eri_core.hpp) is OFF here: measured on a 20-atom cc-pVDZ gradient it is slower for every
+    // depth threshold -- 0.160 s (classes deeper than 64 primitive quartets), 0.149 (256), 0.140 (1024) against 0.107 s for the flat
+    // task maps (DQC_GRAD_WMAP = the depth threshold for A/B runs, 0 / unset = never)
     DevPool wpool(st);
-    static const bool wmap_env = [] { const char *e = getenv("DQC_GRAD_WMAP"); return e && e[0] == '1'; }();
-    if (wmap_env) c.pool = &wpool;
+    static const int wmap_env = [] { const char *e = getenv("DQC_GRAD_WMAP"); return e ? atoi(e) : 0; }();
+    if (wmap_env > 0) { c.pool = &wpool; c.wmap_depth = wmap_env; }
     if ((rc = upload_shells(c.ds, b, pool, st))) { set_error("dqc_eri_grad: device upload failed"); return rc; }
     auto up = [&](HostPairs &hp, DevPairs &dp) {
         int *d_sh = nullptr, *d_off = nullptr;
