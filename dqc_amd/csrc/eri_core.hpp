@@ -311,6 +311,14 @@ DQC_DEV bool screen_skip(const EriOut &og, int ib, int ik, int ish, int jsh, int
     return og.pq[ib] * og.pq[ik] * m < og.tau;
 }
 
+// 1 / x from v_rcp_f64 and two Newton steps (x > 0, normal range: Gaussian exponent sums)
+DQC_DEV double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
 // index of the Cartesian component (lx, ly, lz) of shell l (inverse of cart_pow)
 DQC_DEV int cart_index(int l, int lx, int lz) {
     const int row = l - lx;
@@ -587,22 +595,29 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
             }
         }
-    } else
+    } else {
+    const float inv_nkp = 1.0f / (float)(nkp > 0 ? nkp : 1);
     for (int iq = psj; iq < maxq; iq += psl) {  // (psl = 1, psj = 0 except under the wave map)
         const bool on = iq < nq;
         // ---------------- phase A: 2D integrals for every (direction, root) ----------------
-        const int ipb = on ? iq / nkp : 0, ipk = on ? iq - ipb * nkp : 0;
+        // (iq / nkp through a float reciprocal: exact for iq < 2^22 -- (iq + 1/2) / nkp stays 1 / (2 nkp) away from the integers --
+        // where the integer division costs ~25 instructions per primitive quartet)
+        const int ipb = on ? (int)(((float)iq + 0.5f) * inv_nkp) : 0, ipk = on ? iq - ipb * nkp : 0;
         const double *pb = prs.pp + (size_t)(pb0 + ipb) * prs.stride, *pk = prk.pp + (size_t)(pk0 + ipk) * prk.stride;
         if (on) {
             const double p = pb[0], qq = pk[0];
             const double P[3] = {pb[1], pb[2], pb[3]}, Q[3] = {pk[1], pk[2], pk[3]};
-            const double pq = p + qq, rho = p * qq / pq;
+            // reciprocals once per primitive quartet (the recurrence coefficients below were five fp64 divisions per item) -- and
+            // none of them a full IEEE division: 1 / (p + q) and its square root from ONE rsqrt, 1 / p and 1 / q from the hardware
+            // reciprocal refined by two Newton steps (error ~1 ulp; a division expands to ~13 instructions, four of them plus a
+            // square root per primitive quartet were a sixth of the loop of the small classes)
+            const double pq = p + qq;
+            const double rs_ = rsqrt(pq), ipq = rs_ * rs_, rho = p * qq * ipq;
             const double PQ[3] = {P[0] - Q[0], P[1] - Q[1], P[2] - Q[2]};
             const double X = rho * (PQ[0] * PQ[0] + PQ[1] * PQ[1] + PQ[2] * PQ[2]);
-            // reciprocals once per primitive quartet: the recurrence coefficients below were five fp64 divisions per item
-            const double ipq = 1.0 / pq, ip = 1.0 / p, iqq = 1.0 / qq;
+            const double ip = fast_rcp(p), iqq = fast_rcp(qq);
             // 2 pi^(5/2) K_ab K_cd / (p q sqrt(p + q)): the table holds K / p (grouped: coefficients applied in phase B)
-            const double pref = (NE == 1 ? pb[4] * pk[4] : 1.0) * 34.986836655249725 * sqrt(ipq);
+            const double pref = (NE == 1 ? pb[4] * pk[4] : 1.0) * 34.986836655249725 * rs_;
             // the NR roots depend on X only, not on the direction: lane s of the quartet's group evaluates root s % NR ONCE and
             // the (direction, root) items fetch theirs by shuffle (a one-lane group loops over all roots) -- per item this
             // was a Clenshaw evaluation of its own, i.e. three times the work in groups of 1 or 4 lanes
@@ -715,6 +730,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         eri_group_sync<TPQ>();
     }
 
+    }  // (general path)
     if constexpr (TPQ <= 16) {
         // the lane groups that shared the quartet's primitive quartets combine their partial sums (every group ends with the total)
         for (int o = 1; o < psl; o <<= 1)
