@@ -265,6 +265,8 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(double *__restrict__ gra
     const double *dblk = dcart + (size_t)cao[ish] * nc + cao[jsh];
     const double *wblk = wcart + (size_t)cao[ish] * nc + cao[jsh];
     double ga[3] = {0.0, 0.0, 0.0};  // basis-centre terms, go to a's atom
+    const bool one_nuc = (int)gridDim.y >= natm;
+    double gn[3] = {0.0, 0.0, 0.0};  // operator-derivative term of this thread's nucleus (one_nuc)
     for (int ip = 0; ip < sh.nprim[ish]; ip++)
         for (int jp = 0; jp < sh.nprim[jsh]; jp++) {
             const double a = sh.exps[sh.prim_off[ish] + ip], b = sh.exps[sh.prim_off[jsh] + jp];
@@ -323,11 +325,16 @@ __global__ __launch_bounds__(64) void int1e_grad_kernel(double *__restrict__ gra
                 }
                 for (int d = 0; d < 3; d++) {
                     ga[d] += g3[d];
-                    atomicAdd(&grad[ic * 3 + d], -2.0 * g3[d]);
+                    // (one nucleus per thread when the launch has a y-slice per nucleus: its operator-derivative term is summed over
+                    // the primitive pairs and added once -- 35 M atomics on 60 addresses were most of this kernel's time)
+                    if (one_nuc) gn[d] += g3[d];
+                    else atomicAdd(&grad[ic * 3 + d], -2.0 * g3[d]);
                 }
             }
         }
     for (int d = 0; d < 3; d++) atomicAdd(&grad[sh_atom[ish] * 3 + d], 2.0 * ga[d]);
+    if (one_nuc)
+        for (int d = 0; d < 3; d++) atomicAdd(&grad[blockIdx.y * 3 + d], -2.0 * gn[d]);
 }
 
 }  // namespace dqc

@@ -14,7 +14,7 @@ namespace dqc {
 // used by the GGA nuclear gradient)
 template <int DERIV>
 __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, const double *__restrict__ coords,
-                                                       int ngrid, int nao, int ld, DevShells sh) {
+                                                       int ngrid, int nao, int ld, DevShells sh, int colrange) {
     constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : (DERIV == 2 ? 5 : 10));
     // columns staged per flush.  The tile is what bounds the occupancy (one wave per block): 16 columns x 4 components = 35 KB
     // allowed 4 waves per CU and the kernel wrote at 1 TB/s (round 3); 8 columns (4 with the ten components of DERIV 3) let
@@ -29,7 +29,12 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
     const double px = coords[g * 3], py = coords[g * 3 + 1], pz = coords[g * 3 + 2];
     const size_t cstride = (size_t)ngrid * ld;
 
-    int col0 = 0;     // first AO column held in the tile
+    // grid.y splits the AO columns into ranges of `colrange` (a multiple of GTO_CW): a block evaluates the shells that reach into
+    // its range and stores the columns inside it.  One wave used to walk ALL shells of its 64 points (a 20-atom cc-pVDZ molecule:
+    // 96 shells, 236 exponentials per point) with 6-8 waves per CU: 1.0 ms = 2.2 TB/s of writes for the four GGA components.
+    const int cbeg = blockIdx.y * colrange, cend = min(cbeg + colrange, ld);
+    if (cbeg >= ld) return;
+    int col0 = cbeg;  // first AO column held in the tile
     int nfill = 0;    // columns filled
     auto flush = [&](int ncols) {
         // tile[wave][c][p][j] -> out[c][g0+p][col0+j]; lanes sweep (p, j) with j fastest
@@ -55,6 +60,8 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
 
     for (int is = 0; is < sh.nsh; is++) {
         const int l = sh.l[is], np = sh.nprim[is], po = sh.prim_off[is];
+        const int a0 = sh.ao_off[is];
+        if (a0 + 2 * l + 1 <= cbeg || a0 >= cend) continue;  // (uniform: the shell has no column in this block's range)
         const double x = px - sh.xyz[is * 3], y = py - sh.xyz[is * 3 + 1], z = pz - sh.xyz[is * 3 + 2];
         const double r2 = x * x + y * y + z * z;
         double e0 = 0, e1 = 0, e2 = 0;
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
         const int nc = (l + 1) * (l + 2) / 2, ns = 2 * l + 1;
         const double *C = C2S + C2S_OFF[l];
         for (int m = 0; m < ns; m++) {
+            if (a0 + m < cbeg || a0 + m >= cend) continue;  // (a shell straddling two ranges is evaluated by both blocks)
             double v = 0, vx = 0, vy = 0, vz = 0, vl = 0;
             double hxx = 0, hxy = 0, hxz = 0, hyy = 0, hyz = 0, hzz = 0;
             int c = 0;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
         }
     }
     // zero padding columns nao..ld-1 (ld = the arrays' row stride, dqc_ao_stride: ld - nao < 16)
-    while (col0 + nfill < ld) {
+    while (col0 + nfill < cend) {
         for (int c = 0; c < NC; c++) tile[wave][c][lane][nfill] = 0.0;
         nfill++;
         if (nfill == GTO_CW) {
@@ -163,18 +171,22 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
     if (ngrid > 0) {
         int nblk = (ngrid + 63) / 64;
         const int ld = dqc_ao_stride(b.nao);
+        // column ranges (grid.y): four where the basis is wide enough, every range a whole number of flush tiles
+        const int cw = deriv == 0 ? 16 : (deriv == 3 ? 4 : 8), nsplit = ld >= 64 ? 4 : 1;
+        const int colrange = ((ld + nsplit - 1) / nsplit + cw - 1) / cw * cw;
+        const dim3 grid(nblk, (ld + colrange - 1) / colrange);
         const int ncomp = deriv == 0 ? 1 : (deriv == 1 ? 4 : (deriv == 2 ? 5 : 10));
         // the slack the grid kernels may read past the last row (dqc_ao_doubles): zeros
         const size_t body = (size_t)ncomp * (size_t)ngrid * ld, slack = dqc_ao_doubles(ncomp, ngrid, b.nao) - body;
         if (slack) DQC_HIP(hipMemsetAsync(d_out + body, 0, slack * sizeof(double), st));
         if (deriv == 0)
-            hipLaunchKernelGGL(eval_gto_kernel<0>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+            hipLaunchKernelGGL(eval_gto_kernel<0>, grid, dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds, colrange);
         else if (deriv == 1)
-            hipLaunchKernelGGL(eval_gto_kernel<1>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+            hipLaunchKernelGGL(eval_gto_kernel<1>, grid, dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds, colrange);
         else if (deriv == 2)
-            hipLaunchKernelGGL(eval_gto_kernel<2>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+            hipLaunchKernelGGL(eval_gto_kernel<2>, grid, dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds, colrange);
         else
-            hipLaunchKernelGGL(eval_gto_kernel<3>, dim3(nblk), dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds);
+            hipLaunchKernelGGL(eval_gto_kernel<3>, grid, dim3(64), 0, st, d_out, d_coords, ngrid, b.nao, ld, ds, colrange);
         DQC_CHECK_LAUNCH();
     }
     return DQC_OK;

@@ -53,9 +53,16 @@ def nuclear_gradient(qc) -> torch.Tensor:
     norbs = [eng.norb.u, eng.norb.d] if pol else [eng.norb]
     d_aos, w_ao = [], 0.0
     for dm, fock, w, n in zip(dms, focks, weights, norbs):
-        eps, C = eng._eigpairs(fock)  # generalised problem when the basis is not orthogonalised
-        Cocc = C[:, :n]
-        w_ao = w_ao + X @ ((Cocc * (w * eps[:n]).unsqueeze(0)) @ Cocc.T) @ X.T     # energy-weighted density
+        uniform = w.numel() > 0 and getattr(eng, "_sinvh", None) is None and bool((w == w[0]).all())
+        if uniform:
+            # equal occupations w0 in an orthonormal basis: D = w0 P with P the projector on the occupied space, and at the fixed
+            # point sum_i w0 eps_i c_i c_i^T = w0 P F P = D F D / w0 -- no diagonalisation (a 208 x 208 eigh was 3 ms of the gradient)
+            fs = (fock + fock.T) * 0.5
+            w_ao = w_ao + X @ ((dm @ fs @ dm) / w[0]) @ X.T
+        else:
+            eps, C = eng._eigpairs(fock)  # generalised problem when the basis is not orthogonalised
+            Cocc = C[:, :n]
+            w_ao = w_ao + X @ ((Cocc * (w * eps[:n]).unsqueeze(0)) @ Cocc.T) @ X.T     # energy-weighted density
         d = X @ dm @ X.T
         d_aos.append((d + d.T) * 0.5)
     d_tot = sum(d_aos)
