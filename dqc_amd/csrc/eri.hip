@@ -171,9 +171,12 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
         nblk = Cfg::TPQ == 1 ? (ntask + 3) / 4 : (ntask + Cfg::QPB - 1) / Cfg::QPB;
     }
     nblk = (nblk + o2.nparts - 1) / o2.nparts;  // this rank's share of the blocks (dqc_direct_jk_part)
-    auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
-    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_JK);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES_JK, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
+    // Coulomb only (Kohn-Sham): the mode without the exchange accumulators in LDS (eri_core.hpp: ERI_OUT_J)
+    const bool jonly = o2.kacc == nullptr;
+    auto kern = jonly ? eri_kernel<LA, LB, LC, LD, ERI_OUT_J> : eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
+    const size_t lds_bytes = jonly ? Cfg::LDS_BYTES : Cfg::LDS_BYTES_JK;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
                        nb, hp.cls_start[ck], nk, same, ntask, o2);
     DQC_CHECK_LAUNCH();
     return 0;

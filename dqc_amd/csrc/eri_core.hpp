@@ -190,7 +190,11 @@ struct OidxTab {
 //   ERI_OUT_SCHWARZ : the diagonal quartets (ab|ab) only (task map `same` = 2): max over the spherical block of |(ab|ab)| per
 //                   shell pair -> tiles[pair] (as the bit pattern of a non-negative double, atomicMax) -- the Schwarz bounds
 //                   Q_ab = sqrt(max |(ab|ab)|), |(ab|cd)| <= Q_ab Q_cd, of the screened direct SCF (dqc_direct_*)
-enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3, ERI_OUT_JK = 4, ERI_OUT_SCHWARZ = 5 };
+//   ERI_OUT_J     : ERI_OUT_JK without the exchange blocks (Kohn-Sham builds).  The Coulomb products need no LDS accumulators (two
+//                   matrix-vector passes over the block, see the kernel), so this mode keeps the fill's LDS footprint -- the
+//                   six accumulator blocks of ERI_OUT_JK (294 doubles per quartet for (ff|ff)) halve the occupancy of the
+//                   high-angular-momentum classes
+enum { ERI_OUT_TILES = 0, ERI_OUT_3C = 1, ERI_OUT_2C = 2, ERI_OUT_GRAD = 3, ERI_OUT_JK = 4, ERI_OUT_SCHWARZ = 5, ERI_OUT_J = 6 };
 
 // lane-group size of a compile-time class by its Cartesian block size (EriCfg::TPQ; the host's screened task maps need it too)
 __host__ __device__ constexpr int eri_tpq(int nout) { return nout <= 9 ? 1 : (nout <= 81 ? 4 : (nout <= 324 ? 16 : (nout <= 1296 ? 64 : 256))); }
@@ -378,7 +382,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     using Cfg = EriCfg<LA, LB, LC, LD>;
     // member combinations of a grouped quartet (1: ordinary shell quartets, the tables may have any stride)
     constexpr int NE = NPB * NPK;
-    static_assert(NE == 1 || MODE == ERI_OUT_TILES || MODE == ERI_OUT_JK || MODE == ERI_OUT_SCHWARZ, "grouped tables: fill / direct modes only");
+    static_assert(NE == 1 || MODE == ERI_OUT_TILES || MODE == ERI_OUT_JK || MODE == ERI_OUT_J || MODE == ERI_OUT_SCHWARZ, "grouped tables: fill / direct modes only");
+    constexpr bool DIRECT = MODE == ERI_OUT_JK || MODE == ERI_OUT_J;  // digestion with the density, nothing stored
     static_assert((NPB == 1 || NPB == PairSlots<LA, LB>::N) && (NPK == 1 || NPK == PairSlots<LC, LD>::N), "slot count of the pair class");
     constexpr int NR = Cfg::NR, TPQ = Cfg::TPQ, QPB = Cfg::QPB, NPT = Cfg::NPT, G1 = Cfg::G1, NOUT = Cfg::NOUT;
     constexpr int NMAX = LA + LB, MMAX = LC + LD;
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     ib += b0;
     ik += k0;
     const int ish = prs.sh[2 * ib], jsh = prs.sh[2 * ib + 1], ksh = prk.sh[2 * ik], lsh = prk.sh[2 * ik + 1];
-    if constexpr (MODE == ERI_OUT_JK)
+    if constexpr (DIRECT)
         if (og.pq != nullptr && active && screen_skip(og, ib, ik, ish, jsh, ksh, lsh)) active = false;
     double A[3], Cc[3], AB[3], CD[3];
 #pragma unroll
@@ -877,7 +882,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         double *t_ = cur; cur = oth; oth = t_;
         eri_group_sync<TPQ>();
     }
-    if (act) {
+    if (MODE != ERI_OUT_J && act) {  // (the Coulomb-only direct mode digests the block in the passes below: no per-element work)
         // scatter: value (ma, mb, mc, md) -> all block-canonical images (md fastest over the lanes: runs of consecutive addresses)
         constexpr double S0 = 0.28209479177387864;  // the l = 0 solid harmonic
         constexpr double SCALE = (LA == 0 ? S0 : 1.0) * (LB == 0 ? S0 : 1.0) * (LC == 0 ? S0 : 1.0) * (LD == 0 ? S0 : 1.0);
@@ -919,36 +924,74 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             }
         }
     }
-    if constexpr (MODE == ERI_OUT_JK) {
+    if constexpr (DIRECT) {
         // Coulomb products of the block V[ab][cd] (in `cur`): J_ab += sum_cd V D_cd (a lane per row, the density element uniform
         // over the lanes) and J_cd += sum_ab V D_ab (a lane per column, stride-1 LDS reads), one global atomic per result.  Round 4
         // added v D to LDS accumulators element by element: two ds_add_f64 per integral, up to 49 lanes on one address -- the
         // output phase of an unscreened naphthalene / cc-pVTZ pass took 66 of 121 ms.
-        if (act) {
+        // The lane groups of a wave mostly share one of their two pairs -- the bra pair under the flat / screened maps of the
+        // multi-lane classes (consecutive tasks: one bra pair, consecutive ket pairs), the ket pair under the wave-transposed map
+        // of the one-lane classes -- so that block's results are summed across the groups (shuffle butterfly) and added ONCE
+        // per wave: the ~1.8e9 global fp64 atomics of an unscreened naphthalene / cc-pVTZ pass were 24 ms of its 105.
+        {
             constexpr double S0_ = 0.28209479177387864;
             constexpr double SCALE_ = (LA == 0 ? S0_ : 1.0) * (LB == 0 ? S0_ : 1.0) * (LC == 0 ? S0_ : 1.0) * (LD == 0 ? S0_ : 1.0);
             constexpr int NAB = Cfg::SA * Cfg::SB, NCDS = Cfg::SC * Cfg::SD;
-            const double degj = 4.0 * SCALE_ * (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0);
+            const double degj = act ? 4.0 * SCALE_ * (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0) : 0.0;
             const double *D = og.dmat;
             const size_t n = og.nao;
-            for (int ab = s; ab < NAB; ab += TPQ) {
-                const double *row = cur + ab * NCDS;
-                double a_ = 0.0;
-#pragma unroll
-                for (int mc = 0; mc < Cfg::SC; mc++)
-#pragma unroll
-                    for (int md = 0; md < Cfg::SD; md++) a_ += row[mc * Cfg::SD + md] * D[(size_t)(ak + mc) * n + al + md];
-                atomicAdd(og.jacc + (size_t)(ai + ab / Cfg::SB) * n + aj + ab % Cfg::SB, degj * a_);
+            // wave-uniform shared pair?  (only single-combination launches: the members of a grouped quartet have their own offsets)
+            constexpr bool CAN_SHARE = NE == 1 && TPQ <= 32;
+            bool share_ab = false, share_cd = false;
+            int ai0 = ai, aj0 = aj, ak0 = ak, al0 = al;
+            if constexpr (CAN_SHARE) {
+                const unsigned long long am = __ballot(act);
+                if (am != 0ull) {
+                    const int first = __ffsll((long long)am) - 1;
+                    ai0 = __shfl(ai, first); aj0 = __shfl(aj, first); ak0 = __shfl(ak, first); al0 = __shfl(al, first);
+                    if constexpr (TPQ > 1) share_ab = __all(!act || (ai == ai0 && aj == aj0));
+                    else share_cd = __all(!act || (ak == ak0 && al == al0));
+                }
             }
+            const int grp0 = (tid & 63) < TPQ;  // the lanes of the wave's first lane group issue the shared block's atomics
+            if (share_ab || act)
+            for (int ab = s; ab < NAB; ab += TPQ) {
+                double a_ = 0.0;
+                if (act) {
+                    const double *row = cur + ab * NCDS;
+#pragma unroll
+                    for (int mc = 0; mc < Cfg::SC; mc++)
+#pragma unroll
+                        for (int md = 0; md < Cfg::SD; md++) a_ += row[mc * Cfg::SD + md] * D[(size_t)(ak + mc) * n + al + md];
+                    a_ *= degj;
+                }
+                if (share_ab) {
+                    for (int o = TPQ; o < 64; o <<= 1) a_ += __shfl_xor(a_, o);
+                    if (grp0 && a_ != 0.0) atomicAdd(og.jacc + (size_t)(ai0 + ab / Cfg::SB) * n + aj0 + ab % Cfg::SB, a_);
+                } else if (act) {
+                    atomicAdd(og.jacc + (size_t)(ai + ab / Cfg::SB) * n + aj + ab % Cfg::SB, a_);
+                }
+            }
+            if (share_cd || act)
             for (int cd = s; cd < NCDS; cd += TPQ) {
                 double a_ = 0.0;
+                if (act) {
 #pragma unroll
-                for (int ma = 0; ma < Cfg::SA; ma++)
+                    for (int ma = 0; ma < Cfg::SA; ma++)
 #pragma unroll
-                    for (int mb = 0; mb < Cfg::SB; mb++) a_ += cur[(ma * Cfg::SB + mb) * NCDS + cd] * D[(size_t)(ai + ma) * n + aj + mb];
-                atomicAdd(og.jacc + (size_t)(ak + cd / Cfg::SD) * n + al + cd % Cfg::SD, degj * a_);
+                        for (int mb = 0; mb < Cfg::SB; mb++) a_ += cur[(ma * Cfg::SB + mb) * NCDS + cd] * D[(size_t)(ai + ma) * n + aj + mb];
+                    a_ *= degj;
+                }
+                if (share_cd) {
+                    for (int o = 1; o < 64; o <<= 1) a_ += __shfl_xor(a_, o);
+                    if ((tid & 63) == 0 && a_ != 0.0) atomicAdd(og.jacc + (size_t)(ak0 + cd / Cfg::SD) * n + al0 + cd % Cfg::SD, a_);
+                } else if (act) {
+                    atomicAdd(og.jacc + (size_t)(ak + cd / Cfg::SD) * n + al + cd % Cfg::SD, a_);
+                }
             }
         }
+    }
+    if constexpr (MODE == ERI_OUT_JK) {
         // one atomic per element of the four exchange blocks.  Every unique quartet is visited once (pairs a >= b, c >= d,
         // bra pair >= ket pair): the eight permutational images are covered by accumulating A_ab, A_cd (J = (A + A^T) / 2)
         // and B_ac, B_ad, B_bc, B_bd (K = B + B^T) with 1/2 per coincidence a == b, c == d, (ab) == (cd)
