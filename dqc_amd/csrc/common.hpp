@@ -96,10 +96,12 @@ struct Basis {
     // member shell over the same exponents: its AO offset (-1: none) and its coefficients (same indexing as coefs; 0: none)
     std::vector<int> ao_off1;
     std::vector<double> coefs1;
+    std::vector<int> sh_id0, sh_id1;  // the members' indices in the original shell table (sh_id1 = -1: none)
     bool grouped() const { return !ao_off1.empty(); }
 };
-// merge the s shells of one atom that share their exponent list, two per group (host.hip)
-void group_s_shells(const Basis &b, Basis &g);
+// grouped view of a basis: the s shells of one atom that share their exponent list are merged, two per group (host.hip);
+// merge = false: every shell its own group (the tables then only have the grouped LAYOUT)
+void group_s_shells(const Basis &b, Basis &g, bool merge = true);
 
 // returns 0 or DQC_EINVAL
 int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, const double *env,

@@ -89,7 +89,8 @@ static int launch_class(double *tiles, const DevShells &ds, const FillTables &ft
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     // grouped tables (general contractions merged: eri_core.hpp): the instantiation with the coefficient slots of the two pair classes
     constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
-    auto kern = dpb.stride == PP_STRIDE_G ? eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES>;
+    if (dpb.stride != PP_STRIDE_G || dpk.stride != PP_STRIDE_G) { set_error("eri fill: pair tables without the grouped layout"); return DQC_EINVAL; }
+    auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_TILES, NPB, NPK>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     // lane groups of <= 16 lanes: depth-binned wave map (eri_core.hpp: eri_split_lanes, eri_wave_table) -- where the class pair has
     // contractions deep enough to be split at all (pairs are sorted by depth: the first pair of a class is its deepest); the
@@ -173,7 +174,9 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
     nblk = (nblk + o2.nparts - 1) / o2.nparts;  // this rank's share of the blocks (dqc_direct_jk_part)
     // Coulomb only (Kohn-Sham): the mode without the exchange accumulators in LDS (eri_core.hpp: ERI_OUT_J)
     const bool jonly = o2.kacc == nullptr;
-    auto kern = jonly ? eri_kernel<LA, LB, LC, LD, ERI_OUT_J> : eri_kernel<LA, LB, LC, LD, ERI_OUT_JK>;
+    if (dp.stride != PP_STRIDE_G) { set_error("direct J / K: pair tables without the grouped layout"); return DQC_EINVAL; }
+    constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
+    auto kern = jonly ? eri_kernel<LA, LB, LC, LD, ERI_OUT_J, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_JK, NPB, NPK>;
     const size_t lds_bytes = jonly ? Cfg::LDS_BYTES : Cfg::LDS_BYTES_JK;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
@@ -204,7 +207,8 @@ struct ClassLoopSchwarz {
         using Cfg = EriCfg<LA, LB, LA, LB>;
         const int nb = hp.cls_count[CB];
         if (nb > 0 && !hl_forced()) {
-            auto kern = eri_kernel<LA, LB, LA, LB, ERI_OUT_SCHWARZ>;
+            constexpr int NP = PairSlots<LA, LB>::N;
+            auto kern = eri_kernel<LA, LB, LA, LB, ERI_OUT_SCHWARZ, NP, NP>;  // d_q: FOUR slots per pair (member pairs of a grouped pair)
             (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
             const long long nblk = ((long long)nb + Cfg::QPB - 1) / Cfg::QPB;
             hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, st, d_q, ds, dp, dp, hp.cls_start[CB], nb,
@@ -279,9 +283,12 @@ __global__ void jk_direct_finish_kernel(double *__restrict__ J, double *__restri
 // J and K are linear in D, so the SCF driver hands over density DIFFERENCES (hamilton.py): as the SCF converges max|dD| falls
 // and the screened share of the quartets with it.
 struct DirectCtx {
-    Basis b;
-    HostPairs hp;           // Schwarz-sorted inside every class
-    std::vector<double> q;  // bound of every pair, table order
+    Basis b;                // the caller's shells
+    Basis bg;               // grouped view the kernels work on (general contractions merged: eri_core.hpp; trivial groups with g shells)
+    HostPairs hp;           // GROUP pairs, Schwarz-sorted inside every class
+    std::vector<double> q;  // bound of every group pair (max over its member shell pairs), table order
+    std::vector<double> qm; // (npair, 4): bound of every member shell pair (slot 2 xa + xb, or xb for (l s| pairs; 0: absent)
+    std::vector<long long> wpre;  // prefix sums of the pairs' weights (= member shell pairs per group pair), table order
     DevPool pool;           // synchronous pool: owns the context's device memory until destroy
     DevShells ds;
     DevPairs dp{nullptr, nullptr, nullptr};
@@ -302,7 +309,7 @@ static void class_l(int c, int &la, int &lb) {
 
 // pairs of every class re-ordered by contraction-depth bin (deepest first), then by their Schwarz bound, descending;
 // bins: (NCLS_ALL, SCREEN_NBIN + 1) bin starts relative to the class start
-static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vector<int> &bins) {
+static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vector<int> &bins, std::vector<double> *qm = nullptr) {
     const size_t np = q.size();
     std::vector<int> perm(np);
     for (size_t i = 0; i < np; i++) perm[i] = (int)i;
@@ -320,6 +327,7 @@ static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vect
         for (int k = 0; k < SCREEN_NBIN; k++) bs[k + 1] += bs[k];
     }
     HostPairs n;
+    n.stride = hp.stride;
     for (int c = 0; c < 48; c++) { n.cls_start[c] = hp.cls_start[c]; n.cls_count[c] = hp.cls_count[c]; }
     std::vector<double> nq(np);
     n.pp_off.push_back(0);
@@ -330,11 +338,35 @@ static void sort_pairs_by_bound(HostPairs &hp, std::vector<double> &q, std::vect
         nq[i] = q[o];
         n.sh.push_back(hp.sh[2 * o]);
         n.sh.push_back(hp.sh[2 * o + 1]);
-        n.pp.insert(n.pp.end(), hp.pp.begin() + (size_t)hp.pp_off[o] * 5, hp.pp.begin() + (size_t)hp.pp_off[o + 1] * 5);
-        n.pp_off.push_back((int)n.pp.size() / 5);
+        n.pp.insert(n.pp.end(), hp.pp.begin() + (size_t)hp.pp_off[o] * hp.stride, hp.pp.begin() + (size_t)hp.pp_off[o + 1] * hp.stride);
+        n.pp_off.push_back((int)n.pp.size() / hp.stride);
+    }
+    if (qm) {  // (four member-pair bounds per pair ride along)
+        std::vector<double> nm(qm->size());
+        for (size_t i = 0; i < np; i++)
+            for (int e = 0; e < 4; e++) nm[4 * i + e] = (*qm)[4 * (size_t)perm[i] + e];
+        *qm = std::move(nm);
     }
     hp = std::move(n);
     q = std::move(nq);
+}
+
+// member shell pairs of a group pair: (slot, original shell of the first member, of the second); a pair inside one group keeps
+// xa >= xb.  Slots as in build_pairs: 2 xa + xb for (s s| pairs, xb for (l s| pairs, 0 otherwise
+static int group_pair_members(const Basis &bg, int ga, int gb, int slot[4], int sa[4], int sb[4]) {
+    int n = 0;
+    const bool ss = bg.shells[ga].l == 0 && bg.shells[gb].l == 0;
+    for (int xa = 0; xa < 2; xa++)
+        for (int xb = 0; xb < 2; xb++) {
+            const int ia = xa ? bg.sh_id1[ga] : bg.sh_id0[ga], ib = xb ? bg.sh_id1[gb] : bg.sh_id0[gb];
+            if (ia < 0 || ib < 0) continue;
+            if (ga == gb && xa < xb) continue;
+            slot[n] = ss ? 2 * xa + xb : xb;
+            sa[n] = ia;
+            sb[n] = ib;
+            n++;
+        }
+    return n;
 }
 
 // prefix offsets of the surviving tasks of every class pair for the coarse test Q_b Q_k >= tc: SCREEN_NBIN entries per pair,
@@ -356,7 +388,12 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
             class_l(cb, la, lb);
             class_l(ck, lc, ld);
             const bool same = cb == ck;
-            c.stat_total += same ? (long long)nb * (nb + 1) / 2 : (long long)nb * nk;
+            // statistics in SHELL quartets: a group pair stands for w member shell pairs (wpre: prefix sums of w in table order)
+            const long long *wb_ = c.wpre.data() + c.hp.cls_start[cb], *wk_ = c.wpre.data() + c.hp.cls_start[ck];
+            auto Wb = [&](int lo_, int hi_) { return wb_[hi_] - wb_[lo_]; };
+            auto Wk = [&](int lo_, int hi_) { return wk_[hi_] - wk_[lo_]; };
+            const long long Sb = Wb(0, nb), Sk = Wk(0, nk);
+            c.stat_total += same ? Sb * (Sb + 1) / 2 : Sb * Sk;
             double tc = tc_all;
             if (dl) {
                 auto d2 = [&](int x, int y) { return std::max(dl[5 * x + y], dl[5 * y + x]); };
@@ -382,7 +419,11 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
                             if (chunks < 0) chunks = 0;
                             cnt[(size_t)ik * SCREEN_NBIN + ab] = chunks;
                             const int lo = same ? std::max(ik - b0, 0) : 0;
-                            c.stat_launched += ptr > lo ? ptr - lo : 0;
+                            if (ptr > lo) {
+                                const long long wk1 = Wk(ik, ik + 1);
+                                c.stat_launched += wk1 * Wb(b0 + lo, b0 + ptr);
+                                if (same && ik >= b0 + lo && ik < b0 + ptr) c.stat_launched -= wk1 * (wk1 - 1) / 2;  // the quartet of the pair with itself
+                            }
                         }
                     } else {  // per bra pair: a prefix of ket bin `kb`
                         int ptr = k1 - k0;
@@ -391,7 +432,11 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
                             int n = ptr;
                             if (same) n = std::max(0, std::min(n, ib + 1 - k0));
                             cnt[(size_t)ib * SCREEN_NBIN + kb] = n;
-                            c.stat_launched += n;
+                            if (n > 0) {
+                                const long long wb1 = Wb(ib, ib + 1);
+                                c.stat_launched += wb1 * Wk(k0, k0 + n);
+                                if (same && ib >= k0 && ib < k0 + n) c.stat_launched -= wb1 * (wb1 - 1) / 2;
+                            }
                         }
                     }
                 }
@@ -407,15 +452,22 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
 
 // max |D| over the AO block of every shell pair, and over the whole matrix (non-negative doubles order like their bit patterns)
 __global__ void shell_dmax_kernel(double *__restrict__ dsh, double *__restrict__ dmax, const double *__restrict__ dsym,
-                                  const int *__restrict__ ao_off, const int *__restrict__ shl, int nsh, int nao) {
+                                  const int *__restrict__ ao_off, const int *__restrict__ ao_off1, const int *__restrict__ shl, int nsh,
+                                  int nao) {
+    // (nsh GROUPS: a group's block is the union of its members' blocks -- ao_off1: second member or -1)
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     double m = 0.0;
     if (e < (long long)nsh * nsh) {
         const int i = (int)(e / nsh), j = (int)(e % nsh);
         const int ni = 2 * shl[i] + 1, nj = 2 * shl[j] + 1;
-        const double *p = dsym + (size_t)ao_off[i] * nao + ao_off[j];
-        for (int a = 0; a < ni; a++)
-            for (int b_ = 0; b_ < nj; b_++) m = fmax(m, fabs(p[(size_t)a * nao + b_]));
+        for (int xi = 0; xi < 2; xi++)
+            for (int xj = 0; xj < 2; xj++) {
+                const int oi = xi ? (ao_off1 ? ao_off1[i] : -1) : ao_off[i], oj = xj ? (ao_off1 ? ao_off1[j] : -1) : ao_off[j];
+                if (oi < 0 || oj < 0) continue;
+                const double *p = dsym + (size_t)oi * nao + oj;
+                for (int a = 0; a < ni; a++)
+                    for (int b_ = 0; b_ < nj; b_++) m = fmax(m, fabs(p[(size_t)a * nao + b_]));
+            }
         dsh[e] = m;
     }
 #pragma unroll
@@ -449,11 +501,17 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
     if (rc) return rc;
     if (nbas == 0 || b.nao == 0) return DQC_OK;
     if ((rc = boys_table_ensure())) return rc;
+    // grouped view (general contractions merged: eri_core.hpp; trivial groups with g shells, whose runtime kernel reads one
+    // coefficient per primitive pair)
+    bool merge = !hl_forced();
+    for (const HostShell &h : b.shells) merge = merge && h.l <= ERI_LMAX;
+    Basis bg;
+    group_s_shells(b, bg, merge);
     HostPairs hp;
-    build_pairs(b, hp);
+    build_pairs(bg, hp);
     DevPool pool(st);
     DevShells ds;
-    if ((rc = upload_shells(ds, b, pool, st))) { set_error("dqc_jk_direct: device upload failed"); return rc; }
+    if ((rc = upload_shells(ds, bg, pool, st))) { set_error("dqc_jk_direct: device upload failed"); return rc; }
     int *d_sh = nullptr, *d_off = nullptr;
     double *d_pp = nullptr, *d_sym = nullptr, *d_a = nullptr, *d_b = nullptr;
     const size_t n2 = (size_t)b.nao * b.nao;
@@ -464,7 +522,7 @@ int dqc_jk_direct(double *d_J, double *d_K, const double *d_dm, const int *atm, 
     }
     hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, d_sym, d_a, d_b, d_dm, b.nao);
     DQC_CHECK_LAUNCH();
-    DevPairs dp{d_sh, d_off, d_pp};
+    DevPairs dp{d_sh, d_off, d_pp, hp.stride};
     EriOut og{b.nao, 0, 0, 0};
     og.dmat = d_sym;
     og.jacc = d_a;
@@ -489,29 +547,42 @@ int dqc_direct_create(void **ctx_out, const int *atm, int natm, const int *bas, 
     if (rc) return rc;
     if (nbas == 0 || c->b.nao == 0) { set_error("dqc_direct_create: empty basis"); return DQC_EINVAL; }
     if ((rc = boys_table_ensure())) return rc;
-    build_pairs(c->b, c->hp);
-    const size_t np = c->hp.sh.size() / 2, n2 = (size_t)c->b.nao * c->b.nao, nsh = c->b.shells.size();
-    if ((rc = upload_shells(c->ds, c->b, c->pool, st))) { set_error("dqc_direct_create: device upload failed"); return rc; }
+    // the kernels work on the grouped view: general contractions merged (eri_core.hpp) unless the basis has g shells (the runtime
+    // kernel of those classes reads one coefficient per primitive pair) or DQC_ERI_GROUP=0
+    static const bool group_env = [] { const char *e = getenv("DQC_ERI_GROUP"); return !(e && e[0] == '0'); }();
+    bool merge = group_env && !hl_forced();
+    for (const HostShell &h : c->b.shells) merge = merge && h.l <= ERI_LMAX;
+    group_s_shells(c->b, c->bg, merge);
+    build_pairs(c->bg, c->hp);
+    const size_t np = c->hp.sh.size() / 2, n2 = (size_t)c->b.nao * c->b.nao, nsh = c->bg.shells.size();
+    if ((rc = upload_shells(c->ds, c->bg, c->pool, st))) { set_error("dqc_direct_create: device upload failed"); return rc; }
     c->q.assign(np, 0.0);
-    {   // Schwarz bounds from the unsorted tables (scratch of this block only)
+    c->qm.assign(np * 4, 0.0);
+    {   // Schwarz bounds from the unsorted tables (scratch of this block only): four slots per pair, one per member shell pair
         DevPool tmp;
         int *d_sh = nullptr, *d_off = nullptr;
         double *d_pp = nullptr, *d_q0 = nullptr;
         if ((rc = tmp.upload(&d_sh, c->hp.sh, st)) || (rc = tmp.upload(&d_off, c->hp.pp_off, st)) || (rc = tmp.upload(&d_pp, c->hp.pp, st)) ||
-            (rc = tmp.alloc(&d_q0, np))) {
+            (rc = tmp.alloc(&d_q0, np * 4))) {
             set_error("dqc_direct_create: device allocation failed");
             return rc;
         }
-        DQC_HIP(hipMemsetAsync(d_q0, 0, sizeof(double) * np, st));
-        DevPairs dp0{d_sh, d_off, d_pp};
+        DQC_HIP(hipMemsetAsync(d_q0, 0, sizeof(double) * np * 4, st));
+        DevPairs dp0{d_sh, d_off, d_pp, c->hp.stride};
         constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
         if ((rc = ClassLoopSchwarz<NCLS - 1>::run(d_q0, c->ds, dp0, c->hp, st))) return rc;
         if ((rc = run_generic_classes<ERI_OUT_SCHWARZ>(d_q0, c->ds, dp0, c->hp, EriOut{0, 0, 0, 0}, st))) return rc;
-        DQC_HIP(hipMemcpyAsync(c->q.data(), d_q0, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+        DQC_HIP(hipMemcpyAsync(c->qm.data(), d_q0, sizeof(double) * np * 4, hipMemcpyDeviceToHost, st));
         DQC_HIP(hipStreamSynchronize(st));
     }
-    for (double &v : c->q) v = std::sqrt(v);
-    sort_pairs_by_bound(c->hp, c->q, c->bins);
+    for (double &v : c->qm) v = std::sqrt(v);
+    for (size_t i = 0; i < np; i++) c->q[i] = std::max(std::max(c->qm[4 * i], c->qm[4 * i + 1]), std::max(c->qm[4 * i + 2], c->qm[4 * i + 3]));
+    sort_pairs_by_bound(c->hp, c->q, c->bins, &c->qm);
+    c->wpre.assign(np + 1, 0);
+    for (size_t i = 0; i < np; i++) {
+        int slot[4], sa[4], sb[4];
+        c->wpre[i + 1] = c->wpre[i] + group_pair_members(c->bg, c->hp.sh[2 * i], c->hp.sh[2 * i + 1], slot, sa, sb);
+    }
     int *d_sh = nullptr, *d_off = nullptr;
     double *d_pp = nullptr;
     size_t ntoff = 0;
@@ -527,7 +598,7 @@ int dqc_direct_create(void **ctx_out, const int *atm, int natm, const int *bas, 
         return rc;
     }
     DQC_HIP(hipStreamSynchronize(st));  // the uploads read host vectors that may move
-    c->dp = DevPairs{d_sh, d_off, d_pp};
+    c->dp = DevPairs{d_sh, d_off, d_pp, c->hp.stride};
     c->h_toff.reserve(ntoff);
     *ctx_out = c.release();
     return DQC_OK;
@@ -538,15 +609,26 @@ int dqc_direct_destroy(void *ctx) {
     return DQC_OK;
 }
 
-int dqc_direct_npairs(void *ctx) { return ctx ? (int)static_cast<dqc::DirectCtx *>(ctx)->q.size() : 0; }
+int dqc_direct_npairs(void *ctx) { return ctx ? (int)static_cast<dqc::DirectCtx *>(ctx)->wpre.back() : 0; }
 
-int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells) {
-    // HOST arrays: the Schwarz bound of every shell pair (npairs) and its two shells (npairs, 2), in table order
-    if (!ctx) { dqc::set_error("dqc_direct_bounds: null context"); return DQC_EINVAL; }
-    const dqc::DirectCtx &c = *static_cast<dqc::DirectCtx *>(ctx);
+int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells) { return dqc_direct_bounds_groups(ctx, h_q, h_shells, nullptr); }
+
+int dqc_direct_bounds_groups(void *ctx, double *h_q, int *h_shells, int *h_group) {
+    // HOST arrays: the Schwarz bound of every SHELL pair (npairs), its two shells (npairs, 2) -- indices of the caller's table -- and
+    // (h_group, optional) the index of the group pair it belongs to: the screening works on group pairs (general contractions
+    // merged, eri_core.hpp) with the largest bound of their members
+    using namespace dqc;
+    if (!ctx) { set_error("dqc_direct_bounds: null context"); return DQC_EINVAL; }
+    const DirectCtx &c = *static_cast<DirectCtx *>(ctx);
+    size_t o = 0;
     for (size_t i = 0; i < c.q.size(); i++) {
-        if (h_q) h_q[i] = c.q[i];
-        if (h_shells) { h_shells[2 * i] = c.hp.sh[2 * i]; h_shells[2 * i + 1] = c.hp.sh[2 * i + 1]; }
+        int slot[4], sa[4], sb[4];
+        const int n = group_pair_members(c.bg, c.hp.sh[2 * i], c.hp.sh[2 * i + 1], slot, sa, sb);
+        for (int e = 0; e < n; e++, o++) {
+            if (h_q) h_q[o] = c.qm[4 * i + slot[e]];
+            if (h_shells) { h_shells[2 * o] = sa[e]; h_shells[2 * o + 1] = sb[e]; }
+            if (h_group) h_group[o] = (int)i;
+        }
     }
     return DQC_OK;
 }
@@ -571,7 +653,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     if (!(tau >= 0.0)) { set_error("dqc_direct_jk: tau must be >= 0"); return DQC_EINVAL; }
     if (nparts < 1 || part < 0 || part >= nparts) { set_error("dqc_direct_jk_part: need 0 <= part < nparts"); return DQC_EINVAL; }
     DirectCtx &c = *static_cast<DirectCtx *>(ctx);
-    const int nao = c.b.nao, nsh = (int)c.b.shells.size();
+    const int nao = c.b.nao, nsh = (int)c.bg.shells.size();  // (groups: the kernels' "shells")
     hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, c.d_sym, c.d_a, d_K ? c.d_b : nullptr, d_dm, nao);
     DQC_CHECK_LAUNCH();
     EriOut og{nao, 0, 0, 0};
@@ -588,7 +670,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
         DQC_HIP(hipMemsetAsync(c.d_dmax, 0, sizeof(double) * 26, st));
         const long long npr = (long long)nsh * nsh;
         hipLaunchKernelGGL(shell_dmax_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dsh, c.d_dmax, c.d_sym, c.ds.ao_off,
-                           c.ds.l, nsh, nao);
+                           c.ds.ao_off1, c.ds.l, nsh, nao);
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(shell_dmax_by_l_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dmax, c.d_dsh, c.ds.l, nsh);
         DQC_CHECK_LAUNCH();
@@ -648,8 +730,8 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     bool group = group_env && !hl_forced();
     for (const HostShell &h : b.shells) group = group && h.l <= ERI_LMAX;
     Basis bg;
-    if (group) group_s_shells(b, bg);
-    const Basis &bu = group ? bg : b;
+    group_s_shells(b, bg, group);  // (merge = false: one shell per group, the tables still have the grouped layout the kernels read)
+    const Basis &bu = bg;
     HostPairs hp;
     build_pairs(bu, hp);
     DevPool pool(st);  // stream-ordered scratch: this call only enqueues

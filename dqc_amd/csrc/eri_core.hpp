@@ -892,8 +892,10 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const int mc = mabc % Cfg::SC, mb = (mabc / Cfg::SC) % Cfg::SB, ma = mabc / (Cfg::SC * Cfg::SB);
             const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
             if constexpr (MODE == ERI_OUT_SCHWARZ) {
-                if (ma == mc && mb == md)  // non-negative doubles order like their bit patterns
-                    atomicMax(reinterpret_cast<unsigned long long *>(tiles) + ib, (unsigned long long)__double_as_longlong(fabs(v)));
+                // (four slots per pair: the bound of every member pair of a grouped pair on its own -- slot = the bra combination;
+                // the mixed combinations eb != ek are no diagonal quartets of a shell pair)
+                if (ma == mc && mb == md && eb == ek)  // non-negative doubles order like their bit patterns
+                    atomicMax(reinterpret_cast<unsigned long long *>(tiles) + (size_t)ib * 4 + eb, (unsigned long long)__double_as_longlong(fabs(v)));
             } else
             if constexpr (MODE == ERI_OUT_JK) {
                 const double *D = og.dmat;
@@ -940,8 +942,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const double degj = act ? 4.0 * SCALE_ * (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0) : 0.0;
             const double *D = og.dmat;
             const size_t n = og.nao;
-            // wave-uniform shared pair?  (only single-combination launches: the members of a grouped quartet have their own offsets)
-            constexpr bool CAN_SHARE = NE == 1 && TPQ <= 32;
+            // wave-uniform shared pair?
+            constexpr bool CAN_SHARE = TPQ <= 32;  // (grouped quartets: per member combination -- this code runs inside the combination loop)
             bool share_ab = false, share_cd = false;
             int ai0 = ai, aj0 = aj, ak0 = ak, al0 = al;
             if constexpr (CAN_SHARE) {

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
             // ---------------- A1: vertical recurrence of every (direction, root) item, rolling columns in registers ----------------
             if (on) {
                 const int ipb = iq / nkp, ipk = iq - ipb * nkp;
-                const double *pb = prs.pp + (size_t)(pb0 + ipb) * 5, *pk = prk.pp + (size_t)(pk0 + ipk) * 5;
+                const double *pb = prs.pp + (size_t)(pb0 + ipb) * prs.stride, *pk = prk.pp + (size_t)(pk0 + ipk) * prk.stride;
                 const double p = pb[0], qq = pk[0];
                 const double P[3] = {pb[1], pb[2], pb[3]}, Q[3] = {pk[1], pk[2], pk[3]};
                 const double pq = p + qq, rho = p * qq / pq;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
                 const int i = ai + ma, j = aj + mb, k = ak + mc, l = al + md;
                 if constexpr (MODE == ERI_OUT_SCHWARZ) {
                     if (ma == mc && mb == md)
-                        atomicMax(reinterpret_cast<unsigned long long *>(tiles) + ib, (unsigned long long)__double_as_longlong(fabs(v)));
+                        atomicMax(reinterpret_cast<unsigned long long *>(tiles) + (size_t)ib * 4, (unsigned long long)__double_as_longlong(fabs(v)));  // (four slots per pair: eri_core.hpp)
                 } else
                 if constexpr (MODE == ERI_OUT_JK) {
                     const double *D = og.dmat;

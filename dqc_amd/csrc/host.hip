@@ -128,15 +128,16 @@ int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, co
     return 0;
 }
 
-void group_s_shells(const Basis &b, Basis &g) {
+void group_s_shells(const Basis &b, Basis &g, bool merge) {
     g = Basis();
     g.nao = b.nao;
     g.natm = b.natm;
     g.atom_xyz = b.atom_xyz;
     g.atom_z = b.atom_z;
-    for (const HostShell &h : b.shells) {
+    for (size_t ish = 0; ish < b.shells.size(); ish++) {
+        const HostShell &h = b.shells[ish];
         int hit = -1;
-        if (h.l == 0)
+        if (merge && h.l == 0)
             for (size_t k = 0; k < g.shells.size() && hit < 0; k++) {
                 const HostShell &o = g.shells[k];
                 if (o.l != 0 || o.atom != h.atom || o.nprim != h.nprim || g.ao_off1[k] >= 0) continue;
@@ -145,6 +146,7 @@ void group_s_shells(const Basis &b, Basis &g) {
                 if (same) hit = (int)k;
             }
         if (hit >= 0) {
+            g.sh_id1[hit] = (int)ish;
             g.ao_off1[hit] = h.ao_off;
             for (int p = 0; p < h.nprim; p++) g.coefs1[g.shells[hit].prim_off + p] = b.coefs[h.prim_off + p];
             continue;
@@ -158,6 +160,8 @@ void group_s_shells(const Basis &b, Basis &g) {
         }
         g.shells.push_back(n);
         g.ao_off1.push_back(-1);
+        g.sh_id0.push_back((int)ish);
+        g.sh_id1.push_back(-1);
     }
 }
 

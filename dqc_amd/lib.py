@@ -71,6 +71,7 @@ def load():
     lib.dqc_direct_stats.argtypes = [c_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), dp]
     lib.dqc_direct_npairs.argtypes = [c_vp]
     lib.dqc_direct_bounds.argtypes = [c_vp, dp, ip]
+    lib.dqc_direct_bounds_groups.argtypes = [c_vp, dp, ip, ip]
     lib.dqc_direct_destroy.argtypes = [c_vp]
     lib.dqc_int3c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_int2c2e.argtypes = [c_dp] + tab + [c_int, c_int, c_vp]
@@ -539,13 +540,16 @@ class DirectContext:
         _check(load().dqc_direct_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(d)), "dqc_direct_stats")
         return a.value, b.value, d.value
 
-    def bounds(self):
-        """(Q (npairs,), shells (npairs, 2)): Schwarz bound sqrt(max |(ab|ab)|) of every shell pair, table order"""
+    def bounds(self, groups=False):
+        """(Q (npairs,), shells (npairs, 2)): Schwarz bound sqrt(max |(ab|ab)|) of every shell pair, table order; groups=True adds
+        the index of the GROUP pair each shell pair is screened with (s shells of one atom over the same exponents are evaluated
+        together, with the largest bound of their members)"""
         n = int(load().dqc_direct_npairs(self._h))
-        q, sh = np.zeros(n), np.zeros((n, 2), dtype=np.int32)
-        _check(load().dqc_direct_bounds(self._h, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
-                                        sh.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), "dqc_direct_bounds")
-        return q, sh
+        q, sh, gr = np.zeros(n), np.zeros((n, 2), dtype=np.int32), np.zeros(n, dtype=np.int32)
+        _check(load().dqc_direct_bounds_groups(self._h, q.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               sh.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), gr.ctypes.data_as(ctypes.POINTER(ctypes.c_int))),
+               "dqc_direct_bounds_groups")
+        return (q, sh, gr) if groups else (q, sh)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

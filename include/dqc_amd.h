@@ -370,6 +370,9 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
 int dqc_direct_stats(void *ctx, long long *quartets_total, long long *quartets_launched, double *dmax);
 int dqc_direct_npairs(void *ctx);
 int dqc_direct_bounds(void *ctx, double *h_q, int *h_shells);
+/* the same, plus (h_group, npairs, optional) the index of the GROUP pair every shell pair belongs to: s shells of one atom over the
+ * same exponents are evaluated together and screened with the largest bound of their members (round 5) */
+int dqc_direct_bounds_groups(void *ctx, double *h_q, int *h_shells, int *h_group);
 int dqc_direct_destroy(void *ctx);
 
 /* ---- deterministic mode ----------------------------------------------------------------------
