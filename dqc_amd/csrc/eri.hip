@@ -414,8 +414,10 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
                         int ptr = b1 - b0;
                         for (int ik = k0; ik < k1; ik++) {
                             while (ptr > 0 && !(qb[b0 + ptr - 1] * qk[ik] >= tc)) ptr--;
-                            const int c0 = (same && ik > b0) ? ((ik - b0) >> 6) : 0;
-                            int chunks = (ptr + 63) / 64 - c0;
+                            // (chunks of 64 / PS bra pairs: the kernel spreads a quartet's primitive quartets over PS lanes)
+                            const int per = 64 / eri_split_lanes(ab, c.hp.pp_off[c.hp.cls_start[ck] + ik + 1] - c.hp.pp_off[c.hp.cls_start[ck] + ik], 1);
+                            const int c0 = (same && ik > b0) ? ((ik - b0) / per) : 0;
+                            int chunks = (ptr + per - 1) / per - c0;
                             if (chunks < 0) chunks = 0;
                             cnt[(size_t)ik * SCREEN_NBIN + ab] = chunks;
                             const int lo = same ? std::max(ik - b0, 0) : 0;

@@ -423,8 +423,14 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
             const int e = screen_find(og.toff, nk * SCREEN_NBIN, w2);
             const int ikl = e / SCREEN_NBIN, bin = e % SCREEN_NBIN;
             const int bs = og.pbin[bin];                             // the bra bin [bs, be) of this wave's chunk
-            const int c0 = (same && ikl > bs) ? ((ikl - bs) >> 6) : 0;  // (triangle: chunks wholly below the ket pair are not launched)
-            const int ibl = bs + (int)(w2 - og.toff[e] + c0) * 64 + (tid & 63);
+            // the primitive quartets of a quartet are spread over PS lanes (eri_split_lanes: from the bra bin's depth bound and
+            // the ket pair's primitive count, uniform per wave): a chunk is 64 / PS bra pairs
+            const int nkp_ = prk.pp_off[k0 + ikl + 1] - prk.pp_off[k0 + ikl];
+            psl = eri_split_lanes(bin, nkp_, 1);
+            const int per = 64 / psl;
+            const int c0 = (same && ikl > bs) ? ((ikl - bs) / per) : 0;  // (triangle: chunks wholly below the ket pair are not launched)
+            const int ibl = bs + (int)(w2 - og.toff[e] + c0) * per + (tid & 63) / psl;
+            psj = (tid & 63) % psl;
             active = inr && ibl < og.pbin[bin + 1] && (!same || ibl >= ikl);
             ib = ibl < nb ? ibl : nb - 1;
             ik = ikl;
