@@ -17,9 +17,10 @@ __global__ __launch_bounds__(64) void eval_gto_kernel(double *__restrict__ out, 
                                                        int ngrid, int nao, int ld, DevShells sh, int colrange) {
     constexpr int NC = DERIV == 0 ? 1 : (DERIV == 1 ? 4 : (DERIV == 2 ? 5 : 10));
     // columns staged per flush.  The tile is what bounds the occupancy (one wave per block): 16 columns x 4 components = 35 KB
-    // allowed 4 waves per CU and the kernel wrote at 1 TB/s (round 3); 8 columns (4 with the ten components of DERIV 3) let
-    // 8 waves per CU overlap their evaluation and their stores
-    constexpr int GTO_CW = DERIV == 0 ? 16 : (DERIV == 3 ? 4 : 8);
+    // allowed 4 waves per CU and the kernel wrote at 1 TB/s (round 3); 8 columns let 8 waves per CU overlap their evaluation and
+    // their stores.  The ten components of DERIV 3 had 4 columns (32-byte row segments): 5.1 ms for a 20-atom cc-pVDZ molecule;
+    // with 8 (64-byte segments, 46 KB of tile, three waves per CU) 3.1 ms
+    constexpr int GTO_CW = DERIV == 0 ? 16 : 8;
     __shared__ double tile[1][NC][64][GTO_CW + 1];
     constexpr int wave = 0;
     const int lane = threadIdx.x;
@@ -172,7 +173,7 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
         int nblk = (ngrid + 63) / 64;
         const int ld = dqc_ao_stride(b.nao);
         // column ranges (grid.y): four where the basis is wide enough, every range a whole number of flush tiles
-        const int cw = deriv == 0 ? 16 : (deriv == 3 ? 4 : 8), nsplit = ld >= 64 ? 4 : 1;
+        const int cw = deriv == 0 ? 16 : 8, nsplit = ld >= 64 ? 4 : 1;
         const int colrange = ((ld + nsplit - 1) / nsplit + cw - 1) / cw * cw;
         const dim3 grid(nblk, (ld + colrange - 1) / colrange);
         const int ncomp = deriv == 0 ? 1 : (deriv == 1 ? 4 : (deriv == 2 ? 5 : 10));
