@@ -172,8 +172,11 @@ extern "C" int dqc_eval_gto(int deriv, double *d_out, const double *d_coords, in
     if (ngrid > 0) {
         int nblk = (ngrid + 63) / 64;
         const int ld = dqc_ao_stride(b.nao);
-        // column ranges (grid.y): four where the basis is wide enough, every range a whole number of flush tiles
-        const int cw = deriv == 0 ? 16 : 8, nsplit = ld >= 64 ? 4 : 1;
+        // column ranges (grid.y), every range a whole number of flush tiles.  Measured by rocprofv3: the four GGA components take
+        // 1.17 ms split four ways against 1.01 ms unsplit (shells that straddle two ranges are evaluated twice, and the write
+        // pattern, not the parallelism, bounds the kernel): only the ten-component form is split
+        static const int nsplit3 = [] { const char *e = getenv("DQC_GTO_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+        const int cw = deriv == 0 ? 16 : 8, nsplit = (deriv == 3 && ld >= 64) ? nsplit3 : 1;
         const int colrange = ((ld + nsplit - 1) / nsplit + cw - 1) / cw * cw;
         const dim3 grid(nblk, (ld + colrange - 1) / colrange);
         const int ncomp = deriv == 0 ? 1 : (deriv == 1 ? 4 : (deriv == 2 ? 5 : 10));
