@@ -835,6 +835,38 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     return DQC_OK;
 }
 
+int dqc_eri_pair_stats(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, int merge, long long *h_out) {
+    // HOST only (no device call): the pair tables the fill / direct kernels would be launched with -- h_out[0] groups (= shells when
+    // merge == 0), [1] pairs, [2] primitive pairs kept after the negligible-pair cut, [3] primitive quartets over all class pairs
+    // (bra class >= ket class, bra pair >= ket pair inside a class).  What merging the general contractions buys, and a check of
+    // the host logic that runs without a GPU
+    using namespace dqc;
+    if (!h_out) { set_error("dqc_eri_pair_stats: null output"); return DQC_EINVAL; }
+    Basis b, bg;
+    int rc = parse_basis(b, atm, natm, bas, nbas, env, nenv, nullptr);
+    if (rc) return rc;
+    group_s_shells(b, bg, merge != 0);
+    HostPairs hp;
+    build_pairs(bg, hp);
+    h_out[0] = (long long)bg.shells.size();
+    h_out[1] = (long long)hp.sh.size() / 2;
+    h_out[2] = hp.pp_off.empty() ? 0 : hp.pp_off.back();
+    long long tot = 0;
+    for (int cb = 0; cb < NCLS_ALL; cb++)
+        for (int ck = 0; ck <= cb; ck++) {
+            long long sb = 0, sk = 0, sq = 0;
+            for (int i = 0; i < hp.cls_count[cb]; i++) {
+                const long long n = hp.pp_off[hp.cls_start[cb] + i + 1] - hp.pp_off[hp.cls_start[cb] + i];
+                sb += n;
+                sq += n * n;
+            }
+            for (int i = 0; i < hp.cls_count[ck]; i++) sk += hp.pp_off[hp.cls_start[ck] + i + 1] - hp.pp_off[hp.cls_start[ck] + i];
+            tot += cb == ck ? (sb * sb + sq) / 2 : sb * sk;
+        }
+    h_out[3] = tot;
+    return DQC_OK;
+}
+
 int dqc_eri_tiles_to_dense(double *d_dense, const double *d_tiles, int nao, void *stream) {
     using namespace dqc;
     if (nao <= 0) return DQC_OK;

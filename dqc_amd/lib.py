@@ -70,6 +70,7 @@ def load():
     lib.dqc_direct_jk_part.argtypes = [c_vp, c_dp, c_dp, c_dp, ctypes.c_double, c_int, c_int, c_vp]
     lib.dqc_direct_stats.argtypes = [c_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong), dp]
     lib.dqc_direct_npairs.argtypes = [c_vp]
+    lib.dqc_eri_pair_stats.argtypes = [ip, c_int, ip, c_int, dp, c_int, c_int, ctypes.POINTER(ctypes.c_longlong)]
     lib.dqc_direct_bounds.argtypes = [c_vp, dp, ip]
     lib.dqc_direct_bounds_groups.argtypes = [c_vp, dp, ip, ip]
     lib.dqc_direct_destroy.argtypes = [c_vp]
@@ -511,6 +512,13 @@ def jk_direct(tab, dm_ao, with_k=True):
     with _on(dm_ao.device) as st_:
         _check(load().dqc_jk_direct(_ptr(J), _ptr(K), _ptr(dm_ao.contiguous()), *tab.args(), st_), "dqc_jk_direct")
     return J, K
+
+
+def eri_pair_stats(tab, merge=True):
+    """host-side size of the ERI pair tables (no GPU needed): dict(groups, pairs, primitive_pairs, primitive_quartets)"""
+    out = (ctypes.c_longlong * 4)()
+    _check(load().dqc_eri_pair_stats(*tab.args(), 1 if merge else 0, out), "dqc_eri_pair_stats")
+    return {"groups": out[0], "pairs": out[1], "primitive_pairs": out[2], "primitive_quartets": out[3]}
 
 
 class DirectContext:

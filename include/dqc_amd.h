@@ -70,6 +70,11 @@ size_t dqc_eri_store_doubles(int nao);
 int dqc_eri_fill_tiles(double *d_tiles, const int *atm, int natm, const int *bas, int nbas,
                        const double *env, int nenv, void *stream);
 /* expand the tiles into the reference's dense (nao,nao,nao,nao) tensor (tests / small nao only) */
+/* HOST only (no device call): the pair tables the fill / direct kernels are launched with.  merge != 0: s shells of one atom over the
+ * same exponent list -- the contractions the reference splits a generally contracted shell into (dqc/api/loadbasis.py:72-82) --
+ * evaluated as one group.  h_out[4] = groups, pairs, primitive pairs kept, primitive quartets over all unique (bra, ket) pairs. */
+int dqc_eri_pair_stats(const int *atm, int natm, const int *bas, int nbas, const double *env, int nenv, int merge, long long *h_out);
+
 int dqc_eri_tiles_to_dense(double *d_dense, const double *d_tiles, int nao, void *stream);
 
 /* ---- J / K contraction ---------------------------------------------------------------------

@@ -489,3 +489,70 @@ def test_design_md_sections_cited_elsewhere_exist():
     assert cited, "expected at least the README's citations"
     missing = sorted(c for c in cited if c[0] not in have)
     assert not missing, missing
+
+
+def _pair_counts_numpy(t, merge):
+    """independent count of the ERI pair tables (numpy): groups of s shells of one atom over the same exponents (two per group),
+    primitive pairs kept by the cuts of csrc/eri_core.hpp (exp(-100), 1e-20 prefactor bound), primitive quartets over the unique
+    (bra pair >= ket pair) combinations of every class pair"""
+    shells = []
+    for s_ in t.bas:
+        at, l, npr = int(s_[0]), int(s_[1]), int(s_[2])
+        shells.append(dict(at=at, l=l, ex=t.env[s_[5]:s_[5] + npr], co=[t.env[s_[6]:s_[6] + npr]], r=t.env[t.atm[at][1]:t.atm[at][1] + 3]))
+    groups = []
+    for s_ in shells:
+        hit = None
+        if merge and s_["l"] == 0:
+            for o in groups:
+                if o["l"] == 0 and o["at"] == s_["at"] and len(o["ex"]) == len(s_["ex"]) and len(o["co"]) == 1 and np.all(o["ex"] == s_["ex"]):
+                    hit = o
+                    break
+        if hit is not None:
+            hit["co"].append(s_["co"][0])
+        else:
+            groups.append(dict(s_, co=list(s_["co"])))
+    cls = {}
+    npp_tot = 0
+    for i in range(len(groups)):
+        for j in range(i + 1):
+            A, B = groups[i], groups[j]
+            if B["l"] > A["l"]:
+                A, B = B, A
+            ab2 = float(((A["r"] - B["r"]) ** 2).sum())
+            ea, eb = A["ex"][:, None], B["ex"][None, :]
+            p = ea + eb
+            arg = ea * eb / p * ab2
+            ca = np.max(np.abs(np.array(A["co"])), axis=0)[:, None]
+            cb = np.max(np.abs(np.array(B["co"])), axis=0)[None, :]
+            f = ca * cb * np.exp(-arg) / p * (1.0 + np.sqrt(ab2)) ** (A["l"] + B["l"])
+            n = int(((arg <= 100.0) & (f >= 1e-20)).sum())
+            cls.setdefault((A["l"], B["l"]), []).append(n)
+            npp_tot += n
+    keys = sorted(cls)
+    tot = 0
+    for ib, kb in enumerate(keys):
+        for kk in keys[:ib + 1]:
+            nb, nk = np.array(cls[kb], dtype=np.int64), np.array(cls[kk], dtype=np.int64)
+            tot += int((nb.sum() ** 2 + (nb ** 2).sum()) // 2) if kb == kk else int(nb.sum() * nk.sum())
+    return len(groups), sum(len(v) for v in cls.values()), npp_tot, tot
+
+
+@pytest.mark.parametrize("name,basis", [("c5", "cc-pvdz"), ("benzene", "cc-pvdz"), ("h2o", "sto-3g"), ("ch4", "cc-pvtz")])
+def test_eri_pair_tables_host_logic_without_a_gpu(name, basis):
+    """dqc_eri_pair_stats (host only): the grouped pair tables of the ERI fill -- general contractions merged -- have the sizes an
+    independent numpy count gives; the 20-atom cc-pVDZ molecule of the bench goes from 96 shells / 3.39e8 primitive quartets to
+    84 groups / 1.05e8"""
+    from dqc_amd import lib
+    geo = {"c5": M.c5_molecule(0), "benzene": M.benzene(), "h2o": M.H2O, "ch4": M.CH4}[name]
+    t = ob.make_tables(geo, basis)
+    tab = lib.Tables(t.atm, t.bas, t.env)
+    for merge in (True, False):
+        st = lib.eri_pair_stats(tab, merge)
+        g, npair, npp, nq = _pair_counts_numpy(t, merge)
+        assert (st["groups"], st["pairs"], st["primitive_pairs"], st["primitive_quartets"]) == (g, npair, npp, nq), (merge, st, (g, npair, npp, nq))
+        if not merge:
+            assert st["groups"] == t.bas.shape[0]
+    if name == "c5":
+        assert lib.eri_pair_stats(tab, True)["groups"] == 84 and lib.eri_pair_stats(tab, True)["primitive_quartets"] < 0.32 * lib.eri_pair_stats(tab, False)["primitive_quartets"]
+    if basis == "sto-3g":  # s and p share exponents but not the angular momentum: nothing to merge
+        assert lib.eri_pair_stats(tab, True) == lib.eri_pair_stats(tab, False)
