@@ -976,11 +976,20 @@ def eri_fill_stats(h, dev):
             roots = L // 2 + 1
             per = roots * (24.0 * (sum(a) + 1) * (sum(b) + 1) + 3.0 * ncart(a[0]) * ncart(a[1]) * ncart(b[0]) * ncart(b[1]))
             flops += 0.5 * wa * wb * per
+    # what the kernels really walk: pair tables after the negligible-primitive cut, general contractions merged (round 5)
+    try:
+        stg, stu = lib.eri_pair_stats(tab, True), lib.eri_pair_stats(tab, False)
+        actual = {"groups": stg["groups"], "shells": stu["groups"], "primitive_quartets_evaluated": stg["primitive_quartets"],
+                  "primitive_quartets_one_shell_per_contraction": stu["primitive_quartets"],
+                  "primitive_quartets_evaluated_per_s": stg["primitive_quartets"] / (ms * 1e-3)}
+    except Exception as e:  # noqa: BLE001
+        actual = {"error": repr(e)[:200]}
     return {"ms": ms, "shell_quartets": int(nquart), "shell_quartets_per_s": nquart / (ms * 1e-3),
-            "primitive_quartets_per_s": nprimq / (ms * 1e-3), "tile_bytes": nbytes,
+            "primitive_quartets_nominal_per_s": nprimq / (ms * 1e-3), "pair_tables": actual, "tile_bytes": nbytes,
             "tile_write_gbs": nbytes / (ms * 1e-3) / 1e9, "fp64_gflops_model": flops / (ms * 1e-3) / 1e9,
-            "flop_model": "per primitive quartet and Rys root: 24 (la+lb+1)(lc+ld+1) for the 2D recurrences + 3 per Cartesian "
-                          "integral; an estimate, not a hardware counter"}
+            "flop_model": "NOMINAL primitive quartets (nprim products of all shell pairs, no cut, one shell per contraction) x, per "
+                          "Rys root, 24 (la+lb+1)(lc+ld+1) for the 2D recurrences + 3 per Cartesian integral; an estimate, not a "
+                          "hardware counter -- the kernels evaluate pair_tables.primitive_quartets_evaluated of them"}
 
 
 def _calibrated_threads(fn):
