@@ -177,7 +177,7 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
     if (dp.stride != PP_STRIDE_G) { set_error("direct J / K: pair tables without the grouped layout"); return DQC_EINVAL; }
     constexpr int NPB = PairSlots<LA, LB>::N, NPK = PairSlots<LC, LD>::N;
     auto kern = jonly ? eri_kernel<LA, LB, LC, LD, ERI_OUT_J, NPB, NPK> : eri_kernel<LA, LB, LC, LD, ERI_OUT_JK, NPB, NPK>;
-    const size_t lds_bytes = jonly ? Cfg::LDS_BYTES : Cfg::LDS_BYTES_JK;
+    const size_t lds_bytes = Cfg::LDS_BYTES;  // (both direct modes digest the block in place: the fill's LDS footprint)
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, (double *)nullptr, ds, dp, dp, hp.cls_start[cb],
                        nb, hp.cls_start[ck], nk, same, ntask, o2);

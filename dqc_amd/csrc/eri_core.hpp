@@ -392,12 +392,11 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
 
     const int tid = threadIdx.x;
     const int q = tid / TPQ, s = tid % TPQ;  // quartet slot in the block, lane inside the quartet group
-    constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : (MODE == ERI_OUT_JK ? Cfg::REGION_JK : Cfg::REGION);
+    constexpr int REGION = MODE == ERI_OUT_GRAD ? Cfg::REGION_G : Cfg::REGION;  // (the direct modes digest the block in place: the fill's footprint)
     double *reg = lds + (size_t)q * REGION;
     constexpr bool TAB_LDS = Cfg::TAB_DOUBLES > 0;
     typedef __attribute__((address_space(3))) double lds_double_t;
-    lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G
-                                                 : (MODE == ERI_OUT_JK ? Cfg::REG_DOUBLES_JK : Cfg::REG_DOUBLES));
+    lds_double_t *ltab = (lds_double_t *)lds + (MODE == ERI_OUT_GRAD ? Cfg::REG_DOUBLES_G : Cfg::REG_DOUBLES);
     if constexpr (TAB_LDS) {
         if constexpr (Cfg::BOYS01) boys_stage_lds(ltab, tid, 256);
         else rys_stage_lds<NR>(ltab, tid, 256);
@@ -855,9 +854,6 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         } else if (!__any(act)) continue;
         eri_group_sync<TPQ>();  // the previous combination's last stage has read buf1
     }
-    if constexpr (MODE == ERI_OUT_JK) {  // the combination's partial J / K sums start at zero (synchronised by the stages below)
-        for (int x = s; x < Cfg::NJK; x += TPQ) reg[Cfg::REG0 + x] = 0.0;
-    }
 #pragma unroll
     for (int m = 0; m < NPT; m++) {
         const int n = s + TPQ * m;
@@ -888,7 +884,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         double *t_ = cur; cur = oth; oth = t_;
         eri_group_sync<TPQ>();
     }
-    if (MODE != ERI_OUT_J && act) {  // (the Coulomb-only direct mode digests the block in the passes below: no per-element work)
+    if (MODE != ERI_OUT_J && MODE != ERI_OUT_JK && act) {  // (the direct modes digest the block in the passes below: no per-element work)
         // scatter: value (ma, mb, mc, md) -> all block-canonical images (md fastest over the lanes: runs of consecutive addresses)
         constexpr double S0 = 0.28209479177387864;  // the l = 0 solid harmonic
         constexpr double SCALE = (LA == 0 ? S0 : 1.0) * (LB == 0 ? S0 : 1.0) * (LC == 0 ? S0 : 1.0) * (LD == 0 ? S0 : 1.0);
@@ -902,24 +898,6 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 // the mixed combinations eb != ek are no diagonal quartets of a shell pair)
                 if (ma == mc && mb == md && eb == ek)  // non-negative doubles order like their bit patterns
                     atomicMax(reinterpret_cast<unsigned long long *>(tiles) + (size_t)ib * 4 + eb, (unsigned long long)__double_as_longlong(fabs(v)));
-            } else
-            if constexpr (MODE == ERI_OUT_JK) {
-                const double *D = og.dmat;
-                const size_t n = og.nao;
-                double *jk = reg + Cfg::REG0;
-                constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
-                              OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
-                auto ladd = [](double *p_, double x) {
-                    if constexpr (TPQ == 1) *p_ += x;   // the lane owns its quartet's sums
-                    else atomicAdd(p_, x);              // ds_add_f64
-                };
-                // (the two Coulomb products are matrix-vector passes over the block below: no LDS atomics)
-                if (og.kacc) {
-                    ladd(&jk[OK1 + ma * Cfg::SC + mc], v * D[(size_t)j * n + l]);
-                    ladd(&jk[OK2 + ma * Cfg::SD + md], v * D[(size_t)j * n + k]);
-                    ladd(&jk[OK3 + mb * Cfg::SC + mc], v * D[(size_t)i * n + l]);
-                    ladd(&jk[OK4 + mb * Cfg::SD + md], v * D[(size_t)i * n + k]);
-                }
             } else
             if (MODE == ERI_OUT_TILES) {
                 if (!(og.dbg & 4) || v == 12345.678) tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
@@ -1000,26 +978,52 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         }
     }
     if constexpr (MODE == ERI_OUT_JK) {
-        // one atomic per element of the four exchange blocks.  Every unique quartet is visited once (pairs a >= b, c >= d,
-        // bra pair >= ket pair): the eight permutational images are covered by accumulating A_ab, A_cd (J = (A + A^T) / 2)
-        // and B_ac, B_ad, B_bc, B_bd (K = B + B^T) with 1/2 per coincidence a == b, c == d, (ab) == (cd)
-        eri_group_sync<TPQ>();
-        if (act) {
-            // (grouped: two members of one group are different shells -- the coincidences are those of the AO offsets)
-            const double deg = (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0);
+        // The four exchange blocks, each a pass over the block V[a b c d] in `cur` with a lane per result element and the two summed
+        // indices in the inner loops: B_ac += sum_bd V D_bd, B_ad += sum_bc V D_bc, B_bc += sum_ad V D_ad, B_bd += sum_ac V D_ac (K = B + B^T
+        // with 1/2 per coincidence a == b, c == d, (ab) == (cd): every unique quartet is visited once), one global atomic per element.
+        // Round 4 added v D to LDS accumulators element by element (four ds_add_f64 per integral) -- and the accumulator blocks
+        // (294 doubles per (ff|ff) quartet) halved the occupancy of the high classes
+        if (act && og.kacc) {
+            constexpr double S0_ = 0.28209479177387864;
+            constexpr double SCALE_ = (LA == 0 ? S0_ : 1.0) * (LB == 0 ? S0_ : 1.0) * (LC == 0 ? S0_ : 1.0) * (LD == 0 ? S0_ : 1.0);
+            constexpr int SA = Cfg::SA, SB = Cfg::SB, SC = Cfg::SC, SD = Cfg::SD;
+            constexpr int O2 = SA * SC, O3 = O2 + SA * SD, O4 = O3 + SB * SC, NK4 = O4 + SB * SD;
+            const double deg = SCALE_ * (ai == aj ? 0.5 : 1.0) * (ak == al ? 0.5 : 1.0) * ((ai == ak && aj == al) ? 0.5 : 1.0);
+            const double *D = og.dmat;
             const size_t n = og.nao;
-            const double *jk = reg + Cfg::REG0;
-            constexpr int OJ2 = Cfg::SA * Cfg::SB, OK1 = OJ2 + Cfg::SC * Cfg::SD, OK2 = OK1 + Cfg::SA * Cfg::SC,
-                          OK3 = OK2 + Cfg::SA * Cfg::SD, OK4 = OK3 + Cfg::SB * Cfg::SC;
-            const int nend = og.kacc ? Cfg::NJK : OK1;
-            for (int e_ = OK1 + s; e_ < nend; e_ += TPQ) {
+            for (int x = s; x < NK4; x += TPQ) {
+                double a_ = 0.0;
                 double *dst;
-                double f = deg;
-                if (e_ < OK2) { const int x = e_ - OK1; dst = og.kacc + (size_t)(ai + x / Cfg::SC) * n + ak + x % Cfg::SC; }
-                else if (e_ < OK3) { const int x = e_ - OK2; dst = og.kacc + (size_t)(ai + x / Cfg::SD) * n + al + x % Cfg::SD; }
-                else if (e_ < OK4) { const int x = e_ - OK3; dst = og.kacc + (size_t)(aj + x / Cfg::SC) * n + ak + x % Cfg::SC; }
-                else { const int x = e_ - OK4; dst = og.kacc + (size_t)(aj + x / Cfg::SD) * n + al + x % Cfg::SD; }
-                atomicAdd(dst, f * jk[e_]);
+                if (x < O2) {  // (a, c): sum over b, d
+                    const int ma = x / SC, mc = x % SC;
+#pragma unroll
+                    for (int mb = 0; mb < SB; mb++)
+#pragma unroll
+                        for (int md = 0; md < SD; md++) a_ += cur[((ma * SB + mb) * SC + mc) * SD + md] * D[(size_t)(aj + mb) * n + al + md];
+                    dst = og.kacc + (size_t)(ai + ma) * n + ak + mc;
+                } else if (x < O3) {  // (a, d): sum over b, c
+                    const int y = x - O2, ma = y / SD, md = y % SD;
+#pragma unroll
+                    for (int mb = 0; mb < SB; mb++)
+#pragma unroll
+                        for (int mc = 0; mc < SC; mc++) a_ += cur[((ma * SB + mb) * SC + mc) * SD + md] * D[(size_t)(aj + mb) * n + ak + mc];
+                    dst = og.kacc + (size_t)(ai + ma) * n + al + md;
+                } else if (x < O4) {  // (b, c): sum over a, d
+                    const int y = x - O3, mb = y / SC, mc = y % SC;
+#pragma unroll
+                    for (int ma = 0; ma < SA; ma++)
+#pragma unroll
+                        for (int md = 0; md < SD; md++) a_ += cur[((ma * SB + mb) * SC + mc) * SD + md] * D[(size_t)(ai + ma) * n + al + md];
+                    dst = og.kacc + (size_t)(aj + mb) * n + ak + mc;
+                } else {  // (b, d): sum over a, c
+                    const int y = x - O4, mb = y / SD, md = y % SD;
+#pragma unroll
+                    for (int ma = 0; ma < SA; ma++)
+#pragma unroll
+                        for (int mc = 0; mc < SC; mc++) a_ += cur[((ma * SB + mb) * SC + mc) * SD + md] * D[(size_t)(ai + ma) * n + ak + mc];
+                    dst = og.kacc + (size_t)(aj + mb) * n + al + md;
+                }
+                atomicAdd(dst, deg * a_);
             }
         }
     }
