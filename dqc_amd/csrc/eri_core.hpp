@@ -134,11 +134,6 @@ struct EriCfg {
 #endif
     static constexpr size_t REG_DOUBLES = (size_t)REGION * QPB;
     static constexpr size_t LDS_BYTES = sizeof(double) * (REG_DOUBLES + TAB_DOUBLES);
-    // JK mode (direct SCF): per-quartet partial sums J_ab, J_cd, K_ac, K_ad, K_bc, K_bd behind the region
-    static constexpr int NJK = SA * SB + SC * SD + SA * SC + SA * SD + SB * SC + SB * SD;
-    static constexpr int REGION_JK = (REG0 + NJK) | 1;
-    static constexpr size_t REG_DOUBLES_JK = (size_t)REGION_JK * QPB;
-    static constexpr size_t LDS_BYTES_JK = sizeof(double) * (REG_DOUBLES_JK + TAB_DOUBLES);
     // GRAD mode contracts straight from the accumulators: only the 2D-integral staging area is needed
     static constexpr int REGION_G = GSZ | 1;
     static constexpr size_t REG_DOUBLES_G = (size_t)(REGION_G * QPB > 16 ? REGION_G * QPB : 16);
@@ -185,8 +180,9 @@ struct OidxTab {
 //                   the derivative d/dA of (a b|c d); it is contracted on the fly with Cartesian density matrices,
 //                   sum [jfac D_ab D_cd - k (D_ac D_bd + D_ad D_bc)], and added to the gradient of a's atom
 //   ERI_OUT_JK    : direct SCF -- nothing is stored; the spherical block of every unique shell quartet is contracted with the
-//                   density on the fly (J_ab += (ab|cd) D_cd, J_cd += (ab|cd) D_ab, four exchange products), summed per
-//                   quartet in LDS and added to the global accumulators with one atomic per (shell-pair) element
+//                   density on the fly (J_ab += (ab|cd) D_cd, J_cd += (ab|cd) D_ab, four exchange products): passes over the
+//                   quartet's block in LDS, a lane per result element, one global atomic per (shell-pair) element -- or per
+//                   WAVE for the Coulomb block the wave's quartets share
 //   ERI_OUT_SCHWARZ : the diagonal quartets (ab|ab) only (task map `same` = 2): max over the spherical block of |(ab|ab)| per
 //                   shell pair -> tiles[pair] (as the bit pattern of a non-negative double, atomicMax) -- the Schwarz bounds
 //                   Q_ab = sqrt(max |(ab|ab)|), |(ab|cd)| <= Q_ab Q_cd, of the screened direct SCF (dqc_direct_*)
