@@ -147,15 +147,25 @@ struct ClassLoop {
 // screened task maps of one J / K pass (direct-SCF context below): per class pair (cb >= ck) the slice of the device array of
 // prefix offsets (EriOut::toff) and the number of surviving tasks (waves, for the one-lane-per-quartet classes)
 constexpr int NCLS_ALL = (DQC_LMAX + 1) * (DQC_LMAX + 2) / 2;
+struct DirectCtx;
 struct ScreenPlan {
     const long long *d_toff = nullptr;
     const int *d_bins = nullptr;  // (NCLS_ALL, SCREEN_NBIN + 1) bin starts of every pair class, relative to the class start
     long long start[NCLS_ALL][NCLS_ALL], total[NCLS_ALL][NCLS_ALL];
+    // the entries of a class pair are computed and uploaded right before its launch (plan_screen_pair): the device works on the first
+    // class pairs while the host plans the later ones -- planning everything first left it idle for ~1 ms per pass
+    DirectCtx *ctx = nullptr;
+    const double *dl = nullptr;  // 5 x 5 density maxima by angular momentum (or nullptr: tc_all)
+    double tc_all = 0.0, tau = 0.0;
+    bool with_k = false;
+    hipStream_t st = nullptr;
+    bool upload = false;  // upload every planned slice on `st` (which may be the null stream)
 };
+static int plan_screen_pair(ScreenPlan &sp, int cb, int ck);
 
 template <int LA, int LB, int LC, int LD>
 static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st,
-                           const ScreenPlan *sp = nullptr) {
+                           ScreenPlan *sp = nullptr) {
     using Cfg = EriCfg<LA, LB, LC, LD>;
     const int cb = LA * (LA + 1) / 2 + LB, ck = LC * (LC + 1) / 2 + LD;
     const int nb = hp.cls_count[cb], nk = hp.cls_count[ck];
@@ -165,11 +175,14 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
     long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     EriOut o2 = og;
     if (sp) {
+        if (int rc = plan_screen_pair(*sp, cb, ck)) return rc;
         ntask = sp->total[cb][ck];
         if (ntask == 0) return 0;
         o2.toff = sp->d_toff + sp->start[cb][ck];
-        o2.pbin = sp->d_bins + (Cfg::TPQ == 1 ? cb : ck) * (SCREEN_NBIN + 1);  // bins of the PARTNER list the prefixes run over
-        nblk = Cfg::TPQ == 1 ? (ntask + 3) / 4 : (ntask + Cfg::QPB - 1) / Cfg::QPB;
+        // (one-lane classes: entries per ket pair, tasks = waves -- unless the class takes the bra-uniform entries, eri_core.hpp FLIP1)
+        const bool ket_entries = Cfg::TPQ == 1 && !(og.flip1 && Cfg::SA * Cfg::SB > Cfg::SC * Cfg::SD);
+        o2.pbin = sp->d_bins + (ket_entries ? cb : ck) * (SCREEN_NBIN + 1);  // bins of the PARTNER list the prefixes run over
+        nblk = ket_entries ? (ntask + 3) / 4 : (ntask + Cfg::QPB - 1) / Cfg::QPB;
     }
     nblk = (nblk + o2.nparts - 1) / o2.nparts;  // this rank's share of the blocks (dqc_direct_jk_part)
     // Coulomb only (Kohn-Sham): the mode without the exchange accumulators in LDS (eri_core.hpp: ERI_OUT_J)
@@ -188,7 +201,7 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
 template <int CB, int CK>
 struct ClassLoopJK {
     static int run(const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og, hipStream_t st,
-                   const ScreenPlan *sp = nullptr) {
+                   ScreenPlan *sp = nullptr) {
         constexpr int LA = CB < 1 ? 0 : (CB < 3 ? 1 : (CB < 6 ? 2 : 3)), LB = CB - LA * (LA + 1) / 2;
         constexpr int LC = CK < 1 ? 0 : (CK < 3 ? 1 : (CK < 6 ? 2 : 3)), LD = CK - LC * (LC + 1) / 2;
         int rc = launch_class_jk<LA, LB, LC, LD>(ds, dp, hp, og, st, sp);
@@ -224,7 +237,7 @@ struct ClassLoopSchwarz {
 // (eri_generic.hpp); DQC_ERI_GENERIC=1: all classes
 template <int MODE>
 static int run_generic_classes(double *tiles, const DevShells &ds, const DevPairs &dp, const HostPairs &hp, const EriOut &og,
-                               hipStream_t st, const ScreenPlan *sp = nullptr) {
+                               hipStream_t st, ScreenPlan *sp = nullptr) {
     for (int la = 0; la <= DQC_LMAX; la++)
         for (int lb = 0; lb <= la; lb++)
             for (int lc = 0; lc <= la; lc++)
@@ -236,6 +249,7 @@ static int run_generic_classes(double *tiles, const DevShells &ds, const DevPair
                     EriOut o2 = og;
                     long long nscr = -1;
                     if (sp) {
+                        if (int rc = plan_screen_pair(*sp, cb, ck)) return rc;
                         nscr = sp->total[cb][ck];
                         o2.toff = sp->d_toff + sp->start[cb][ck];
                         o2.pbin = sp->d_bins + ck * (SCREEN_NBIN + 1);
@@ -295,8 +309,15 @@ struct DirectCtx {
     double *d_q = nullptr, *d_dsh = nullptr, *d_sym = nullptr, *d_a = nullptr, *d_b = nullptr, *d_dmax = nullptr;
     long long *d_toff = nullptr;
     int *d_bins = nullptr;
+    int split_per = 16;     // (plan_screen / EriOut::split_per; DQC_ERI_SPLIT_PER)
+    int flip1 = 1;          // (plan_screen / EriOut::flip1; DQC_ERI_FLIP1=0: A/B runs)
     std::vector<int> bins;  // (NCLS_ALL, SCREEN_NBIN + 1): starts of the contraction-depth bins of every class (relative)
-    std::vector<long long> h_toff;
+    // offsets of the screened task maps, PINNED: every class pair's slice is uploaded on its own in front of its launch (plan_screen_pair)
+    // -- from pageable memory the runtime locks and unlocks the pages of each copy, and slices that share pages faulted on the device
+    long long *h_toff = nullptr;
+    size_t n_toff = 0;
+    std::vector<long long> cnt_scratch;
+    ~DirectCtx() { if (h_toff) (void)hipHostFree(h_toff); }
     long long stat_total = 0, stat_launched = 0;  // unique quartets / quartets launched, last pass
     double stat_dmax = 0.0;
 };
@@ -374,16 +395,39 @@ static int group_pair_members(const Basis &bg, int ga, int gb, int slot[4], int 
 // survivors are a prefix and a two-pointer sweep per (bin, bin) block finds them all)
 // dl: nullptr (one threshold `tc` for every class pair) or the 5 x 5 table of density maxima by angular momentum -- then the
 // threshold of a class pair is tau / max(4 dl[la][lb], 4 dl[lc][ld], and with K: dl[la][lc], dl[la][ld], dl[lb][lc], dl[lb][ld])
-static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const double *dl = nullptr, double tau = 0.0, bool with_k = false) {
-    c.h_toff.clear();
-    c.stat_total = c.stat_launched = 0;
-    std::vector<long long> cnt;
+static void plan_screen_begin(DirectCtx &c, ScreenPlan &sp, double tc_all, const double *dl = nullptr, double tau = 0.0, bool with_k = false,
+                              bool upload = false, hipStream_t upload_on = nullptr) {
+    // slices of the offset array: fixed per class pair (the larger of the two lists owns the entries at most)
+    size_t n = 0;
     for (int cb = 0; cb < NCLS_ALL; cb++)
         for (int ck = 0; ck <= cb; ck++) {
-            sp.start[cb][ck] = (long long)c.h_toff.size();
+            sp.start[cb][ck] = (long long)n;
+            sp.total[cb][ck] = 0;
+            if (c.hp.cls_count[cb] && c.hp.cls_count[ck]) n += (size_t)std::max(c.hp.cls_count[cb], c.hp.cls_count[ck]) * SCREEN_NBIN + 1;
+        }
+    (void)n;  // (== n_toff: dqc_direct_create sized the host and device arrays with the same formula)
+    c.stat_total = c.stat_launched = 0;
+    sp.ctx = &c;
+    sp.dl = dl;
+    sp.tc_all = tc_all;
+    sp.tau = tau;
+    sp.with_k = with_k;
+    sp.st = upload_on;
+    sp.upload = upload;
+}
+
+static int plan_screen_pair(ScreenPlan &sp, int cb, int ck) {
+    DirectCtx &c = *sp.ctx;
+    const double *dl = sp.dl;
+    const double tau = sp.tau;
+    const bool with_k = sp.with_k;
+    std::vector<long long> &cnt = c.cnt_scratch;
+    long long *toff = c.h_toff + sp.start[cb][ck];
+    {
+        {
             sp.total[cb][ck] = 0;
             const int nb = c.hp.cls_count[cb], nk = c.hp.cls_count[ck];
-            if (nb == 0 || nk == 0) continue;
+            if (nb == 0 || nk == 0) return 0;
             int la, lb, lc, ld;
             class_l(cb, la, lb);
             class_l(ck, lc, ld);
@@ -394,14 +438,16 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
             auto Wk = [&](int lo_, int hi_) { return wk_[hi_] - wk_[lo_]; };
             const long long Sb = Wb(0, nb), Sk = Wk(0, nk);
             c.stat_total += same ? Sb * (Sb + 1) / 2 : Sb * Sk;
-            double tc = tc_all;
+            double tc = sp.tc_all;
             if (dl) {
                 auto d2 = [&](int x, int y) { return std::max(dl[5 * x + y], dl[5 * y + x]); };
                 double m = 4.0 * std::max(d2(la, lb), d2(lc, ld));
                 if (with_k) m = std::max(std::max(m, std::max(d2(la, lc), d2(la, ld))), std::max(d2(lb, lc), d2(lb, ld)));
                 tc = m > 0.0 ? tau / m : INFINITY;
             }
-            const bool tpq1 = !hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX && eri_tpq(ncart(la) * ncart(lb) * ncart(lc) * ncart(ld)) == 1;
+            // (one-lane classes with a larger bra than ket block may take the bra-uniform entries: eri_core.hpp, FLIP1)
+            const bool flip = c.flip1 && (2 * la + 1) * (2 * lb + 1) > (2 * lc + 1) * (2 * ld + 1);
+            const bool tpq1 = !hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX && eri_tpq(ncart(la) * ncart(lb) * ncart(lc) * ncart(ld)) == 1 && !flip;
             const double *qb = c.q.data() + c.hp.cls_start[cb], *qk = c.q.data() + c.hp.cls_start[ck];
             const int *bb = c.bins.data() + (size_t)cb * (SCREEN_NBIN + 1), *bk = c.bins.data() + (size_t)ck * (SCREEN_NBIN + 1);
             const int nown = tpq1 ? nk : nb;  // the list the entries belong to: ket pairs (one lane per quartet) or bra pairs
@@ -442,14 +488,36 @@ static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp, const doubl
                         }
                     }
                 }
+            // multi-lane classes with lane groups of <= 16 lanes: PS slots per task (eri_split_lanes of the ket bin's depth bound and
+            // the bra pair's primitive count), every entry starting at a multiple of its PS (eri_core.hpp, screened map)
+            const int tpq_ = (!hl_forced() && la <= ERI_LMAX && lc <= ERI_LMAX) ? eri_tpq(ncart(la) * ncart(lb) * ncart(lc) * ncart(ld)) : 0;
+            const bool split = tpq_ >= 1 && tpq_ <= 16 && !tpq1;
             long long run = 0;
-            c.h_toff.push_back(0);
+            size_t w = 0;
             for (size_t e = 0; e < cnt.size(); e++) {
-                run += cnt[e];
-                c.h_toff.push_back(run);
+                int ps = 1;
+                if (split) {
+                    const int ib = c.hp.cls_start[cb] + (int)(e / SCREEN_NBIN);
+                    ps = eri_split_lanes((int)(e % SCREEN_NBIN), c.hp.pp_off[ib + 1] - c.hp.pp_off[ib], tpq_, c.split_per);
+                    run = (run + ps - 1) / ps * ps;
+                }
+                toff[w++] = run;
+                run += cnt[e] * ps;
             }
+            toff[w++] = run;
             sp.total[cb][ck] = run;
+            if (sp.upload && run > 0)
+                DQC_HIP(hipMemcpyAsync(c.d_toff + sp.start[cb][ck], toff, sizeof(long long) * w, hipMemcpyHostToDevice, sp.st));
         }
+    }
+    return 0;
+}
+
+// all class pairs at once, nothing uploaded (statistics of an unscreened pass)
+static void plan_screen(DirectCtx &c, double tc_all, ScreenPlan &sp) {
+    plan_screen_begin(c, sp, tc_all);
+    for (int cb = 0; cb < NCLS_ALL; cb++)
+        for (int ck = 0; ck <= cb; ck++) (void)plan_screen_pair(sp, cb, ck);
 }
 
 // max |D| over the AO block of every shell pair, and over the whole matrix (non-negative doubles order like their bit patterns)
@@ -601,7 +669,12 @@ int dqc_direct_create(void **ctx_out, const int *atm, int natm, const int *bas, 
     }
     DQC_HIP(hipStreamSynchronize(st));  // the uploads read host vectors that may move
     c->dp = DevPairs{d_sh, d_off, d_pp, c->hp.stride};
-    c->h_toff.reserve(ntoff);
+    c->n_toff = ntoff;
+    if (hipHostMalloc((void **)&c->h_toff, sizeof(long long) * std::max<size_t>(ntoff, 1), hipHostMallocDefault) != hipSuccess) {
+        c->h_toff = nullptr;
+        set_error("dqc_direct_create: pinned host allocation failed");
+        return DQC_ENOMEM;
+    }
     *ctx_out = c.release();
     return DQC_OK;
 }
@@ -665,8 +738,13 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     og.part = part;
     og.nparts = nparts;
     if (const char *e = getenv("DQC_ERI_DBG")) og.dbg = atoi(e);  // timing experiments (eri_core.hpp)
+    if (const char *e = getenv("DQC_ERI_SPLIT_PER")) c.split_per = atoi(e) > 0 ? atoi(e) : 1 << 30;
+    og.split_per = c.split_per;
+    if (const char *e = getenv("DQC_ERI_FLIP1")) c.flip1 = atoi(e) != 0;
+    og.flip1 = c.flip1;
     ScreenPlan sp;
-    const ScreenPlan *spp = nullptr;
+    ScreenPlan *spp = nullptr;
+    double dmx[26];  // [0]: max |D|, [1 + 5 li + lj]: by angular momentum of the block (read by the planner until the last launch)
     int rc;
     if (tau > 0.0) {
         DQC_HIP(hipMemsetAsync(c.d_dmax, 0, sizeof(double) * 26, st));
@@ -676,13 +754,10 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
         DQC_CHECK_LAUNCH();
         hipLaunchKernelGGL(shell_dmax_by_l_kernel, dim3((unsigned)((npr + 255) / 256)), dim3(256), 0, st, c.d_dmax, c.d_dsh, c.ds.l, nsh);
         DQC_CHECK_LAUNCH();
-        double dmx[26];  // [0]: max |D|, [1 + 5 li + lj]: by angular momentum of the block
         DQC_HIP(hipMemcpyAsync(dmx, c.d_dmax, sizeof(dmx), hipMemcpyDeviceToHost, st));
         DQC_HIP(hipStreamSynchronize(st));  // the launch sizes of this pass depend on the density maxima
         c.stat_dmax = dmx[0];
-        plan_screen(c, 0.0, sp, dmx + 1, tau, d_K != nullptr);
-        if (!c.h_toff.empty())
-            DQC_HIP(hipMemcpyAsync(c.d_toff, c.h_toff.data(), sizeof(long long) * c.h_toff.size(), hipMemcpyHostToDevice, st));
+        plan_screen_begin(c, sp, 0.0, dmx + 1, tau, d_K != nullptr, true, st);  // (the class pairs are planned one by one in front of their launches)
         sp.d_toff = c.d_toff;
         sp.d_bins = c.d_bins;
         spp = &sp;

@@ -258,7 +258,9 @@ struct EriOut {
     const WaveRun *wruns = nullptr;
     int nruns = 0;
     int wbin[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int dbg = 0;  // timing experiments (DQC_ERI_DBG): 1 = skip the primitive loops, 2 = skip the output phase, 4 = skip the tile stores only
+    int flip1 = 0;      // screened maps of the one-lane classes with a larger bra than ket block: bra-uniform entries (see FLIP1)
+    int split_per = 16; // screened maps of the multi-lane classes: primitive quartets per lane group below which a quartet is not spread further
+    int dbg = 0;  // timing experiments (DQC_ERI_DBG): 1 = skip the primitive loops, 2 = skip the output phase, 4 = skip the tile stores only, 8 = skip the Coulomb atomics of the direct modes
     // ---- one molecule sharded over GPUs (dqc_direct_jk_part): this launch is part `part` of `nparts` interleaved block sets
     int part = 0, nparts = 1;
     // ---- TILES mode: slice [st_lo, st_hi) (double offsets) of the store this launch fills (dqc_eri_fill_tiles_part)
@@ -285,10 +287,10 @@ __host__ __device__ constexpr int screen_bin(int npp) {
 __host__ __device__ constexpr int screen_bin_bound(int bin) {  // largest primitive-pair count of the bin (bin 0: open, 128 stands in)
     return bin == 0 ? 128 : (128 >> bin);
 }
-__host__ __device__ inline int eri_split_lanes(int bin, int nkp, int tpq) {  // tpq: lanes of one lane group (EriCfg::TPQ <= 16)
+__host__ __device__ inline int eri_split_lanes(int bin, int nkp, int tpq, int per = 8) {  // tpq: lanes of one lane group (EriCfg::TPQ <= 16)
     const int depth = screen_bin_bound(bin) * nkp;
     int ps = 1;
-    while (ps * tpq < 64 && ps * 8 < depth) ps <<= 1;
+    while (ps * tpq < 64 && ps * per < depth) ps <<= 1;
     return ps;
 }
 
@@ -383,6 +385,10 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     static_assert((NPB == 1 || NPB == PairSlots<LA, LB>::N) && (NPK == 1 || NPK == PairSlots<LC, LD>::N), "slot count of the pair class");
     constexpr int NR = Cfg::NR, TPQ = Cfg::TPQ, QPB = Cfg::QPB, NPT = Cfg::NPT, G1 = Cfg::G1, NOUT = Cfg::NOUT;
     constexpr int NMAX = LA + LB, MMAX = LC + LD;
+    // one-lane classes whose bra block is larger than the ket block ((ps|ss), (pp|ss), (ds|ss)): under the wave-transposed map every
+    // lane adds its own Coulomb bra block (9 atomics per quartet in (pp|ss): that launch ran at the atomic rate, 1.26 ms against
+    // 0.55 ms in the fill); the screened direct maps may take the bra-uniform entries of the multi-lane classes instead (og.flip1)
+    constexpr bool FLIP1 = DIRECT && TPQ == 1 && Cfg::SA * Cfg::SB > Cfg::SC * Cfg::SD;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ int s_maxq;
 
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     } else if (og.toff != nullptr) {
         // screened map (direct SCF): the surviving tasks of every bra pair -- or, one lane per quartet, the surviving 64-bra-pair
         // chunks of every ket pair -- are a prefix of the Schwarz-sorted partner list; ntask counts tasks (waves)
-        if constexpr (TPQ == 1) {
+        if (TPQ == 1 && !(FLIP1 && og.flip1)) {
             const long long wv = bidx * 4 + (tid >> 6);
             const bool inr = wv < ntask;
             const long long w2 = inr ? wv : ntask - 1;
@@ -432,7 +438,22 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
         } else {
             const int e = screen_find(og.toff, nb * SCREEN_NBIN, task);
             ib = e / SCREEN_NBIN;
-            ik = og.pbin[e % SCREEN_NBIN] + (int)(task - og.toff[e]);
+            const int bin = e % SCREEN_NBIN;
+            if constexpr (TPQ <= 16) {
+                // the primitive quartets of a quartet spread over PS lane groups here too (from the ket bin's depth bound and the
+                // bra pair's primitive count): an entry holds PS slots per task and starts at a multiple of its PS (plan_screen), so
+                // the PS groups of a quartet are an aligned run of lane groups of one wave.  The slots that pad an entry's tail map
+                // to partners behind its prefix: past the bin, above the diagonal, or under the threshold (screen_skip)
+                const int nbp_ = prs.pp_off[b0 + ib + 1] - prs.pp_off[b0 + ib];
+                psl = eri_split_lanes(bin, nbp_, TPQ, og.split_per);
+                const int rel = (int)(task - og.toff[e]);
+                ik = og.pbin[bin] + rel / psl;
+                psj = rel % psl;
+                active = active && ik < og.pbin[bin + 1] && (!same || ik <= ib);
+                ik = ik < nk ? ik : nk - 1;
+            } else {
+                ik = og.pbin[bin] + (int)(task - og.toff[e]);
+            }
         }
     } else
     if (TPQ <= 16 && og.wruns != nullptr) {
@@ -739,11 +760,19 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
     }  // (general path)
     if constexpr (TPQ <= 16) {
         // the lane groups that shared the quartet's primitive quartets combine their partial sums (every group ends with the total)
-        for (int o = 1; o < psl; o <<= 1)
+        // (psl is wave-uniform under the fill's wave maps; the screened maps of the multi-lane classes mix entries in a wave: the
+        // shuffles run to the wave's largest count, every lane adds only inside its own run of groups)
+        int pslw = psl;
+        if constexpr (DIRECT)
+            for (int o = TPQ; o < 64; o <<= 1) pslw = max(pslw, __shfl_xor(pslw, o));
+        for (int o = 1; o < pslw; o <<= 1)
 #pragma unroll
             for (int e = 0; e < NE; e++)
 #pragma unroll
-                for (int m = 0; m < NPT; m++) acc[e][m] += __shfl_xor(acc[e][m], o * TPQ);
+                for (int m = 0; m < NPT; m++) {
+                    const double t_ = __shfl_xor(acc[e][m], o * TPQ);
+                    if (o < psl) acc[e][m] += t_;
+                }
     }
     if constexpr (MODE == ERI_OUT_GRAD) {
         // ---------------- gradient contraction straight from the Cartesian accumulators ----------------
@@ -931,7 +960,7 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 if (am != 0ull) {
                     const int first = __ffsll((long long)am) - 1;
                     ai0 = __shfl(ai, first); aj0 = __shfl(aj, first); ak0 = __shfl(ak, first); al0 = __shfl(al, first);
-                    if constexpr (TPQ > 1) share_ab = __all(!act || (ai == ai0 && aj == aj0));
+                    if (TPQ > 1 || (FLIP1 && og.flip1 && og.toff != nullptr)) share_ab = __all(!act || (ai == ai0 && aj == aj0));
                     else share_cd = __all(!act || (ak == ak0 && al == al0));
                 }
             }
@@ -949,8 +978,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
                 if (share_ab) {
                     for (int o = TPQ; o < 64; o <<= 1) a_ += __shfl_xor(a_, o);
-                    if (grp0 && a_ != 0.0) atomicAdd(og.jacc + (size_t)(ai0 + ab / Cfg::SB) * n + aj0 + ab % Cfg::SB, a_);
-                } else if (act) {
+                    if (grp0 && a_ != 0.0 && (!(og.dbg & 8) || a_ == 12345.678)) atomicAdd(og.jacc + (size_t)(ai0 + ab / Cfg::SB) * n + aj0 + ab % Cfg::SB, a_);
+                } else if (act && (!(og.dbg & 8) || a_ == 12345.678)) {
                     atomicAdd(og.jacc + (size_t)(ai + ab / Cfg::SB) * n + aj + ab % Cfg::SB, a_);
                 }
             }
@@ -966,8 +995,8 @@ __global__ __launch_bounds__(256) void eri_kernel(double *__restrict__ tiles, De
                 }
                 if (share_cd) {
                     for (int o = 1; o < 64; o <<= 1) a_ += __shfl_xor(a_, o);
-                    if ((tid & 63) == 0 && a_ != 0.0) atomicAdd(og.jacc + (size_t)(ak0 + cd / Cfg::SD) * n + al0 + cd % Cfg::SD, a_);
-                } else if (act) {
+                    if ((tid & 63) == 0 && a_ != 0.0 && (!(og.dbg & 8) || a_ == 12345.678)) atomicAdd(og.jacc + (size_t)(ak0 + cd / Cfg::SD) * n + al0 + cd % Cfg::SD, a_);
+                } else if (act && (!(og.dbg & 8) || a_ == 12345.678)) {
                     atomicAdd(og.jacc + (size_t)(ak + cd / Cfg::SD) * n + al + cd % Cfg::SD, a_);
                 }
             }

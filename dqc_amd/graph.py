@@ -92,6 +92,7 @@ class GraphedSCFStep:
         self.f_in = torch.zeros(shape, dtype=engine.dtype, device=engine.device)
         idx = torch.arange(n, device=engine.device)
         self.f_in[..., idx, idx] = idx.to(engine.dtype)  # any matrix with a gap at n_occ
+        self.graph = None
         if not capture:
             return
         s = torch.cuda.Stream(device=engine.device)
@@ -149,5 +150,7 @@ class GraphedSCFStep:
     def __call__(self, f_in):
         if f_in is not self.f_in:
             self.f_in.copy_(f_in)
+        if self.graph is None:  # (capture=False: the same step, launched eagerly -- direct SCF builds are not capturable)
+            return self._body()
         self.graph.replay()
         return self.fock, self.dm, self.err

@@ -211,14 +211,16 @@ class SCF_QCCalc:
         graphed, purified = None, None
         # (direct SCF builds allocate stream-ordered scratch and upload pair tables per call: not captured)
         # (nor the builds of a Hamiltonian sharded over several GPUs: they hold collectives)
-        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "_direct", False) \
-                and not getattr(eng.hamilton, "sharded", False):
+        # A direct-SCF engine still takes the purification step, launched eagerly: the 412 x 412 eigh of naphthalene / cc-pVTZ is
+        # 6 ms of rocSOLVER launches per iteration against ~1 ms of GEMMs
+        direct = bool(getattr(eng.hamilton, "_direct", False))
+        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "sharded", False):
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
             if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and getattr(eng, "ovlp", None) is None:
-                purified = GraphedSCFStep(eng)
-            elif not pol:
+                purified = GraphedSCFStep(eng, capture=not direct)
+            elif not pol and not direct:
                 graphed = GraphedFock(eng)
         perr = None
         fprev = None
@@ -326,9 +328,11 @@ class SCF_QCCalc:
             fprev = fmix
             if purified is not None:
                 f_out, d_out, perr = purified(fmix)
-                # static buffers of the graph: copy out
-                fock, perr = f_out.clone(), perr.clone()
-                dm = SpinParam(u=d_out.u.clone(), d=d_out.d.clone()) if pol else d_out.clone()
+                if purified.graph is None:  # eager step (direct SCF): fresh tensors, and the Hamiltonian's caches stay keyed on them
+                    fock, dm = f_out, d_out
+                else:  # static buffers of the graph: copy out
+                    fock, perr = f_out.clone(), perr.clone()
+                    dm = SpinParam(u=d_out.u.clone(), d=d_out.d.clone()) if pol else d_out.clone()
             elif graphed is not None:
                 fock = graphed(eng.scp2orb(fmix)).clone()
                 dm = graphed.density_matrix().clone()

@@ -9,8 +9,9 @@ dev = torch.device("cuda")
 tab = dqc_amd.Mol(M.naphthalene(), basis="cc-pvtz").get_hamiltonian()._tab
 D = torch.as_tensor(M.seeded_dm_ao(tab.nao, 34, np.eye(tab.nao), 3), device=dev)
 ctx = lib.DirectContext(tab, dev)
+TAU = float(os.environ.get("DQC_TAU", "0"))
 for wk in (False, True):
-    ctx.jk(D, wk, 0.0); torch.cuda.synchronize()
+    ctx.jk(D, wk, TAU); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); ctx.jk(D, wk, 0.0); ctx.jk(D, wk, 0.0); e1.record(); torch.cuda.synchronize()
+    e0.record(); ctx.jk(D, wk, TAU); ctx.jk(D, wk, TAU); e1.record(); torch.cuda.synchronize()
     print("DBG=%s  with_k=%s  %.1f ms per pass" % (os.environ.get("DQC_ERI_DBG", "0"), wk, e0.elapsed_time(e1) / 2), flush=True)
