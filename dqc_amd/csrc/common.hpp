@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -201,6 +202,52 @@ struct DevPool {
 int upload_shells(DevShells &d, const Basis &b, DevPool &pool, hipStream_t st);
 
 inline int ncart(int l) { return (l + 1) * (l + 2) / 2; }
+
+// Side streams for the class launches of one ERI pass (fill, direct J / K, gradient).  A pass is ~55 launches of 0.2-3 ms, each
+// latency-bound with a long tail of deep quartets: dealt round-robin to a few streams, the next class fills the chip while the
+// last waves of the previous one drain (naphthalene / cc-pVTZ direct Coulomb pass 67.7 -> 63.7 ms with three streams).
+// fork(st): the side streams wait for what `st` holds so far; join(st): `st` waits for all of them.  One set per device and
+// process (DQC_SIDE_STREAMS = 0 / 1: none, default 3, at most 4); calls that share it are ordered by the events alone.
+struct SideStreams {
+    static constexpr int MAX = 4;
+    hipStream_t s[MAX] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[MAX] = {};
+    int n = 0, next = 0;
+    hipStream_t take() { return s[next++ % n]; }
+    int fork(hipStream_t st) {
+        if (hipEventRecord(ev_fork, st) != hipSuccess) return DQC_EHIP;
+        for (int i = 0; i < n; i++)
+            if (hipStreamWaitEvent(s[i], ev_fork, 0) != hipSuccess) return DQC_EHIP;
+        return DQC_OK;
+    }
+    int join(hipStream_t st) {
+        for (int i = 0; i < n; i++)
+            if (hipEventRecord(ev_join[i], s[i]) != hipSuccess || hipStreamWaitEvent(st, ev_join[i], 0) != hipSuccess) return DQC_EHIP;
+        return DQC_OK;
+    }
+};
+inline SideStreams *side_streams() {  // nullptr: switched off, or the streams could not be created
+    constexpr int MAXDEV = 16;
+    static SideStreams pool[MAXDEV];
+    static int state[MAXDEV] = {};  // 0: not tried, 1: there, -1: none
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0) {
+        const char *e = getenv("DQC_SIDE_STREAMS");
+        int want = e ? atoi(e) : 3;
+        want = want < 2 ? 0 : (want > SideStreams::MAX ? SideStreams::MAX : want);
+        SideStreams &p = pool[dev];
+        bool ok = want > 0 && hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < want; i++)
+            ok = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.ev_join[i], hipEventDisableTiming) == hipSuccess;
+        p.n = ok ? want : 0;
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1 ? &pool[dev] : nullptr;
+}
 
 }  // namespace dqc
 

@@ -60,7 +60,8 @@ __global__ void tiles_to_dense_kernel(double *__restrict__ dense, const double *
 // ---------------------------------------------------------------------------------------------
 // the pool the per-launch wave tables of a fill are uploaded through
 struct WaveMaps {
-    DevPool *pool = nullptr;
+    DevPool *pool = nullptr;      // stream-ordered pool of the wave tables (nullptr: flat task maps)
+    SideStreams *side = nullptr;  // class launches dealt round-robin to the side streams (common.hpp)
 };
 
 // One class launch of the fill.  Bra and ket pairs come from their own tables: the same one (a whole-store fill: diagonal classes
@@ -96,7 +97,8 @@ static int launch_class(double *tiles, const DevShells &ds, const FillTables &ft
     // contractions deep enough to be split at all (pairs are sorted by depth: the first pair of a class is its deepest); the
     // single-primitive classes of a cc-pVTZ fill are 1-2 % faster under the flat map
     const int dmax = (hpb.pp_off[hpb.cls_start[cb] + 1] - hpb.pp_off[hpb.cls_start[cb]]) * (hpk.pp_off[hpk.cls_start[ck] + 1] - hpk.pp_off[hpk.cls_start[ck]]);
-    if (Cfg::TPQ <= 16 && wm != nullptr && dmax > 16) {
+    if (wm != nullptr && wm->side != nullptr) st = wm->side->take();  // (the wave table's upload and the launch on the same stream)
+    if (Cfg::TPQ <= 16 && wm != nullptr && wm->pool != nullptr && dmax > 16) {
         EriOut o2 = og;
         long long nwave;
         if (same) {  // diagonal class (bra pair >= ket pair): one table entry per wave
@@ -160,6 +162,8 @@ struct ScreenPlan {
     bool with_k = false;
     hipStream_t st = nullptr;
     bool upload = false;  // upload every planned slice on `st` (which may be the null stream)
+    // class launches dealt round-robin to the side streams (common.hpp: SideStreams; forked from / joined to the caller's stream)
+    SideStreams *side = nullptr;
 };
 static int plan_screen_pair(ScreenPlan &sp, int cb, int ck);
 
@@ -175,6 +179,7 @@ static int launch_class_jk(const DevShells &ds, const DevPairs &dp, const HostPa
     long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     EriOut o2 = og;
     if (sp) {
+        if (sp->side) st = sp->st = sp->side->take();  // (slice upload and launch on the same stream)
         if (int rc = plan_screen_pair(*sp, cb, ck)) return rc;
         ntask = sp->total[cb][ck];
         if (ntask == 0) return 0;
@@ -249,6 +254,7 @@ static int run_generic_classes(double *tiles, const DevShells &ds, const DevPair
                     EriOut o2 = og;
                     long long nscr = -1;
                     if (sp) {
+                        sp->st = st;
                         if (int rc = plan_screen_pair(*sp, cb, ck)) return rc;
                         nscr = sp->total[cb][ck];
                         o2.toff = sp->d_toff + sp->start[cb][ck];
@@ -312,8 +318,8 @@ struct DirectCtx {
     int split_per = 16;     // (plan_screen / EriOut::split_per; DQC_ERI_SPLIT_PER)
     int flip1 = 1;          // (plan_screen / EriOut::flip1; DQC_ERI_FLIP1=0: A/B runs)
     std::vector<int> bins;  // (NCLS_ALL, SCREEN_NBIN + 1): starts of the contraction-depth bins of every class (relative)
-    // offsets of the screened task maps, PINNED: every class pair's slice is uploaded on its own in front of its launch (plan_screen_pair)
-    // -- from pageable memory the runtime locks and unlocks the pages of each copy, and slices that share pages faulted on the device
+    // offsets of the screened task maps, PINNED: every class pair's slice is uploaded on its own in front of its launch (plan_screen_pair),
+    // asynchronously
     long long *h_toff = nullptr;
     size_t n_toff = 0;
     std::vector<long long> cnt_scratch;
@@ -758,6 +764,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
         DQC_HIP(hipStreamSynchronize(st));  // the launch sizes of this pass depend on the density maxima
         c.stat_dmax = dmx[0];
         plan_screen_begin(c, sp, 0.0, dmx + 1, tau, d_K != nullptr, true, st);  // (the class pairs are planned one by one in front of their launches)
+        if ((sp.side = side_streams()) != nullptr && (rc = sp.side->fork(st))) { set_error("dqc_direct_jk: stream fork failed"); return rc; }
         sp.d_toff = c.d_toff;
         sp.d_bins = c.d_bins;
         spp = &sp;
@@ -772,6 +779,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     if ((rc = ClassLoopJK<NCLS - 1, NCLS - 1>::run(c.ds, c.dp, c.hp, og, st, spp))) return rc;
     if ((rc = run_generic_classes<ERI_OUT_JK>(nullptr, c.ds, c.dp, c.hp, og, st, spp))) return rc;
+    if (spp && sp.side && (rc = sp.side->join(st))) { set_error("dqc_direct_jk: stream join failed"); return rc; }
     hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, c.d_a, c.d_b, nao);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
@@ -831,10 +839,12 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     // depth-binned wave maps of the one-lane classes (DQC_ERI_WMAP=0: the plain wave-transposed map, A/B runs)
     static const bool wmap_env = [] { const char *e = getenv("DQC_ERI_WMAP"); return !(e && e[0] == '0'); }();
     WaveMaps wm;
-    wm.pool = &pool;
-    const WaveMaps *wmp = wmap_env ? &wm : nullptr;
+    wm.pool = wmap_env ? &pool : nullptr;
+    wm.side = side_streams();
+    const WaveMaps *wmp = &wm;
     if (tile_begin == 0 && tile_end == nt_all) {
         const FillTables ft{&dp, &dp, &hp, &hp, FILL_SAME_TABLE};
+        if (wm.side && (rc = wm.side->fork(st))) { set_error("dqc_eri_fill_tiles: stream fork failed"); return rc; }
         rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, ft, st, og, wmp);
         if (rc) return rc;
     } else {
@@ -902,11 +912,13 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
         };
         if ((rc = up(h1, d1)) || (rc = up(h0, d0))) { set_error("dqc_eri_fill_tiles_part: device upload failed"); return rc; }
         const FillTables f11{&d1, &d1, &h1, &h1, FILL_SAME_TABLE}, f10{&d1, &d0, &h1, &h0, FILL_CROSS}, f01{&d0, &d1, &h0, &h1, FILL_CROSS_OFFDIAG};
+        if (wm.side && (rc = wm.side->fork(st))) { set_error("dqc_eri_fill_tiles_part: stream fork failed"); return rc; }
         if ((rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f11, st, og, wmp)) || (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f10, st, og, wmp)) ||
             (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f01, st, og, wmp)))
             return rc;
     }
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;
+    if (wm.side && (rc = wm.side->join(st))) { set_error("dqc_eri_fill_tiles: stream join failed"); return rc; }
     return DQC_OK;
 }
 

@@ -89,6 +89,7 @@ struct GradCtx {
     const HostPairs *hbra, *hket;
     EriOut og;
     DevPool *pool = nullptr;  // stream-ordered pool for the wave tables (nullptr: flat task maps)
+    SideStreams *side = nullptr;  // class launches dealt round-robin to the side streams (common.hpp)
     int wmap_depth = 1 << 30;  // class pairs whose deepest contraction has at least this many primitive quartets take the wave map
 };
 
@@ -102,6 +103,7 @@ static int launch_grad_class(const GradCtx &c, hipStream_t st) {
     const long long nblk = eri_num_blocks<Cfg>(nb, nk, ntask);
     auto kern = eri_kernel<LA, LB, LC, LD, ERI_OUT_GRAD>;
     (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES_G);
+    if (c.side != nullptr) st = c.side->take();
     // (only where the class pair's deepest contraction -- first pair of each class: the lists are sorted by depth -- is worth splitting)
     const int dmax = (c.hbra->pp_off[c.hbra->cls_start[cb] + 1] - c.hbra->pp_off[c.hbra->cls_start[cb]]) *
                      (c.hket->pp_off[c.hket->cls_start[ck] + 1] - c.hket->pp_off[c.hket->cls_start[ck]]);
@@ -437,10 +439,12 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     c.og = EriOut{0, 0, 0, 0};
     c.og.dcart = d_dcart; c.og.ncart = ncart; c.og.cao = d_cao; c.og.sh_atom = d_atom; c.og.gpart = d_part;
     c.og.nslot = nslot; c.og.natm = natm; c.og.norig = N; c.og.jscale = jscale; c.og.kscale = kscale;
+    if ((c.side = side_streams()) != nullptr && (rc = c.side->fork(st))) { set_error("dqc_eri_grad: stream fork failed"); return rc; }
     c.dbra = dup; c.hbra = &hup; c.og.dirn = +1;
     if ((rc = launch_grad_all(c, st))) return rc;
     c.dbra = ddown; c.hbra = &hdown; c.og.dirn = -1;
     if ((rc = launch_grad_all(c, st))) return rc;
+    if (c.side && (rc = c.side->join(st))) { set_error("dqc_eri_grad: stream join failed"); return rc; }
     // fold the slots into d_grad on the host side of the stream: tiny
     std::vector<double> part((size_t)nslot * natm * 3), g((size_t)natm * 3);
     DQC_HIP(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
