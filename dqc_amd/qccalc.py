@@ -213,8 +213,9 @@ class SCF_QCCalc:
         # (nor the builds of a Hamiltonian sharded over several GPUs: they hold collectives)
         # A direct-SCF engine still takes the purification step, launched eagerly: the 412 x 412 eigh of naphthalene / cc-pVTZ is
         # 6 ms of rocSOLVER launches per iteration against ~1 ms of GEMMs
-        direct = bool(getattr(eng.hamilton, "_direct", False))
-        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(eng.hamilton, "sharded", False):
+        ham = getattr(eng, "hamilton", None)
+        direct = bool(getattr(ham, "_direct", False))
+        if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(ham, "sharded", False):
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
