@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256) void eri_hl_kernel(double *__restrict__ tiles,
                         atomicAdd(&jk[ok4 + mb * sd + md], v * D[(size_t)i * n + k]);
                     }
                 } else if constexpr (MODE == ERI_OUT_TILES) {
-                    tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
+                    // (one of the two equal-by-symmetry values of a quartet with a repeated shell: eri_core.hpp, bitwise reproducible store)
+                    const bool twin = (ai == aj && mb > ma) || (ak == al && md > mc) || (ai == ak && aj == al && mc * sd + md > ma * sb + mb);
+                    if (!twin) tile_put_all(tiles, i, j, k, l, v, og.st_lo, og.st_hi, og.st_nao);
                 } else if constexpr (MODE == ERI_OUT_3C) {
                     const size_t io = i - og.ao0, jo = j - og.ao0, kx = k - og.aux0;
                     tiles[(io * og.nao + jo) * og.naux + kx] = v;
