@@ -779,6 +779,42 @@ class HamiltonMI355(_Base):
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
 
+    def get_elrep_plus_vxc_pol(self, dm: SpinParam):
+        """J[D_u + D_d] + Vxc_s[D_u, D_d] of an unrestricted pair of density matrices as a stacked (2, nao, nao) tensor in the
+        orthogonalised basis -- the sums the polarised `_KSEngine.__dm2fock` forms (ks.py:176-187, hf.py:93-103) -- with ONE batched
+        AO -> orthogonal conversion X^T (J_ao + V_s,ao) X of the two sums instead of one per operator (three), the AO-basis total
+        density from the two orbital factors when they are known, and the Coulomb stream over the tile store (HBM-bound) enqueued on
+        a second stream BESIDE the two-spin grid pass (its Vxc products are bound by the matrix cores; DQC_AMD_J_OVERLAP=0 or a
+        graph capture: one stream).  Same numbers as get_elrep(dm.u + dm.d) + get_vxc(dm) up to round-off."""
+        assert self.xc is not None and dm.u.dim() == 2 and self._df is None and not self._direct and self._tile_slice is None
+        n = self._nao_ao
+        fu, fd = self._factor_of(dm.u), self._factor_of(dm.d)
+        if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
+            dao = (fu[0][0] @ fu[0][1] + fd[0][0] @ fd[0][1])[:n, :n].contiguous()
+        else:
+            dao = self._unconvert_dm(dm.u + dm.d)
+        side = None
+        if dao.is_cuda and os.environ.get("DQC_AMD_J_OVERLAP", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            side = getattr(self, "_j_stream", None)
+            if side is None:
+                side = self._j_stream = torch.cuda.Stream(device=dao.device)
+        if side is not None:
+            main = torch.cuda.current_stream(dao.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                jao, _ = self._jk_ao(dao, False)
+        else:
+            jao, _ = self._jk_ao(dao, False)
+        potinfo = self.xc.get_vxc(self._dm2densinfo_pol(dm))
+        vu = self._vxc_ao_from_potinfo(potinfo.u)[:n, :n]
+        vd = self._vxc_ao_from_potinfo(potinfo.d)[:n, :n]
+        if side is not None:
+            main.wait_stream(side)
+            jao.record_stream(main)  # (allocated on the side stream, read and later freed on this one)
+        x = self._orthozer
+        mat = x.transpose(-2, -1) @ torch.stack([jao + vu, jao + vd]) @ x
+        return (mat + mat.transpose(-2, -1)) * 0.5
+
     def _memo_energy(self, dm, k):
         c = getattr(self, "_energy_memo", None)
         if c is not None and isinstance(dm, torch.Tensor) and c[0] is dm and c[1] == dm._version and k < len(c):

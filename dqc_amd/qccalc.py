@@ -82,21 +82,10 @@ class _Engine:
                 J, kx = h.get_elrep_exchange_pol(dm)
                 core = self.knvext.fullmatrix() + J
                 return torch.stack([core + kx.u, core + kx.d])
-            if (self.is_ks and dm.u.is_cuda and h.df is None and not getattr(h, "_direct", False) and not getattr(h, "sharded", False)
-                    and os.environ.get("DQC_AMD_J_OVERLAP", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
-                # the Coulomb matrix (a stream over the tile store: HBM-bound) on a second stream BESIDE the two-spin grid pass (its
-                # Vxc products are bound by the matrix cores) instead of in front of it
-                main = torch.cuda.current_stream(dm.u.device)
-                side = getattr(self, "_j_stream", None)
-                if side is None:
-                    side = self._j_stream = torch.cuda.Stream(device=dm.u.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    core = (self.knvext + h.get_elrep(dm.u + dm.d)).fullmatrix()
-                v = h.get_vxc(dm)
-                main.wait_stream(side)
-                core.record_stream(main)  # (allocated on the side stream, read and later freed on this one)
-                return torch.stack([core + v.u.fullmatrix(), core + v.d.fullmatrix()])
+            if (self.is_ks and dm.u.dim() == 2 and h.df is None and hasattr(h, "get_elrep_plus_vxc_pol") and not getattr(h, "_direct", False)
+                    and not getattr(h, "sharded", False) and getattr(h, "_tile_slice", None) is None):
+                # J + Vxc_s with one batched AO -> orthogonal conversion, the Coulomb stream beside the grid pass (hamilton.py)
+                return self.knvext.fullmatrix() + h.get_elrep_plus_vxc_pol(dm)
             core = self.knvext + h.get_elrep(dm.u + dm.d)
             v = h.get_vxc(dm) if self.is_ks else h.get_exchange(dm)
             return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])
