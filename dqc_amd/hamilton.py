@@ -789,22 +789,26 @@ class HamiltonMI355(_Base):
         assert self.xc is not None and dm.u.dim() == 2 and self._df is None and not self._direct and self._tile_slice is None
         n = self._nao_ao
         fu, fd = self._factor_of(dm.u), self._factor_of(dm.d)
-        if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
-            dao = (fu[0][0] @ fu[0][1] + fd[0][0] @ fd[0][1])[:n, :n].contiguous()
-        else:
-            dao = self._unconvert_dm(dm.u + dm.d)
+
+        def coulomb():  # (the AO-basis total density and its Coulomb matrix: nothing the grid pass waits for)
+            if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
+                dao = (fu[0][0] @ fu[0][1] + fd[0][0] @ fd[0][1])[:n, :n].contiguous()
+            else:
+                dao = self._unconvert_dm(dm.u + dm.d)
+            return self._jk_ao(dao, False)[0]
+
         side = None
-        if dao.is_cuda and os.environ.get("DQC_AMD_J_OVERLAP", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        if dm.u.is_cuda and os.environ.get("DQC_AMD_J_OVERLAP", "1") != "0" and not torch.cuda.is_current_stream_capturing():
             side = getattr(self, "_j_stream", None)
             if side is None:
-                side = self._j_stream = torch.cuda.Stream(device=dao.device)
+                side = self._j_stream = torch.cuda.Stream(device=dm.u.device)
         if side is not None:
-            main = torch.cuda.current_stream(dao.device)
+            main = torch.cuda.current_stream(dm.u.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                jao, _ = self._jk_ao(dao, False)
+                jao = coulomb()
         else:
-            jao, _ = self._jk_ao(dao, False)
+            jao = coulomb()
         potinfo = self.xc.get_vxc(self._dm2densinfo_pol(dm))
         vu = self._vxc_ao_from_potinfo(potinfo.u)[:n, :n]
         vd = self._vxc_ao_from_potinfo(potinfo.d)[:n, :n]
