@@ -935,7 +935,8 @@ int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part,
     if (with_k && !(jimpl && jimpl[0] == 's')) {
         // contiguous tile ranges of >= 8 tiles, 1024 ... 6144 blocks (4 resident per CU; sweep 1024 ... 8192 on benzene, 20-atom
         // cc-pVDZ and naphthalene / cc-pVTZ: flat within 3 % inside this window)
-        const long long nblk = std::min<long long>(nrun, std::max<long long>(1024, std::min<long long>(6144, nrun / 8)));
+        static const long long jk_nblk_env = [] { const char *e = getenv("DQC_JK_NBLK"); return e ? atoll(e) : 0LL; }();
+        const long long nblk = jk_nblk_env > 0 ? std::min<long long>(nrun, jk_nblk_env) : std::min<long long>(nrun, std::max<long long>(1024, std::min<long long>(6144, nrun / 8)));
         const long long per = (nrun + nblk - 1) / nblk;
         hipLaunchKernelGGL(jk_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg, nao);
     } else if (with_k) {
@@ -945,7 +946,12 @@ int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part,
     } else {
         // contiguous tile ranges, ~6 resident blocks per CU x 2 rounds.  (Tried: 8 x 4 tile rectangles with the column sums in
         // LDS, 24 atomics per tile and no barrier -- 0.396 ms against 0.37 ms for this form: shorter contiguous runs.)
-        const long long nblk = std::min<long long>(nrun, 256 * 12);
+        static const long long j_nblk_env = [] { const char *e = getenv("DQC_J_NBLK"); return e ? atoll(e) : 0LL; }();
+        // Ranges of >= 4 tiles, at most 65536 blocks (DQC_J_NBLK overrides the cap).  Sweep of the cap, same box
+        // (profiles/r05s_j_nblk_sweep.txt): 3072 blocks (rounds 2-4) benzene 0.0366 ms, C5 0.368, naphthalene / cc-pVTZ 5.57;
+        // 16384: 0.0364 / 0.341 / 5.27; 65536: 0.0363 / 0.341 / 5.20 -- shorter ranges even out the tail of the launch; ranges
+        // of 2 tiles (benzene with 4096 blocks) lose it again to the per-range prologue and flush: 0.043 ms.
+        const long long nblk = std::max<long long>(1, std::min<long long>((nrun + 3) / 4, j_nblk_env > 0 ? j_nblk_env : 65536));
         const long long per = (nrun + nblk - 1) / nblk;
         hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg, nao);
     }
