@@ -16,6 +16,7 @@ With --gpus N > 1 from a bare shell the script launches its own N ranks (torch.d
 started under a launcher (WORLD_SIZE set) it is one of the ranks.  ONE JSON line on rank 0 either way.
 """
 import argparse
+import contextlib
 import glob
 import hashlib
 import json
@@ -47,6 +48,10 @@ def source_sha16():
             "bench_py_sha16": hashlib.sha256(open(os.path.abspath(__file__), "rb").read()).hexdigest()[:16]}
 
 
+DEFAULT_J_CUS = 0  # compute units per XCD for a Coulomb-stream partition: OFF -- measured no better than ordinary streams
+                   # (profiles/r06a_cu_partition_curves.txt, r06b_vxc_cus_streams_partition_sweep.txt: 714 against 726-738 it/s)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +63,11 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the batch's Fock builds are dealt to (molecule k -> stream k %% S): independent molecules, so "
                          "the tail of one molecule's kernels overlaps the head of the next one's (SURVEY 8e: each rank, own streams)")
+    ap.add_argument("--j-cus", type=int, default=-1,
+                    help="compute units PER XCD given to the Coulomb tile stream (dqc_amd.batch.CuPartition): the grid pass of every "
+                         "build runs on the other 32 - k of each XCD, the HBM-bound tile stream of the same molecule beside it; 0: no "
+                         "partition (--streams ordinary streams, the rounds 2-5 form); -1: DQC_AMD_J_CUS or the shipped default")
+    ap.add_argument("--grid-streams", type=int, default=2, help="with --j-cus > 0: streams (all on the grid partition) the builds are dealt to")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-molecule-leg", action="store_true",
                     help="N > 1: skip the leg that spreads ONE C4 molecule over the ranks (HamiltonMI355.shard_over)")
@@ -202,8 +212,20 @@ def main():
     h0 = engines[0].hamilton
     nao, ngrid, ld = h0._nao_ao, h0.rgrid.shape[0], h0._ld
 
-    nstreams = max(1, min(args.streams, len(engines)))
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(dev)]
+    from dqc_amd.batch import CuPartition
+    j_cus = args.j_cus if args.j_cus >= 0 else int(os.environ.get("DQC_AMD_J_CUS", str(DEFAULT_J_CUS)))
+    if args.df or args.dense_dm:
+        j_cus = 0 if args.df else j_cus
+    partition = None
+    if j_cus > 0:
+        # round 6: the chip split in two -- grid pass (matrix-core-bound) on 32 - k CUs of every XCD, the Coulomb tile stream
+        # (HBM-bound) of the same molecule on the other k; builds dealt to --grid-streams streams of the grid partition
+        partition = CuPartition(dev, j_cus, max(1, args.grid_streams))
+        streams = partition.grid_streams
+        nstreams = len(streams)
+    else:
+        nstreams = max(1, min(args.streams, len(engines)))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else [torch.cuda.current_stream(dev)]
     torch.cuda.synchronize()
 
     def step(record=None, dense_dm=False, sel=None):
@@ -214,7 +236,7 @@ def main():
             # Default: D = ao_orb2dm(C_occ, n) exactly as scp2dm produces it in every SCF iteration (hf.py:105-113), so
             # the Hamiltonian knows its rank-n_occ factor; --dense-dm hands over an anonymous full matrix instead.
             if record is None:
-                with torch.cuda.stream(streams[k % nstreams]):  # independent molecules: dealt round-robin to the streams
+                with torch.cuda.stream(streams[k % nstreams]) if (nstreams > 1 or partition is not None) else contextlib.nullcontext():  # independent molecules: dealt round-robin to the streams
                     d = dm.clone() if dense_dm else eng.hamilton.ao_orb2dm(orb, eng.orb_weight)
                     eng.dm2scp(d)
             else:  # per-kernel events: one molecule at a time on the current stream

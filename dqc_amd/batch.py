@@ -47,6 +47,59 @@ def reserve_device_memory(nbytes: int, device) -> float:
     return time.perf_counter() - t0
 
 
+class CuPartition:
+    """The chip split in two for a batch of restricted Kohn-Sham builds (round 6): `grid_streams` -- HIP streams confined to the
+    first 32 - k compute units of every XCD, on which the caller runs its Fock builds (density, functional and Vxc kernels: bound
+    by the matrix cores, every VGPR of their CUs taken) -- and ONE Coulomb stream on the other k CUs per XCD, to which
+    `HamiltonMI355.get_elrep_plus_vxc` sends the pass over the ERI tiles (HBM-bound, no matrix-core work) of every build that runs
+    on one of the grid streams.  The tile stream of molecule m then rides in the HBM bandwidth the grid pass of molecule m leaves;
+    with two or more grid streams the next molecule's Coulomb pass starts while this one's build still waits for its own.
+    k = 0 or DQC_AMD_J_CUS=0: no partition (`grid_streams` are ordinary streams, Coulomb pass in line).  k must be a multiple of 4:
+    a mask bit is (CU slot, XCD) with the slots dealt to the four shader engines of an XCD in turn, and the workgroup dispatcher
+    feeds the engines round-robin -- a partition with unequal engines runs at the pace of its smallest (30 CUs per XCD: Vxc 2 x
+    slower than on 28).  MEASURED (profiles/r06a_cu_partition_curves.txt, r06b_*): the Coulomb stream is bound per CU (36 GB/s each:
+    64 CUs for 2.2 TB/s), the Vxc kernel by the chip's power (192 CUs: 0.64 ms against 0.56 on 256), and the batch's throughput is
+    the same 715-739 it/s for every split, stream count and Vxc CU cap -- opt-in, not what bench.py runs.
+        part = CuPartition(dev); ...; with torch.cuda.stream(part.grid_streams[i % len(part.grid_streams)]): eng.dm2scp(dm)"""
+
+    def __init__(self, device, j_cus_per_xcd=None, n_grid_streams=2):
+        import os
+        from . import lib
+        from .hamilton import register_coulomb_side_stream
+        dev = torch.device(device)
+        self.device = dev
+        if j_cus_per_xcd is None:
+            j_cus_per_xcd = int(os.environ.get("DQC_AMD_J_CUS", "8"))
+        ncu = lib.device_cu_count(dev)
+        per = ncu // 8 if (ncu >= 64 and ncu % 8 == 0) else ncu
+        k = max(0, min(int(j_cus_per_xcd), per - 1))
+        self.j_cus_per_xcd, self.cus_per_xcd = k, per
+        self._parts = []
+        if k == 0:
+            self.coulomb = None
+            self.grid_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, n_grid_streams))]
+            return
+        pj = lib.partition_stream(dev, per - k, per)
+        self._parts.append(pj)
+        self.coulomb = pj.stream
+        self.grid_streams = []
+        for _ in range(max(1, n_grid_streams)):
+            pg = lib.partition_stream(dev, 0, per - k)
+            self._parts.append(pg)
+            self.grid_streams.append(pg.stream)
+            register_coulomb_side_stream(pg.stream, pj.stream)
+
+    def close(self):
+        from .hamilton import register_coulomb_side_stream
+        torch.cuda.synchronize(self.device)
+        if self.coulomb is not None:
+            for g in self.grid_streams:
+                register_coulomb_side_stream(g, None)
+        for p in self._parts:
+            p.close()
+        self._parts = []
+
+
 def prepare_orthogonalisers(hams) -> int:
     """The orthogonalisers X (X^T S X = 1: eigh(S), eigenvalues below 1e-6 dropped, dqc/hamilton/orbconverter.py:67-116) of a
     batch of Hamiltonians from ONE batched eigh per matrix size instead of one rocSOLVER call per molecule: 6.5 ms for 32

@@ -68,6 +68,7 @@ inline long long eri_store_data_doubles(int nao) {
 void set_error(const std::string &msg);
 bool deterministic_mode();  // dqc_set_deterministic (host.hip)
 bool generic_eri_forced();  // dqc_set_generic_eri (host.hip)
+int stream_cus(hipStream_t st);  // CUs the stream's kernels may run on (dqc_stream_create_partition; else the device's) (host.hip)
 
 #define DQC_HIP(call)                                                                      \
     do {                                                                                   \

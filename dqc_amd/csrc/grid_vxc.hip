@@ -18,6 +18,8 @@
 
 namespace dqc {
 
+int vxc_cus_cap();  // host.hip: dqc_set_vxc_cus / DQC_VXC_CUS
+
 // fixed-point scale of the split-K accumulation into V in deterministic mode (0: fp64 atomics); common.hpp: acc_add
 __device__ double g_vxc_det_scale = 0.0;
 
@@ -1159,7 +1161,8 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         // 145 <= nao <= 208 (10 <= T <= 13): one block per slab over the upper-triangular tiles (vxc_wsu_kernel) instead of two
         // blocks that each stage the whole slab.  One operand, symmetric result; DQC_VXC_IMPL=split keeps the two-block form.
         if (ws_shape && T >= 10 && T * (T + 1) / 2 <= 12 * VXC_WAVES && d_aob == d_ao && !(impl_env && impl_env[0] == 's')) {
-            int ncu = 256;
+            int ncu = stream_cus(st);  // one block per CU of the stream's partition (all 256 on an ordinary stream)
+            if (vxc_cus_cap() > 0) ncu = std::max(8, std::min(ncu, vxc_cus_cap()));  // (leave CUs to other streams' kernels: host.hip)
             int nslab = ncu;
             int slab = (ngrid + nslab - 1) / nslab;
             slab = (slab + 15) / 16 * 16;
@@ -1200,7 +1203,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
         const int nl = nlneed <= 1 ? 1 : (nlneed <= 2 ? 2 : (nlneed <= 4 ? 4 : 8));
         if (nlneed > 8) { set_error("dqc_grid_vxc: nao above 1008 is not supported by this build"); return DQC_EINVAL; }
         // one 8-wave block per CU; slabs in multiples of 8 so that the XCD-aware decode is exact
-        int nslab = std::max(8, (256 / nsplit) / 8 * 8);
+        int nslab = std::max(8, (stream_cus(st) / nsplit) / 8 * 8);
         int slab = (ngrid + nslab - 1) / nslab;
         slab = (slab + kch - 1) / kch * kch;
         nslab = ((ngrid + slab - 1) / slab + 7) / 8 * 8;

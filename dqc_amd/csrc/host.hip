@@ -1,4 +1,5 @@
 // host.hip -- error handling, table parsing and small utilities of libdqc_amd.so
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -52,6 +53,46 @@ bool generic_eri_forced() {
         v = g_generic_eri.load(std::memory_order_relaxed);
     }
     return v == 1;
+}
+
+// ---- compute-unit partitions (round 6): streams created with a CU mask and the CU count the grid kernels size their launches for ----
+// One block per CU is how vxc_ws* / vxc_wsd fill the chip; on a stream that owns only part of the CUs (the Coulomb stream of another
+// molecule runs on the rest, dqc_stream_create_partition) the slab count follows the partition.  Registry: stream -> CUs.
+static std::mutex g_cu_mu;
+static std::vector<std::pair<hipStream_t, int>> g_stream_cus;
+static int device_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+// Cap on the CUs the one-block-per-CU Vxc kernels occupy (0: none).  Those blocks hold every VGPR of their CU for the whole launch, so
+// while a Vxc kernel runs nothing else is resident anywhere; with a cap of e.g. 208 the launch leaves 48 CUs to the kernels other
+// streams have queued (the HBM-bound Coulomb / density passes of other molecules of a batch).  dqc_set_vxc_cus / DQC_VXC_CUS.
+static std::atomic<int> g_vxc_cus{-1};
+int vxc_cus_cap() {
+    int v = g_vxc_cus.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = std::getenv("DQC_VXC_CUS");
+        v = e ? std::max(0, atoi(e)) : 0;
+        int expect = -1;
+        g_vxc_cus.compare_exchange_strong(expect, v);
+        v = g_vxc_cus.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+int stream_cus(hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        for (auto &e : g_stream_cus)
+            if (e.first == st) return e.second;
+    }
+    return device_cus();
 }
 
 // ---- pinned staging blocks of the stream-ordered DevPool ----
@@ -199,6 +240,57 @@ int dqc_set_deterministic(int on) {
     return dqc::g_deterministic.exchange(on != 0) ? 1 : 0;
 }
 int dqc_get_deterministic(void) { return dqc::deterministic_mode() ? 1 : 0; }
+
+int dqc_device_cu_count(void) { return dqc::device_cus(); }
+
+int dqc_stream_create_partition(void **stream_out, int cu_begin, int cu_end, int priority) {
+    // A stream whose kernels run on the compute units [cu_begin, cu_end) of EVERY XCD only (hipExtStreamCreateWithCUMask; the
+    // mask's bit i is CU i / nxcd of XCD i % nxcd on the multi-die parts, so a contiguous per-XCD range is a strided bit set).
+    // The grid kernels size their launches for the partition (stream_cus).  priority: 0 normal, < 0 higher.
+    using namespace dqc;
+    if (!stream_out) { set_error("dqc_stream_create_partition: null output"); return DQC_EINVAL; }
+    const int ncu = device_cus();
+    const int nxcd = ncu >= 64 && ncu % 8 == 0 ? 8 : 1, per = ncu / nxcd;
+    if (cu_begin < 0 || cu_end > per || cu_begin >= cu_end) { set_error("dqc_stream_create_partition: CU range outside [0, CUs per XCD]"); return DQC_EINVAL; }
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int c = cu_begin; c < cu_end; c++)
+        for (int x = 0; x < nxcd; x++) {
+            const int bit = c * nxcd + x;
+            mask[bit >> 5] |= 1u << (bit & 31);
+        }
+    hipStream_t st = nullptr;
+    (void)priority;  // (hipExtStreamCreateWithCUMask has no priority argument; kept in the ABI for a later driver)
+    DQC_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    {
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        g_stream_cus.emplace_back(st, (cu_end - cu_begin) * nxcd);
+    }
+    *stream_out = (void *)st;
+    return DQC_OK;
+}
+
+int dqc_stream_destroy(void *stream) {
+    using namespace dqc;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        std::lock_guard<std::mutex> lk(g_cu_mu);
+        for (size_t i = 0; i < g_stream_cus.size(); i++)
+            if (g_stream_cus[i].first == st) { g_stream_cus.erase(g_stream_cus.begin() + i); break; }
+    }
+    DQC_HIP(hipStreamDestroy(st));
+    return DQC_OK;
+}
+
+int dqc_stream_cus(void *stream) { return dqc::stream_cus((hipStream_t)stream); }
+
+int dqc_set_vxc_cus(int ncu) {
+    // process-wide; returns the previous setting (0: no cap)
+    const int prev = dqc::vxc_cus_cap();
+    dqc::g_vxc_cus.store(ncu > 0 ? ncu : 0);
+    return prev;
+}
+
+
 
 int dqc_set_generic_eri(int on) {
     // process-wide: every shell-quartet class through the runtime-angular-momentum kernel (eri_generic.hpp) instead of only the

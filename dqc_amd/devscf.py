@@ -200,10 +200,18 @@ class DeviceLoop:
             qc.niter, qc.scf_error = j + 1, emax
             if trace:
                 print("scf it %2d  max|[F,D]| %.2e  (device loop)" % (j, emax), flush=True)
-            if not pe < 1e-9 or not emax == emax or emax == float("inf"):  # (a non-finite error: the host-driven loop sorts it out)
+            if not emax == emax or emax == float("inf"):  # a non-finite error: the host-driven loop starts over with eigh steps
+                return "restart"
+            if getattr(self, "_test_fail_at", None) == j:  # (test hook: a projector failure at iteration j)
+                return "fallback"
+            if not pe < 1e-9:  # the projector of this step failed (vanishing gap): the host-driven loop resumes from the last good density
                 return "fallback"
             if emax < best_err * 0.9:
                 best_err, best_it = emax, j
+            if j - best_it >= 40 and emax > 1e-6:
+                # the wander guard of the host-driven loop (qccalc.py): inside a degenerate Fermi level the purification step has no
+                # preferred basis and the iteration never settles (UKS SCAN, oxygen triplet) -- hand over, eigh steps from the core guess
+                return "restart"
             if emax < f_tol:
                 qc.converged = True
                 return "done"
@@ -225,10 +233,20 @@ class DeviceLoop:
         if verdict is None:
             verdict = look(maxiter - 1)
             done_at = maxiter - 1
+            if verdict is None and qc.scf_error > 1e-6:
+                # out of iterations far from a fixed point: the reference's diagonalise-and-occupy step (hf.py:105-113) gets its turn
+                # before the run is reported as not converged (the degenerate-level wander needs 40 steps to be told from slow progress)
+                verdict = "restart"
         torch.cuda.synchronize(dev)
+        if verdict == "restart":
+            # wandering or non-finite: nothing of this run is worth resuming from (a non-finite commutator means the entering pair of
+            # iteration `done_at` is already non-finite) -- the host-driven loop starts at the core guess WITHOUT the purification step
+            qc._resume_dm = None
+            qc._skip_purification = True
+            return False
         if verdict == "fallback":
-            # the entering density of the failing iteration is the last good iterate (every earlier step passed its projector
-            # check): the host-driven loop resumes from it instead of the core guess
+            # a projector failure with a finite error: the entering density of the failing iteration is the last good iterate (every
+            # earlier step passed its projector check) -- the host-driven loop resumes from it instead of the core guess
             p = done_at % 2
             if done_at >= 1:
                 qc._resume_dm = SpinParam(u=self.ring_d[p, 0].clone(), d=self.ring_d[p, 1].clone()) if self.pol else self.ring_d[p, 0].clone()

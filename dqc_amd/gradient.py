@@ -152,12 +152,21 @@ def _xc_gradient(eng, d_aos):
     natm = len(mol.atomzs)
     ao_atom = _ao_owner(h, dev)
     g = torch.zeros((natm, 3), dtype=torch.float64, device=dev)
+    live = getattr(h, "live_index", None)  # the Hamiltonian keeps the points of non-zero weight only (setup_grid)
+
+    def full(x):  # per-point rows on the live points -> rows on the caller's grid (zero elsewhere: zero weight, zero derivative)
+        if live is None:
+            return x
+        o = torch.zeros((h.ngrid_full,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        o[live] = x
+        return o
+
     for info, b, c, pt in zip(infos, bs, cs_, pots):
         vrho, u, vtau = pt.value, pt.grad, pt.kin
         if gga and ao.shape[0] == 10 and nao <= 512:
             # one fused pass over the ten derivative arrays (dqc_grid_xc_gradient_terms) instead of ~40 element-wise passes
             q, per_ao = lib.grid_xc_gradient_terms(ao, nao, b, c, w, vrho, u, info.grad, vtau if fam == 4 else None)
-            g += _sum_by_owner(mol, q)             # (ii)
+            g += _sum_by_owner(mol, full(q))       # (ii)
             g.index_add_(0, ao_atom, -2.0 * per_ao)  # (iii)
             continue
         q = torch.empty((h.rgrid.shape[0], 3), dtype=torch.float64, device=dev)
@@ -177,12 +186,12 @@ def _xc_gradient(eng, d_aos):
             else:
                 q[:, j] = w * vrho * _grad_rho(ao, b, j)
                 per_ao[:, j] = (ao[1 + j] * t1 * w.unsqueeze(-1)).sum(0)[:nao]
-        g += _sum_by_owner(mol, q)             # (ii)
+        g += _sum_by_owner(mol, full(q))       # (ii)
         g.index_add_(0, ao_atom, -2.0 * per_ao)  # (iii)
     # (i) Becke-weight derivative, energy density held fixed
     pos = mol.atompos.to(dtype=torch.float64, device=dev).clone().requires_grad_(True)
     grid = get_predefined_grid(mol._grid_inp, mol.atomzs.tolist(), pos, dtype=torch.float64, device=dev)
-    loss = (grid.get_dvolume() * edens.detach()).sum()
+    loss = (grid.get_dvolume() * full(edens.detach())).sum()
     return g + torch.autograd.grad(loss, pos)[0]
 
 

@@ -26,6 +26,22 @@ from .linop import LinearOperator
 from .utils.datastruct import AtomCGTOBasis, SpinParam, ValGrad
 from .xc import LibXC
 
+# Coulomb side streams (round 6, dqc_amd.batch.CuPartition): a Fock build that runs on a registered "grid" stream sends its
+# Coulomb pass over the ERI tiles to the stream registered beside it -- a HIP stream confined to OTHER compute units
+# (dqc_stream_create_partition), so that the HBM-bound tile stream of this molecule runs beside the matrix-core-bound grid pass
+# instead of before it.  Key: (device index, stream handle).
+_COULOMB_SIDE = {}
+
+
+def register_coulomb_side_stream(grid_stream, side_stream):
+    """builds whose CURRENT stream is `grid_stream` run their Coulomb tile pass on `side_stream` (None: forget the pair)"""
+    key = (grid_stream.device.index, grid_stream.cuda_stream)
+    if side_stream is None:
+        _COULOMB_SIDE.pop(key, None)
+    else:
+        _COULOMB_SIDE[key] = side_stream
+
+
 
 try:  # inside a DQC installation the class IS a BaseHamilton (isinstance checks of dqc.qccalc / dqc.system pass)
     from dqc.hamilton.base_hamilton import BaseHamilton as _Base
@@ -250,6 +266,27 @@ class HamiltonMI355(_Base):
         assert grid.coord_type == "cart"
         self.rgrid = grid.get_rgrid().to(self.device)
         self.dvolume = grid.get_dvolume().to(self.device).contiguous()
+        # Points of weight EXACTLY zero are dropped from the resident arrays (round 6).  The reference's Becke partition zeroes the
+        # weight of every point that fails its `mu < 0.74` cut (multiatoms_grid.py:233-262: p[ia] stays 0) -- 3.0 % of the sg3 grid
+        # of a 20-atom molecule -- and such a point adds exactly nothing to any quadrature this class forms (E_xc, Vxc, vext, the
+        # electron count): same sums, fewer AO rows to evaluate, store and stream in every grid pass.  `rgrid`, `dvolume`, `basis`,
+        # `grad_basis` and the per-point arrays of `_dm2densinfo` then hold the LIVE points only; `ngrid_full` and `live_index`
+        # (None: nothing dropped) relate them to the caller's grid, and get_vext indexes its argument.  DQC_AMD_PRUNE_GRID=0 keeps all.
+        self.ngrid_full = int(self.rgrid.shape[0])
+        self.live_index = None
+        if os.environ.get("DQC_AMD_PRUNE_GRID", "1") != "0" and self.ngrid_full > 0:
+            cached = getattr(grid, "_live_index_cache", None)
+            if cached is None or cached[0].device != self.dvolume.device:
+                idx = torch.nonzero(self.dvolume != 0).squeeze(1)
+                cached = (idx, int(idx.shape[0]))  # (one device -> host read per grid object)
+                try:
+                    grid._live_index_cache = cached
+                except AttributeError:
+                    pass
+            if cached[1] < self.ngrid_full:
+                self.live_index = cached[0]
+                self.rgrid = self.rgrid[self.live_index].contiguous()
+                self.dvolume = self.dvolume[self.live_index].contiguous()
         if self._pworld > 1:  # this rank's contiguous slab of the points (equal work per point: equal slabs)
             g = self.rgrid.shape[0]
             lo, hi = g * self._prank // self._pworld, g * (self._prank + 1) // self._pworld
@@ -520,6 +557,8 @@ class HamiltonMI355(_Base):
             raise RuntimeError("Please call `setup_grid(grid, xc)` to call this function")
         ao = self._ao if self._ao.dim() == 2 else self._ao[0]
         zero = None
+        if vext.shape[-1] == self.ngrid_full and self._pworld == 1 and self.live_index is not None:
+            vext = vext.to(self.device)[..., self.live_index]  # (the caller's array lives on the caller's grid)
         mat = self._batched1(lambda v: lib.grid_vxc(ao, self._nao_ao, self.dvolume, v.contiguous(), zero), vext)
         mat = self._convert2(mat[..., :self._nao_ao, :self._nao_ao])
         mat = (mat + mat.transpose(-2, -1)) * 0.5
@@ -754,8 +793,18 @@ class HamiltonMI355(_Base):
             dao = self._unconvert_dm(dm)
         if self._tile_slice is not None:  # tile store spread over the ranks: J, Vxc and E_xc parts travel in one all_reduce
             self._deferred = []
+        side = main = None
+        if _COULOMB_SIDE and dm.is_cuda and self._df is None and not self._direct and self._tile_slice is None \
+                and not torch.cuda.is_current_stream_capturing():
+            main = torch.cuda.current_stream(dm.device)
+            side = _COULOMB_SIDE.get((dm.device.index, main.cuda_stream))
         try:
-            if self._df is not None:
+            if side is not None:  # the tile stream on its own compute units, beside this molecule's grid pass
+                side.wait_stream(main)
+                dao.record_stream(side)
+                with torch.cuda.stream(side):
+                    jao, _ = self._jk_ao(dao, False)
+            elif self._df is not None:
                 jao = self._df.coulomb_ao(dao)
             else:
                 jao, _ = self._jk_ao(dao, False)
@@ -768,6 +817,9 @@ class HamiltonMI355(_Base):
             else:
                 potinfo, exc = self.xc.get_vxc(densinfo), None
             vm = self._vxc_ao_from_potinfo(potinfo)
+            if side is not None:
+                main.wait_stream(side)
+                jao.record_stream(main)  # (allocated on the side stream, read and later freed on this one)
             if self._deferred is not None:
                 self._allsum_flush()
         finally:

@@ -107,6 +107,10 @@ def load():
     lib.dqc_xc_eval_mgga.argtypes = [c_dp] * 7 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga_pol.argtypes = [c_dp] * 11 + [c_int, ip, dp, c_int, c_vp]
     lib.dqc_xc_eval_mgga_pol2.argtypes = [c_dp] * 12 + [c_int, ip, dp, c_int, c_vp]
+    lib.dqc_stream_create_partition.argtypes = [ctypes.POINTER(c_vp), c_int, c_int, c_int]
+    lib.dqc_stream_destroy.argtypes = [c_vp]
+    lib.dqc_stream_cus.argtypes = [c_vp]
+    lib.dqc_set_vxc_cus.argtypes = [c_int]
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
@@ -866,6 +870,53 @@ def grid_vxc(ao, nao, w, vrho, vgrad):
         _check(load().dqc_grid_vxc(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), st_),
                "dqc_grid_vxc" if vgrad is not None else "dqc_grid_vxc[no gradient term]")
     return vm
+
+
+class PartitionStream:
+    """a HIP stream whose kernels run on compute units [cu_begin, cu_end) of every XCD only (dqc_stream_create_partition), wrapped
+    as a torch stream (`.stream`) so that `with torch.cuda.stream(p.stream)` sends library calls and torch ops to it"""
+
+    def __init__(self, device, cu_begin, cu_end):
+        dev = torch.device(device)
+        dev = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.device = dev
+        self.cu_begin, self.cu_end = int(cu_begin), int(cu_end)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _check(load().dqc_stream_create_partition(ctypes.byref(h), self.cu_begin, self.cu_end, 0), "dqc_stream_create_partition")
+            self.cus = int(load().dqc_stream_cus(h))
+        self._handle = h
+        self.stream = torch.cuda.ExternalStream(h.value, device=dev)
+
+    def close(self):
+        """hand the stream back to the process-wide pool (partition_stream): PyTorch's caching allocator keeps events and block
+        records that name a stream for as long as the process lives, so a stream it has seen is never destroyed"""
+        if self._handle is not None:
+            self.stream.synchronize()
+            _PART_POOL.setdefault((self.device.index, self.cu_begin, self.cu_end), []).append(self)
+
+
+_PART_POOL = {}
+
+
+def partition_stream(device, cu_begin, cu_end):
+    """a PartitionStream from the pool of closed ones, or a new one"""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    free = _PART_POOL.get((idx, int(cu_begin), int(cu_end)))
+    if free:
+        return free.pop()
+    return PartitionStream(torch.device("cuda", idx), cu_begin, cu_end)
+
+
+def set_vxc_cus(ncu):
+    """cap on the CUs the one-block-per-CU Vxc kernels occupy (0: none); returns the previous setting"""
+    return int(load().dqc_set_vxc_cus(int(ncu)))
+
+
+def device_cu_count(device=None):
+    with torch.cuda.device(device):
+        return int(load().dqc_device_cu_count())
 
 
 def probe_stream_read(buf):

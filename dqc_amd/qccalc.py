@@ -219,11 +219,15 @@ class SCF_QCCalc:
         # 6 ms of rocSOLVER launches per iteration against ~1 ms of GEMMs
         ham = getattr(eng, "hamilton", None)
         direct = bool(getattr(ham, "_direct", False))
+        skip_purify = bool(getattr(self, "_skip_purification", False))  # (the device loop wandered: eigh steps from the start)
+        self._skip_purification = False
+        if skip_purify:
+            self.purification_dropped = True
         if opts.get("graph", os.environ.get("DQC_AMD_GRAPH", "1") != "0") and not getattr(ham, "sharded", False):
             from .graph import GraphedFock, GraphedSCFStep
             ws = [eng.orb_weight.u, eng.orb_weight.d] if pol else [eng.orb_weight]
             uniform = all((not w.numel()) or bool((w == w[0]).all()) for w in ws)
-            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and getattr(eng, "ovlp", None) is None:
+            if opts.get("diag", os.environ.get("DQC_AMD_DIAG", "purify")) == "purify" and uniform and getattr(eng, "ovlp", None) is None and not skip_purify:
                 purified = GraphedSCFStep(eng, capture=not direct)
             elif not pol and not direct:
                 graphed = GraphedFock(eng)

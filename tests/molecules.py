@@ -8,6 +8,9 @@ CH4 = ([6, 1, 1, 1, 1], [[0, 0, 0], [1.186, 1.186, 1.186], [-1.186, -1.186, 1.18
                          [1.186, -1.186, -1.186]])
 
 # vitamin C, 20 atoms, exactly the reference's 20-atom cc-pVDZ benchmark input (dqc/test/benchmark.py:7-26)
+# nitroxyl HNO (N-O 1.212 A, N-H 1.063 A, 108.6 deg; Bohr): the smallest molecule with N, O and their cc-pVTZ f shells
+HNO = ([7, 8, 1], [[0, 0, 0], [2.2903, 0, 0], [-0.6408, 1.9040, 0]])
+FORMAMIDE = ([6, 8, 7, 1, 1, 1], [[0, 0, 0], [2.2960, 0, 0], [-1.2420, 2.2490, 0], [-0.9950, -1.8230, 0], [-3.1150, 2.0880, 0], [-0.3560, 3.9420, 0]])
 VITC = ([8] * 6 + [6] * 6 + [1] * 8,
         [[0.1761, -2.0912, 1.2179], [-2.5390, 0.1686, -2.6197], [1.5859, 4.5166, 0.5374], [-7.3565, -0.3855, -0.6285],
          [5.7108, 1.0762, -1.1444], [3.7634, -4.0742, -0.2600], [-0.6419, 0.4947, 1.4840], [-3.0347, 0.8664, -0.0624],

@@ -96,7 +96,8 @@ def test_cgto_normalisation_and_tables_match_reference_layout():
 
 
 @pytest.mark.parametrize("basis,zs,nao,nsh", [("cc-pvdz", M.benzene()[0], 114, 54), ("cc-pvdz", M.VITC[0], 208, 96),
-                                              ("cc-pvtz", M.naphthalene()[0], 412, 148), ("sto-3g", M.H2O[0], 7, 5)])
+                                              ("cc-pvtz", M.naphthalene()[0], 412, 148), ("sto-3g", M.H2O[0], 7, 5),
+                                              ("cc-pvtz", M.FORMAMIDE[0], 132, 48), ("cc-pvtz", M.HNO[0], 74, 26)])
 def test_basis_sizes_match_survey(basis, zs, nao, nsh):
     from dqc_amd.basis import loadbasis
     shells = [s for z in zs for s in loadbasis("%d:%s" % (z, basis))]

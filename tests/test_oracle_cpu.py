@@ -736,3 +736,18 @@ def test_functional_points_published_values(golden_dir):
                 continue
             eps = _uniform_gas_eps_c(name, row["rs"], row["zeta"])
             assert abs(eps - row["value"]) < row["rtol"] * abs(row["value"]), (name, row["rs"], row["zeta"], eps, row["value"])
+
+
+def test_ccpvtz_nitrogen_oxygen_tables_published_energies():
+    """the cc-pVTZ tables of N and O shipped since round 6 (transcribed from Dunning 1989, no network on the build box): restricted
+    Hartree-Fock energies of water (experimental geometry, R = 0.9572 A, 104.52 deg) and N2 (R = 1.0977 A) in the oracle engine
+    against the values tabulated for HF/cc-pVTZ at these geometries (NIST CCCBDB: -76.0571, -108.9835 Ha to the four decimals
+    given); a mistyped exponent or contraction coefficient moves these by 1e-3 Ha and more.  Water / cc-pVDZ (tables shipped since
+    round 1) rides along as the control: -76.0268"""
+    import math
+    from oracle import hamilton as oh
+    R, th = 0.9572 / 0.52917721, 104.52 * math.pi / 180
+    h2o = "O 0 0 0; H %.10f %.10f 0; H %.10f %.10f 0" % (R * math.sin(th / 2), R * math.cos(th / 2), -R * math.sin(th / 2), R * math.cos(th / 2))
+    assert abs(oh.run_scf(h2o, "cc-pvtz")[0] - (-76.0571)) < 2e-4
+    assert abs(oh.run_scf(h2o, "cc-pvdz")[0] - (-76.0268)) < 2e-4
+    assert abs(oh.run_scf("N 0 0 0; N 0 0 %.10f" % (1.0977 / 0.52917721), "cc-pvtz")[0] - (-108.9835)) < 2e-4
