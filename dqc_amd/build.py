@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdqc_amd.so")
-SOURCES = ["host.hip", "int1e.hip", "eri.hip", "df.hip", "grad.hip", "jk.hip", "gto.hip", "becke.hip", "grid_density.hip", "grid_vxc.hip", "grid_xcgrad.hip", "xc.hip", "purify.hip"]
+SOURCES = ["host.hip", "int1e.hip", "eri.hip", "df.hip", "grad.hip", "jk.hip", "fock.hip", "gto.hip", "becke.hip", "grid_density.hip", "grid_vxc.hip", "grid_xcgrad.hip", "xc.hip", "purify.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result", "-Wno-int-to-pointer-cast"]
 
 

@@ -899,8 +899,22 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
     return dqc_jk_from_tiles_part(d_J, d_K, d_tiles, d_dm, nao, d_work, 0, (long long)dqc_eri_tile_count(nao), stream);
 }
 
+static int jk_from_tiles_impl(double *d_J, double *d_K, const double *d_tiles_part, const double *d_dm, int nao, double *d_work,
+                              long long tile_begin, long long tile_end, int with_k_prepared, void *stream);
+
 int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part, const double *d_dm, int nao, double *d_work,
                            long long tile_begin, long long tile_end, void *stream) {
+    return jk_from_tiles_impl(d_J, d_K, d_tiles_part, d_dm, nao, d_work, tile_begin, tile_end, 0, stream);
+}
+
+int dqc_jk_stream_prepared(const double *d_tiles, int nao, double *d_work, int with_k, void *stream) {
+    // the tile pass alone, on a work buffer dqc_fock_prep has filled (AO density, zeroed accumulators); the accumulators stay in the
+    // work buffer for dqc_fock_finish
+    return jk_from_tiles_impl(nullptr, nullptr, d_tiles, nullptr, nao, d_work, 0, (long long)dqc_eri_tile_count(nao), with_k ? 1 : 0, stream);
+}
+
+static int jk_from_tiles_impl(double *d_J, double *d_K, const double *d_tiles_part, const double *d_dm, int nao, double *d_work,
+                              long long tile_begin, long long tile_end, int with_k_prepared, void *stream) {
     using namespace dqc;
     if (nao <= 0) return DQC_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -915,9 +929,13 @@ int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part,
     // the kernels address tiles by their offset in the WHOLE store: a slice is handed over with its virtual origin
     const double *d_tiles = d_tiles_part - dqc_eri_tile_offset(nao, tile_begin);
     const long long ntiles = tile_end, tbeg = tile_begin, nrun = tile_end - tile_begin;
-    const int with_k = d_K != nullptr;
-    hipLaunchKernelGGL(jk_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dm, nao, npad, with_k);
-    DQC_CHECK_LAUNCH();
+    const int with_k = d_dm ? (d_K != nullptr) : with_k_prepared;
+    // d_dm == nullptr: the work buffer was prepared by dqc_fock_prep (symmetric AO density in place, accumulators zeroed);
+    // d_J == nullptr: the accumulators are left for dqc_fock_finish (dqc_jk_stream_prepared)
+    if (d_dm) {
+        hipLaunchKernelGGL(jk_prep_kernel, dim3(64), dim3(256), 0, st, d_work, d_dm, nao, npad, with_k);
+        DQC_CHECK_LAUNCH();
+    }
     double *dscp = nullptr;
     if (deterministic_mode()) {
         dscp = d_work + 3 * (size_t)npad * npad;
@@ -956,8 +974,10 @@ int dqc_jk_from_tiles_part(double *d_J, double *d_K, const double *d_tiles_part,
         hipLaunchKernelGGL(j_stream_kernel, dim3((unsigned)((nrun + per - 1) / per)), dim3(256), 0, st, dscp, d_tiles, d_work, npad, ntiles, per, tbeg, nao);
     }
     DQC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad, dscp);
-    DQC_CHECK_LAUNCH();
+    if (d_J) {
+        hipLaunchKernelGGL(jk_finish_kernel, dim3(64), dim3(256), 0, st, d_J, d_K, d_work, nao, npad, dscp);
+        DQC_CHECK_LAUNCH();
+    }
     return DQC_OK;
 }
 

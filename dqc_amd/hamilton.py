@@ -299,6 +299,18 @@ class HamiltonMI355(_Base):
         self.is_lapl_ao_set = deriv == 2
         self._ao_lapl_pm = None
 
+    def grid_select(self, x):
+        """a per-point array on the caller's grid (last axis ngrid_full) -> the same on the resident (live) points"""
+        return x if self.live_index is None else x[..., self.live_index]
+
+    def grid_scatter(self, x):
+        """a per-point array on the resident points (last axis) -> on the caller's grid, zero at the dropped (zero-weight) points"""
+        if self.live_index is None:
+            return x
+        out = torch.zeros(tuple(x.shape[:-1]) + (self.ngrid_full,), dtype=x.dtype, device=x.device)
+        out[..., self.live_index] = x
+        return out
+
     @property
     def basis(self):
         """(ngrid, nao) AO values, the attribute name of the reference (hcgto.py:168)"""
@@ -464,6 +476,15 @@ class HamiltonMI355(_Base):
             J, K = lib.jk_part(self._tiles, dao, self._jkwork, with_k, self._tile_slice[0], self._tile_slice[1])
             return self._allsum(J), self._allsum(K)
         return lib.jk(self._tiles, dao, self._jkwork, with_k)
+
+    def _fused_fock_ok(self, dm):
+        """the small-matrix ends of this build through the fused kernels of csrc/fock.hip (dqc_fock_prep / dqc_fock_finish)?"""
+        if self._df is not None or self._direct or self._tile_slice is not None or not isinstance(dm, torch.Tensor):
+            return False
+        if dm.dim() != 2 or not dm.is_cuda or dm.dtype != torch.float64 or os.environ.get("DQC_AMD_FUSED_FOCK", "1") == "0":
+            return False
+        x = self._orthozer
+        return self._nao_ao <= lib.fock_max_nao() and x.is_contiguous() and x.shape[0] == self._nao_ao
 
     def _sym_orth(self, m_ao):
         m = self._convert2(m_ao)
@@ -786,6 +807,8 @@ class HamiltonMI355(_Base):
         of one per operator.  Same numbers as get_elrep(dm) + get_vxc(dm) up to round-off."""
         assert self.xc is not None and dm.dim() == 2
         fac = self._factor_of(dm)
+        if self._fused_fock_ok(dm) and not (_COULOMB_SIDE and not torch.cuda.is_current_stream_capturing()):
+            return self._elrep_plus_vxc_fused(dm, fac)
         if fac is not None and len(fac) == 1:  # D_ao = L_ao L_ao^T: one thin GEMM instead of X D X^T
             n = self._nao_ao
             dao = (fac[0][0] @ fac[0][1])[:n, :n].contiguous()
@@ -830,6 +853,29 @@ class HamiltonMI355(_Base):
         self._energy_memo = (dm, dm._version, e_j, None if exc is None else exc[0])
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
         return (mat + mat.transpose(-2, -1)) * 0.5
+
+    def _elrep_plus_vxc_fused(self, dm, fac):
+        """get_elrep_plus_vxc with the small-matrix ends fused (csrc/fock.hip): AO density (from the orbital factor when it is known,
+        else X D X^T) + zeroed accumulators in ONE launch, the tile pass, the grid pass, then J's symmetrisation, tr D J / 2,
+        X^T (J + V_ao) X and its symmetrisation in ONE launch"""
+        n, x, work = self._nao_ao, self._orthozer, self._jkwork
+        tiles = self._tiles
+        if fac is not None and len(fac) == 1 and fac[0][0].is_contiguous():
+            lib.fock_prep(work, x, n, False, orb=fac[0][0])
+        else:
+            lib.fock_prep(work, x, n, False, dm=dm.contiguous())
+        lib.jk_stream_prepared(tiles, n, work, False)
+        densinfo = self._dm2densinfo(dm)
+        if hasattr(self.xc, "get_vxc_and_exc"):
+            potinfo, exc = self.xc.get_vxc_and_exc(densinfo, self.dvolume)
+            if exc is not None:
+                exc = exc[:1]
+        else:
+            potinfo, exc = self.xc.get_vxc(densinfo), None
+        vm = self._vxc_ao_from_potinfo(potinfo)
+        mat, en, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm)
+        self._energy_memo = (dm, dm._version, en[0], None if exc is None else exc[0])
+        return mat
 
     def get_elrep_plus_vxc_pol(self, dm: SpinParam):
         """J[D_u + D_d] + Vxc_s[D_u, D_d] of an unrestricted pair of density matrices as a stacked (2, nao, nao) tensor in the
@@ -885,6 +931,16 @@ class HamiltonMI355(_Base):
         if self._df is not None:  # hcgto.py:229-230
             raise RuntimeError("Exact exchange cannot be computed with density fitting")
         assert dm.dim() == 2
+        if self._fused_fock_ok(dm):
+            # D_ao = X D X^T + zeroed accumulators, the tile pass, then symmetrised J / K, the two traces and X^T (J - K / 2) X: three
+            # launches (csrc/fock.hip) instead of sixteen
+            n, x, work = self._nao_ao, self._orthozer, self._jkwork
+            tiles = self._tiles
+            lib.fock_prep(work, x, n, True, dm=dm.contiguous())
+            lib.jk_stream_prepared(tiles, n, work, True)
+            mat, en, _ = lib.fock_finish(work, x, n, True)
+            self._energy_memo = (dm, dm._version, en[0], None, en[1])
+            return mat
         dao = self._unconvert_dm(dm)
         J, K = self._jk_ao(dao, True)
         # the two-electron energies of THIS density fall out of the build: remembered like get_elrep_plus_vxc's

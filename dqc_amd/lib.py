@@ -111,6 +111,9 @@ def load():
     lib.dqc_stream_destroy.argtypes = [c_vp]
     lib.dqc_stream_cus.argtypes = [c_vp]
     lib.dqc_set_vxc_cus.argtypes = [c_int]
+    lib.dqc_fock_prep.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_vp]
+    lib.dqc_jk_stream_prepared.argtypes = [c_dp, c_int, c_dp, c_int, c_vp]
+    lib.dqc_fock_finish.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_dp, c_int, c_int, c_int, c_vp]
     lib.dqc_padded_norb.argtypes = [c_int]
     lib.dqc_padded_norb.restype = c_int
     lib.dqc_grid_density_lr.argtypes = [c_dp, c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_int, c_vp]
@@ -506,6 +509,37 @@ def jk(tiles, dm_ao, work, with_k=True):
         _check(load().dqc_jk_from_tiles(_ptr(J), _ptr(K), _ptr(tiles), _ptr(dm_ao.contiguous()), nao, _ptr(work),
                                         st_), "dqc_jk_from_tiles")
     return J, K
+
+
+def fock_max_nao():
+    return int(load().dqc_fock_max_nao())
+
+
+def fock_prep(work, x, nao, with_k, dm=None, orb=None):
+    """work <- symmetric AO density + zeroed accumulators: from the orthogonal-basis `dm` (north, north) and the orthogonaliser `x`
+    (nao, north), or from the AO-basis factor `orb` (rows >= nao zero, rp columns): D_ao = orb orb^T"""
+    north = x.shape[1]
+    with _on(work.device) as st_:
+        _check(load().dqc_fock_prep(_ptr(work), _ptr(dm), _ptr(x), _ptr(orb), 0 if orb is None else orb.shape[1], int(nao), int(north),
+                                    1 if with_k else 0, st_), "dqc_fock_prep")
+
+
+def jk_stream_prepared(tiles, nao, work, with_k):
+    with _on(work.device) as st_:
+        _check(load().dqc_jk_stream_prepared(_ptr(tiles), int(nao), _ptr(work), 1 if with_k else 0, st_),
+               "dqc_jk_from_tiles" if with_k else "dqc_jk_from_tiles[J only]")
+
+
+def fock_finish(work, x, nao, with_k, vxc_ao=None, core=None, want_j=False):
+    """-> fock (north, north) = sym(X^T (J - K / 2 + V) X) + core, energies (2,) = [tr D J / 2, -tr D K / 4], J_ao or None"""
+    north = x.shape[1]
+    fock = torch.empty((north, north), dtype=torch.float64, device=work.device)
+    en = torch.empty(2, dtype=torch.float64, device=work.device)
+    jao = torch.empty((nao, nao), dtype=torch.float64, device=work.device) if want_j else None
+    with _on(work.device) as st_:
+        _check(load().dqc_fock_finish(_ptr(fock), _ptr(en), _ptr(jao), _ptr(work), _ptr(vxc_ao), 0 if vxc_ao is None else vxc_ao.shape[-1],
+                                      _ptr(core), _ptr(x), int(nao), int(north), 1 if with_k else 0, st_), "dqc_fock_finish")
+    return fock, en, jao
 
 
 def jk_direct(tab, dm_ao, with_k=True):

@@ -175,6 +175,7 @@ class SCF_QCCalc:
         resume = getattr(self, "_resume_dm", None)  # the device loop's last good density (a projector failure mid-run)
         if resume is not None:
             dm0, self._resume_dm = resume, None
+            self._resumed_after_failure = True
         gen = self._run_gen(dm0, fwd_options)
         # a Hamiltonian sharded over several GPUs (HamiltonMI355.shard_over) runs this loop on every rank: the scalars the
         # driver decides on are rank 0's, so that every rank takes the same branch and issues the same collectives
@@ -219,6 +220,8 @@ class SCF_QCCalc:
         # 6 ms of rocSOLVER launches per iteration against ~1 ms of GEMMs
         ham = getattr(eng, "hamilton", None)
         direct = bool(getattr(ham, "_direct", False))
+        resumed_after_failure = bool(getattr(self, "_resumed_after_failure", False))
+        self._resumed_after_failure = False
         skip_purify = bool(getattr(self, "_skip_purification", False))  # (the device loop wandered: eigh steps from the start)
         self._skip_purification = False
         if skip_purify:
@@ -236,7 +239,12 @@ class SCF_QCCalc:
         gram = np.zeros((0, 0))
         best_err, best_it = float("inf"), 0
         self.converged = self.stalled = False
-        for it in range(int(opts["maxiter"])):
+        # iteration budget: `maxiter` steps -- and `maxiter` more from the restart, once, when the purification step is dropped (the
+        # reference's diagonalise-and-occupy iteration gets the cap the caller set; the steps the purification wandered do not count)
+        it, it_end = -1, int(opts["maxiter"])
+        nfail = 1 if resumed_after_failure else 0   # projector failures so far (the device loop's hand-over counts)
+        while it + 1 < it_end:
+            it += 1
             self.niter = it + 1
             S = getattr(eng, "ovlp", None)  # overlap of a non-orthogonalised basis (None: identity)
             if pol:
@@ -260,6 +268,7 @@ class SCF_QCCalc:
                 print("scf it %2d  max|[F,D]| %.2e  max|F_out-F_in| %.2e" % (it, emax, fres), flush=True)
             if perr is not None and not pe < 1e-9:  # purification did not converge (vanishing gap): redo this step through eigh
                 self.eigh_fallbacks = getattr(self, "eigh_fallbacks", 0) + 1
+                nfail += 1
                 dm = eng.scp2dm(fprev)
                 fock = eng.dm2scp(dm)
                 perr = None
@@ -268,7 +277,8 @@ class SCF_QCCalc:
                 ev = err.reshape(-1)
                 h2 = yield torch.cat([err.abs().max().reshape(1), (torch.stack(hist + [ev]) * ev).sum(-1)])
                 emax, grow = float(h2[0]), h2[1:]
-            if purified is not None and (not np.isfinite(emax) or (it - best_it >= 40 and emax > 1e-6)):
+            if purified is not None and (not np.isfinite(emax) or (it - best_it >= 40 and emax > 1e-6) or nfail >= 3
+                                         or (it + 1 >= it_end and emax > 1e-6)):
                 # The purification step has no preferred basis inside a degenerate Fermi level (open p shells, ...): every step then
                 # lands on another rotation of the degenerate orbitals, the iteration wanders for ever and the DIIS system eventually
                 # blows up (UKS SCAN on the oxygen triplet: NaN after 88 steps, or -26 Ha).  The reference diagonalises (hf.py:105-113),
@@ -284,6 +294,7 @@ class SCF_QCCalc:
                 dm = eng.scp2dm(eng.dm2scp(SpinParam(u=z_, d=z_) if pol else z_))
                 fock = eng.dm2scp(dm)
                 best_err, best_it = float("inf"), it
+                it_end = it + 1 + int(opts["maxiter"])
                 continue
             self.scf_error = emax  # max |[F, D]| of the last iterate
             # the commutator bottoms out at the round-off floor of the Fock build (fp64 atomics; ~1e-9 for ~200 AOs,

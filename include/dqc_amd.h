@@ -87,6 +87,28 @@ size_t dqc_jk_work_doubles(int nao);
 int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const double *d_dm,
                       int nao, double *d_work, void *stream);
 
+/* ---- the small-matrix ends of a restricted Fock build, fused (round 6; csrc/fock.hip) ----------
+ * Around its tile pass and grid pass the reference's Fock build runs, per density matrix, a dozen nao^3 / nao^2 torch calls:
+ * D_ao = X D X^T (orbconverter.py:126-163 unconvert_dm), the symmetrisation of J and K, the energy traces (hcgto.py:302-328),
+ * X^T (J - K / 2 + V_xc) X (convert2, hcgto.py:204-241, ks.py:176-187) and the sum with the core Hamiltonian (hf.py:182-201).
+ * Three entry points replace them around dqc's own kernels:
+ *   dqc_fock_prep           d_work <- symmetric AO density (zero padded) + zeroed J / K accumulators.  Either from the orthogonal-
+ *                           basis density d_dm (north, north) [its symmetric part] and the orthogonaliser d_x (nao, north), or
+ *                           (d_orb != NULL) from the AO-basis orbital factor of ao_orb2dm, d_orb (>= nao rows, rp columns,
+ *                           row-major, rows >= nao zero): D_ao = L L^T.
+ *   dqc_jk_stream_prepared  the pass over the ERI tiles on that work buffer (with_k: Coulomb + exchange), accumulators left in it
+ *   dqc_fock_finish         d_fock (north, north) <- sym(X^T (J - K / 2 + V) X) + core, bitwise symmetric; d_energies[0] =
+ *                           1/2 tr D_ao J, [1] = -1/4 tr D_ao K (0 without K); d_j_ao (nao, nao; may be NULL) <- J.
+ *                           d_vxc_ao: symmetric AO-basis matrix with row stride ldv (dqc_grid_vxc's output) or NULL; d_core:
+ *                           (north, north) or NULL.
+ * nao <= dqc_fock_max_nao().  d_work: dqc_jk_work_doubles(nao) doubles, the same buffer through the three calls. */
+int dqc_fock_max_nao(void);
+int dqc_fock_prep(double *d_work, const double *d_dm, const double *d_x, const double *d_orb, int rp, int nao, int north, int with_k,
+                  void *stream);
+int dqc_jk_stream_prepared(const double *d_tiles, int nao, double *d_work, int with_k, void *stream);
+int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, const double *d_work, const double *d_vxc_ao, int ldv,
+                    const double *d_core, const double *d_x, int nao, int north, int with_k, void *stream);
+
 /* Several density matrices in ONE pass over the tiles (unrestricted HF: J[D_u + D_d], K[2 D_u], K[2 D_d],
  * hcgto.py:238-241, hf.py:93-103; batched dm, base_hamilton.py:92-93).
  * d_dmJ (nj, nao, nao) -> d_J (nj, nao, nao);  d_dmK (nk, nao, nao) -> d_K (nk, nao, nao); either count may be 0.
