@@ -870,7 +870,9 @@ extern "C" {
 
 size_t dqc_jk_work_doubles(int nao) {
     const size_t npad = (size_t)(nao + DQC_TILE_B - 1) / DQC_TILE_B * DQC_TILE_B;
-    return 3 * npad * npad + 8;  // D, J, K accumulators + the fixed-point scale of the deterministic mode
+    // D, J, K accumulators | 8 slots (the fixed-point scale of the deterministic mode, the ticket of fock_combine_kernel) | the combined
+    // AO matrix and the half-transformed matrix of dqc_fock_finish / dqc_fock_prep | 2 x 64 partial sums (csrc/fock.hip)
+    return 5 * npad * npad + 8 + 128;
 }
 
 long long dqc_eri_tile_offset(int nao, long long tile) {

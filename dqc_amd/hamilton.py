@@ -638,7 +638,12 @@ class HamiltonMI355(_Base):
                     if not self._weights_nonneg(w):
                         self._dm_factor.remove(c)
                         return None
-                    l_ao = self._orthozer @ (orb * torch.sqrt(w).unsqueeze(-2))
+                    x = self._orthozer
+                    if (orb.dim() == 2 and w.dim() == 1 and orb.is_cuda and orb.stride(1) == 1 and w.is_contiguous() and x.is_contiguous()
+                            and 0 < orb.shape[1] <= 128 and self._nao_ao <= lib.fock_max_nao() and os.environ.get("DQC_AMD_FUSED_FOCK", "1") != "0"):
+                        c[2:] = [[lib.fock_factor(x, orb, w, self._nao_ao, self._ld)]]  # (one launch: csrc/fock.hip)
+                        return c[2]
+                    l_ao = x @ (orb * torch.sqrt(w).unsqueeze(-2))
                     r = l_ao.shape[-1]
                     if lib.padded_norb(r) > 0:
                         c[2:] = [[lib.pad_factor(l_ao, self._ld)]]
@@ -801,14 +806,14 @@ class HamiltonMI355(_Base):
             vm = vm + lib.grid_vxc_pair(g3, g3, self._nao_ao, self.dvolume.repeat(3), lk.repeat(3), what="dqc_grid_vxc_pair[three gradient components]")
         return self._allsum(vm)
 
-    def get_elrep_plus_vxc(self, dm):
+    def get_elrep_plus_vxc(self, dm, core=None):
         """J[D] + Vxc[D] of ONE restricted density matrix as a plain tensor in the orthogonalised basis -- the sum
         `_KSEngine.__dm2fock` forms (ks.py:176-187) -- with a single AO -> orthogonal conversion X^T (J_ao + V_ao) X instead
         of one per operator.  Same numbers as get_elrep(dm) + get_vxc(dm) up to round-off."""
         assert self.xc is not None and dm.dim() == 2
         fac = self._factor_of(dm)
         if self._fused_fock_ok(dm) and not (_COULOMB_SIDE and not torch.cuda.is_current_stream_capturing()):
-            return self._elrep_plus_vxc_fused(dm, fac)
+            return self._elrep_plus_vxc_fused(dm, fac, core)
         if fac is not None and len(fac) == 1:  # D_ao = L_ao L_ao^T: one thin GEMM instead of X D X^T
             n = self._nao_ao
             dao = (fac[0][0] @ fac[0][1])[:n, :n].contiguous()
@@ -852,9 +857,10 @@ class HamiltonMI355(_Base):
         e_j = 0.5 * (dao * jao).sum()
         self._energy_memo = (dm, dm._version, e_j, None if exc is None else exc[0])
         mat = self._convert2(jao + vm[:self._nao_ao, :self._nao_ao])
-        return (mat + mat.transpose(-2, -1)) * 0.5
+        mat = (mat + mat.transpose(-2, -1)) * 0.5
+        return mat if core is None else core + mat
 
-    def _elrep_plus_vxc_fused(self, dm, fac):
+    def _elrep_plus_vxc_fused(self, dm, fac, core=None):
         """get_elrep_plus_vxc with the small-matrix ends fused (csrc/fock.hip): AO density (from the orbital factor when it is known,
         else X D X^T) + zeroed accumulators in ONE launch, the tile pass, the grid pass, then J's symmetrisation, tr D J / 2,
         X^T (J + V_ao) X and its symmetrisation in ONE launch"""
@@ -873,7 +879,7 @@ class HamiltonMI355(_Base):
         else:
             potinfo, exc = self.xc.get_vxc(densinfo), None
         vm = self._vxc_ao_from_potinfo(potinfo)
-        mat, en, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm)
+        mat, en, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm, core=core)  # (core: the one-electron part, added in the same launch)
         self._energy_memo = (dm, dm._version, en[0], None if exc is None else exc[0])
         return mat
 
@@ -923,7 +929,7 @@ class HamiltonMI355(_Base):
             return c[k]
         return None
 
-    def get_elrep_plus_exchange(self, dm):
+    def get_elrep_plus_exchange(self, dm, core=None):
         """J[D] - K[D] / 2 of ONE restricted density matrix as a plain tensor in the orthogonalised basis -- the sum a restricted
         Hartree-Fock Fock build forms from get_elrep(dm) and get_exchange(dm) (hf.py:198-199, hcgto.py:204-241) -- with a single
         AO -> orthogonal conversion X^T (J_ao - K_ao / 2) X instead of one per operator (two rocBLAS GEMMs of ~10 us each at
@@ -936,9 +942,13 @@ class HamiltonMI355(_Base):
             # launches (csrc/fock.hip) instead of sixteen
             n, x, work = self._nao_ao, self._orthozer, self._jkwork
             tiles = self._tiles
-            lib.fock_prep(work, x, n, True, dm=dm.contiguous())
+            fac = self._factor_of(dm)
+            if fac is not None and len(fac) == 1 and fac[0][0].is_contiguous():  # D_ao = L L^T from the orbital factor (dqc_fock_factor)
+                lib.fock_prep(work, x, n, True, orb=fac[0][0])
+            else:
+                lib.fock_prep(work, x, n, True, dm=dm.contiguous())
             lib.jk_stream_prepared(tiles, n, work, True)
-            mat, en, _ = lib.fock_finish(work, x, n, True)
+            mat, en, _ = lib.fock_finish(work, x, n, True, core=core)
             self._energy_memo = (dm, dm._version, en[0], None, en[1])
             return mat
         dao = self._unconvert_dm(dm)
@@ -946,7 +956,8 @@ class HamiltonMI355(_Base):
         # the two-electron energies of THIS density fall out of the build: remembered like get_elrep_plus_vxc's
         self._energy_memo = (dm, dm._version, 0.5 * (dao * J).sum(), None, -0.25 * (dao * K).sum())
         mat = self._convert2(J - 0.5 * K)
-        return (mat + mat.transpose(-2, -1)) * 0.5
+        mat = (mat + mat.transpose(-2, -1)) * 0.5
+        return mat if core is None else core + mat
 
     def timed_fock_kernels(self, dm, core):
         """measurement aid (bench.py): the restricted KS Fock build `core + get_elrep_plus_vxc(dm)` unrolled -- the same
@@ -955,13 +966,37 @@ class HamiltonMI355(_Base):
         assert self.xc is not None and dm.dim() == 2 and self.xcfamily == 2
         n = self._nao_ao
         fac = self._factor_of(dm)
-        dao_n = self._unconvert_dm((dm + dm.transpose(-2, -1)) * 0.5).contiguous()
         ev = []
 
         def mark():
             e = torch.cuda.Event(enable_timing=True)
             e.record(torch.cuda.current_stream(self.device))
             ev.append(e)
+
+        if self._fused_fock_ok(dm):  # the calls of _elrep_plus_vxc_fused, in its order
+            x, work, tiles = self._orthozer, self._jkwork, self._tiles
+            mark()
+            if fac is not None and len(fac) == 1 and fac[0][0].is_contiguous():
+                lib.fock_prep(work, x, n, False, orb=fac[0][0])
+            else:
+                lib.fock_prep(work, x, n, False, dm=dm.contiguous())
+            mark()
+            lib.jk_stream_prepared(tiles, n, work, False)
+            mark()
+            if fac is not None and len(fac) == 1:
+                rho, grho = lib.grid_density_lr(self._ao, n, fac[0], True)
+            else:
+                dmdmt = (dm + dm.transpose(-2, -1)) * 0.5
+                rho, grho = lib.grid_density(self._ao, n, lib.pad_matrix(self._unconvert_dm(dmdmt), self._ld), True)
+            mark()
+            _, v, vg = lib.xc_eval(self.xc.terms, rho, grho, want_e=False, want_v=True)
+            mark()
+            vm = lib.grid_vxc(self._ao, n, self.dvolume, v, vg)
+            mark()
+            fock, _, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm, core=core.contiguous())  # noqa: F841
+            mark()
+            return ["orth_transforms", "jk_tiles", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"], ev
+        dao_n = self._unconvert_dm((dm + dm.transpose(-2, -1)) * 0.5).contiguous()
 
         mark()
         if self._df is None:

@@ -111,6 +111,7 @@ def load():
     lib.dqc_stream_destroy.argtypes = [c_vp]
     lib.dqc_stream_cus.argtypes = [c_vp]
     lib.dqc_set_vxc_cus.argtypes = [c_int]
+    lib.dqc_fock_factor.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_fock_prep.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_jk_stream_prepared.argtypes = [c_dp, c_int, c_dp, c_int, c_vp]
     lib.dqc_fock_finish.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_dp, c_int, c_int, c_int, c_vp]
@@ -513,6 +514,22 @@ def jk(tiles, dm_ao, work, with_k=True):
 
 def fock_max_nao():
     return int(load().dqc_fock_max_nao())
+
+
+def fock_factor(x, c, w, nao, ld):
+    """the padded AO-basis factor pair (orb (ld, rp), orbt (rp, ld)) of D = C diag(w) C^T: L = X (C sqrt(w)) in one launch; None when
+    the factor is wider than the density kernel's widest instantiation.  c: (north, r) with unit column stride, w: (r,) >= 0"""
+    r = c.shape[1]
+    rp = padded_norb(r)
+    if rp == 0:
+        return None
+    assert c.stride(1) == 1 and c.dtype == torch.float64 and w.is_contiguous()
+    orb = torch.empty((ld, rp), dtype=torch.float64, device=x.device)
+    orbt = torch.empty((rp, ld), dtype=torch.float64, device=x.device)
+    with _on(x.device) as st_:
+        _check(load().dqc_fock_factor(_ptr(orb), _ptr(orbt), _ptr(x), ctypes.c_void_p(c.data_ptr()), int(c.stride(0)), _ptr(w), int(nao),
+                                      int(x.shape[1]), int(r), int(ld), int(rp), st_), "dqc_fock_factor")
+    return orb, orbt
 
 
 def fock_prep(work, x, nao, with_k, dm=None, orb=None):

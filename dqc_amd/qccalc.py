@@ -71,6 +71,14 @@ class _Engine:
     def get_system(self):
         return self._system
 
+    def _core_matrix(self):
+        """the one-electron part of the Fock matrix as a contiguous tensor (handed to the Hamiltonian's fused build, which adds it in
+        the launch that forms X^T (J - K / 2 + V) X)"""
+        c = getattr(self, "_core_cache", None)
+        if c is None:
+            c = self._core_cache = self.knvext.fullmatrix().contiguous()
+        return c
+
     # Fock build -- THE hot path (hf.py:182-201, ks.py:176-187)
     def dm2scp(self, dm):
         if self.polarized:  # scp = stacked (F_u, F_d)  (hf.py:93-103)
@@ -91,10 +99,10 @@ class _Engine:
             return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])
         if self.is_ks and dm.dim() == 2 and hasattr(self.hamilton, "get_elrep_plus_vxc"):
             # J + Vxc with one AO -> orthogonal conversion (the operators' own sum, ks.py:176-187, converts each)
-            return self.knvext.fullmatrix() + self.hamilton.get_elrep_plus_vxc(dm)
+            return self.hamilton.get_elrep_plus_vxc(dm, core=self._core_matrix())
         if not self.is_ks and dm.dim() == 2 and self.hamilton.df is None and hasattr(self.hamilton, "get_elrep_plus_exchange"):
             # J - K / 2 with one AO -> orthogonal conversion (hf.py:198-199 converts each operator)
-            return self.knvext.fullmatrix() + self.hamilton.get_elrep_plus_exchange(dm)
+            return self.hamilton.get_elrep_plus_exchange(dm, core=self._core_matrix())
         elrep = self.hamilton.get_elrep(dm)
         if self.is_ks:
             fock = self.knvext + elrep + self.hamilton.get_vxc(dm)

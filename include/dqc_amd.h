@@ -101,12 +101,18 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
  *                           1/2 tr D_ao J, [1] = -1/4 tr D_ao K (0 without K); d_j_ao (nao, nao; may be NULL) <- J.
  *                           d_vxc_ao: symmetric AO-basis matrix with row stride ldv (dqc_grid_vxc's output) or NULL; d_core:
  *                           (north, north) or NULL.
- * nao <= dqc_fock_max_nao().  d_work: dqc_jk_work_doubles(nao) doubles, the same buffer through the three calls. */
+ *   dqc_fock_factor         the AO-basis factor of D = C diag(w) C^T (ao_orb2dm, hcgto.py:272-281): L = X (C sqrt(w)) written zero
+ *                           padded as d_orb (ld, rp) and its transpose d_orbt (rp, ld) -- the operand pair of dqc_grid_density_lr
+ *                           and of dqc_fock_prep.  d_c: (north, r) orbitals with row stride ldc, d_w: r occupations >= 0.
+ * nao <= dqc_fock_max_nao().  d_work: dqc_jk_work_doubles(nao) doubles, the same buffer through the calls of one build, in the
+ * order prep, tile pass, finish (the buffer also carries the scratch matrices and the reduction ticket of dqc_fock_finish). */
 int dqc_fock_max_nao(void);
+int dqc_fock_factor(double *d_orb, double *d_orbt, const double *d_x, const double *d_c, int ldc, const double *d_w, int nao, int north,
+                    int r, int ld, int rp, void *stream);
 int dqc_fock_prep(double *d_work, const double *d_dm, const double *d_x, const double *d_orb, int rp, int nao, int north, int with_k,
                   void *stream);
 int dqc_jk_stream_prepared(const double *d_tiles, int nao, double *d_work, int with_k, void *stream);
-int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, const double *d_work, const double *d_vxc_ao, int ldv,
+int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, double *d_work, const double *d_vxc_ao, int ldv,
                     const double *d_core, const double *d_x, int nao, int north, int with_k, void *stream);
 
 /* Several density matrices in ONE pass over the tiles (unrestricted HF: J[D_u + D_d], K[2 D_u], K[2 D_d],
