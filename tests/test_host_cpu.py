@@ -63,7 +63,10 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert L.dqc_eri_store_doubles(nao) == tot, nao
     assert L.dqc_eri_store_doubles(114) * 8 / 114 ** 4 < 1.04  # benzene / cc-pVDZ: 1.26 x nao^4 bytes with a full last block
     assert 0.93 < L.dqc_eri_store_doubles(208) / (L.dqc_eri_tile_count(208) * 4096) < 0.94
-    assert L.dqc_jk_work_doubles(7) == 3 * 8 * 8 + 8  # D, J, K accumulators + the deterministic-mode scale slot
+    # D, J, K accumulators + 8 slots (deterministic-mode scale, reduction ticket) + the two scratch matrices and 2 x 64 partial sums of
+    # the fused build ends (csrc/fock.hip, round 6)
+    assert L.dqc_jk_work_doubles(7) == 5 * 8 * 8 + 8 + 128
+    assert L.dqc_fock_max_nao() >= 448
 
 
 def test_hamiltonian_fails_loudly_without_gpu():
