@@ -13,7 +13,7 @@
 
 namespace dqc {
 
-template <bool EXT>
+template <bool EXT, int PAIR = 0>
 __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                           const double *__restrict__ rho, const double *__restrict__ grho, int n, XcTerms terms,
                           int gga, const double *__restrict__ w, double *__restrict__ exc) {
@@ -23,7 +23,8 @@ __global__ __launch_bounds__(256) void xc_kernel(double *__restrict__ edens, dou
         double gx = 0, gy = 0, gz = 0;
         if (gga) { gx = grho[i]; gy = grho[(size_t)n + i]; gz = grho[2 * (size_t)n + i]; }
         double e, vr, vs;
-        xc_point<EXT>(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
+        if constexpr (PAIR != 0) xc_point_pair<PAIR>(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
+        else xc_point<EXT>(terms, r, gx * gx + gy * gy + gz * gz, e, vr, vs);
         if (edens) edens[i] = e;
         if (exc) equad += w[i] * e;
         if (vrho) vrho[i] = vr;
@@ -286,7 +287,15 @@ extern "C" int dqc_xc_eval_quad(double *d_exc, double *d_edens, double *d_vrho, 
     if (blocks > cap) blocks = cap;
     bool ext = false;
     for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
-    if (ext) hipLaunchKernelGGL(xc_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
+    // the two pairs the BASELINE configs run have their own instantiations (xc_point_pair: fewer registers, more waves per SIMD)
+    const int pair = (nterm == 2 && ids[0] == DQC_XC_GGA_X_PBE && ids[1] == DQC_XC_GGA_C_PBE && d_grho) ? 1
+                   : (nterm == 2 && ids[0] == DQC_XC_LDA_X && ids[1] == DQC_XC_LDA_C_PW) ? 2 : 0;
+    static const bool no_pair = getenv("DQC_XC_GENERIC") != nullptr;  // (A/B runs)
+    if (pair == 1 && !no_pair) hipLaunchKernelGGL((xc_kernel<false, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad,
+                                                  d_rho, d_grho, n, t, 1, d_w, d_exc);
+    else if (pair == 2 && !no_pair) hipLaunchKernelGGL((xc_kernel<false, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad,
+                                                       d_rho, d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
+    else if (ext) hipLaunchKernelGGL(xc_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
                                 d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);
     else hipLaunchKernelGGL(xc_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_rho,
                             d_grho, n, t, d_grho ? 1 : 0, d_w, d_exc);

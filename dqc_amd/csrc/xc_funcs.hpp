@@ -300,4 +300,23 @@ DQC_DEV void xc_point(const XcTerms &terms, double r, double sigma, double &e, d
     }
 }
 
+// the same for the two functional pairs the BASELINE configs run, with the functionals fixed at compile time: the generic kernel
+// carries the register budget of the widest branch of the switch (240 VGPRs, two waves per SIMD); PAIR 1 = gga_x_pbe + gga_c_pbe,
+// PAIR 2 = lda_x + lda_c_pw.  Same functions, same order of the additions: bit-identical to xc_point.
+template <int PAIR>
+DQC_DEV void xc_point_pair(const XcTerms &terms, double r, double sigma, double &e, double &vr, double &vs) {
+    e = vr = vs = 0.0;
+    if (r > 1e-15) {
+        const Dual dr = mk(r, 1.0, 0.0), ds = mk(sigma, 0.0, 1.0);
+        const Dual f0 = PAIR == 1 ? f_gga_x_pbe(dr, ds) : f_lda_x(dr);
+        e += terms.c[0] * f0.v;
+        vr += terms.c[0] * f0.r;
+        vs += terms.c[0] * f0.s;
+        const Dual f1 = PAIR == 1 ? f_gga_c_pbe(dr, ds) : f_lda_c_pw(dr);
+        e += terms.c[1] * f1.v;
+        vr += terms.c[1] * f1.r;
+        vs += terms.c[1] * f1.s;
+    }
+}
+
 }  // namespace dqc

@@ -774,7 +774,7 @@ class HamiltonMI355(_Base):
     def _dm2densinfo_pol(self, dm: SpinParam) -> SpinParam:
         """both spin channels' densities (SpinParam.apply_fcn over _dm2densinfo in the reference, hcgto.py:260-269).  GGA with both
         factors known: ONE pass over the AO matrix for the two spins (dqc_grid_density_lr_pol) instead of one per spin"""
-        if self.xcfamily == 2 and self.is_ao_set and self.is_grad_ao_set:
+        if self.xcfamily == 2 and self.is_ao_set and self.is_grad_ao_set and os.environ.get("DQC_AMD_POL_DENSITY", "fused") != "split":
             fu, fd = self._factor_of(dm.u), self._factor_of(dm.d)
             if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
                 out = lib.grid_density_lr_pol(self._ao, self._nao_ao, fu[0], fd[0])
