@@ -166,7 +166,7 @@ DQC_DEV D5 pbe_x_unpol5(D5 r, D5 s, double kappa = kPbeKappa, double mu = kPbeMu
 }
 
 
-template <bool EXT>
+template <bool EXT, int PAIR = 0>
 __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens, double *__restrict__ vru, double *__restrict__ vrd,
                               double *__restrict__ vgu, double *__restrict__ vgd, const double *__restrict__ ru_,
                               const double *__restrict__ rd_, const double *__restrict__ gu_,
@@ -187,11 +187,13 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
             const D5 rho = u + d;
             D5 zeta = (u - d) / rho;
             zeta.v = fmin(fmax(zeta.v, -1.0 + 1e-10), 1.0 - 1e-10);
-            for (int t = 0; t < terms.n; t++) {
+            // one term of the functional at this point; called with a run-time id in the generic kernel and with compile-time ids in
+            // the PBE-pair instantiation (PAIR = 1: the switch folds away -- the generic kernel holds 506 VGPRs, one wave per SIMD)
+            auto term = [&](const int tid_) -> D5 {
                 D5 f;
                 bool ext_done = false;
                 if constexpr (EXT) {  // the round-4 functionals live in their own instantiation (see xc_funcs.hpp: xc_id_is_ext)
-                    const int id_ = terms.id[t];
+                    const int id_ = tid_;
                     if (xc_id_is_x_enh(id_)) {  // enhancement-factor exchange: exact spin scaling of the unpolarised form
                         f = 0.5 * (gga_x_by_enh(id_, 2.0 * u, 4.0 * suu) + gga_x_by_enh(id_, 2.0 * d, 4.0 * sdd));
                         ext_done = true;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                     }
                 }
                 if (!ext_done)
-                switch (terms.id[t]) {
+                switch (tid_) {
                 case DQC_XC_LDA_X:
                     f = (-0.75 * 0.98474502184269641 * 1.2599210498948732) * (u * cbrt5(u) + d * cbrt5(d));
                     break;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                 } break;
                 case DQC_XC_GGA_X_PBE: case DQC_XC_GGA_X_PBE_R: case DQC_XC_GGA_X_PBE_SOL: case DQC_XC_GGA_X_RPBE: {
                     // exchange: exact spin scaling of the unpolarised form (kappa, mu by member of the family)
-                    const int id_ = terms.id[t];
+                    const int id_ = tid_;
                     const double ka = id_ == DQC_XC_GGA_X_PBE_R ? 1.245 : kPbeKappa, mu_ = id_ == DQC_XC_GGA_X_PBE_SOL ? 10.0 / 81.0 : kPbeMu;
                     const bool rp = id_ == DQC_XC_GGA_X_RPBE;
                     f = 0.5 * (pbe_x_unpol5(2.0 * u, 4.0 * suu, ka, mu_, rp) + pbe_x_unpol5(2.0 * d, 4.0 * sdd, ka, mu_, rp));
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                 case DQC_XC_GGA_C_LYP: f = lyp_pol5(u, d, suu, sud, sdd); break;
                 default: {
                     const double a3[3] = {0.0310906908696548950, 0.01554534543482745, 0.0168868639403896};
-                    const double beta = terms.id[t] == DQC_XC_GGA_C_PBE_SOL ? 0.046 : kPbeBeta, gamma = 0.031090690869654895;
+                    const double beta = tid_ == DQC_XC_GGA_C_PBE_SOL ? 0.046 : kPbeBeta, gamma = 0.031090690869654895;
                     D5 eps = pw92_pol_eps(rho, zeta, a3);
                     D5 phi = 0.5 * (p5(1.0 + zeta, 2.0 / 3.0) + p5(1.0 - zeta, 2.0 / 3.0));
                     D5 phi3 = phi * phi * phi;
@@ -243,8 +245,21 @@ __global__ __launch_bounds__(256) void xc_pol_kernel(double *__restrict__ edens,
                     f = rho * (eps + gamma * phi3 * log1p5(X));
                 } break;
                 }
-                e += terms.c[t] * f.v;
-                for (int k = 0; k < 5; k++) dv[k] += terms.c[t] * f.d[k];
+                return f;
+            };
+            if constexpr (PAIR == 1) {
+                const D5 f0 = term(DQC_XC_GGA_X_PBE);
+                e += terms.c[0] * f0.v;
+                for (int k = 0; k < 5; k++) dv[k] += terms.c[0] * f0.d[k];
+                const D5 f1 = term(DQC_XC_GGA_C_PBE);
+                e += terms.c[1] * f1.v;
+                for (int k = 0; k < 5; k++) dv[k] += terms.c[1] * f1.d[k];
+            } else {
+                for (int t = 0; t < terms.n; t++) {
+                    const D5 f = term(terms.id[t]);
+                    e += terms.c[t] * f.v;
+                    for (int k = 0; k < 5; k++) dv[k] += terms.c[t] * f.d[k];
+                }
             }
         }
         if (edens) edens[i] = e;
@@ -701,7 +716,11 @@ extern "C" int dqc_xc_eval_pol(double *d_edens, double *d_vrho_u, double *d_vrho
     if (blocks > 4096) blocks = 4096;
     bool ext = false;
     for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
-    if (ext) hipLaunchKernelGGL(xc_pol_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
+    static const bool no_pair = getenv("DQC_XC_GENERIC") != nullptr;  // (A/B runs)
+    if (!no_pair && gga && nterm == 2 && ids[0] == DQC_XC_GGA_X_PBE && ids[1] == DQC_XC_GGA_C_PBE)  // compile-time PBE pair
+        hipLaunchKernelGGL((xc_pol_kernel<false, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d, d_vgrad_u,
+                           d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, 1);
+    else if (ext) hipLaunchKernelGGL(xc_pol_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
                                 d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
     else hipLaunchKernelGGL(xc_pol_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho_u, d_vrho_d,
                             d_vgrad_u, d_vgrad_d, d_rho_u, d_rho_d, d_grho_u, d_grho_d, n, t, gga ? 1 : 0);
