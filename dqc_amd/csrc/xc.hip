@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void xc_mgga_pol_kernel(double *__restrict__ e
     }
 }
 
-template <bool EXT>
+// PAIR: 0 generic (run-time ids), 1 mgga_x_scan alone, 2 mgga_x_scan + mgga_c_scan (compile-time ids: the branches fold away)
+template <bool EXT, int PAIR = 0>
 __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens, double *__restrict__ vrho, double *__restrict__ vgrad,
                                double *__restrict__ vtau, const double *__restrict__ rho,
                                const double *__restrict__ grho, const double *__restrict__ tau, int n, XcTerms terms) {
@@ -629,26 +630,41 @@ __global__ __launch_bounds__(256) void xc_mgga_kernel(double *__restrict__ edens
         if (r > 1e-15) {
             const double sig = fmax(gx * gx + gy * gy + gz * gz, 1e-40), tk = fmax(tau[i], 1e-20);
             const Dual dr = mk(r, 1.0, 0.0), ds = mk(sig, 0.0, 1.0);
-            for (int t = 0; t < terms.n; t++) {
-                double fv, fr, fs, ft = 0.0;
-                if (xc_id_is_mgga(terms.id[t])) {
+            auto term = [&](const int tid_, double &fv, double &fr, double &fs, double &ft) {
+                ft = 0.0;
+                if (xc_id_is_mgga(tid_)) {
                     D5 f;
-                    if (terms.id[t] == DQC_XC_MGGA_C_TPSS) {  // closed shell: the general form at rho_u = rho_d, sigma_ss' = sigma / 4
+                    if (tid_ == DQC_XC_MGGA_C_TPSS) {  // closed shell: the general form at rho_u = rho_d, sigma_ss' = sigma / 4
                         const D5 h = 0.5 * var5(r, 0), q = 0.25 * var5(sig, 1);
                         D5 z = var5(sig, 1) / (8.0 * var5(r, 0) * var5(tk, 2));
                         if (z.v > 1.0) z = c5(1.0);
                         f = tpss_c_core(h, h, q, q, q, z);
                     } else {
-                        f = terms.id[t] == DQC_XC_MGGA_X_SCAN   ? f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2))
-                            : terms.id[t] == DQC_XC_MGGA_X_TPSS ? f_mgga_x_tpss(var5(r, 0), var5(sig, 1), var5(tk, 2))
-                                                                : f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                        if (tid_ == DQC_XC_MGGA_X_SCAN) f = f_mgga_x_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                        else if (tid_ == DQC_XC_MGGA_X_TPSS) f = f_mgga_x_tpss(var5(r, 0), var5(sig, 1), var5(tk, 2));
+                        else f = f_mgga_c_scan(var5(r, 0), var5(sig, 1), var5(tk, 2));
                     }
                     fv = f.v; fr = f.d[0]; fs = f.d[1]; ft = f.d[2];
                 } else {
-                    const Dual f = f_lda_gga<EXT>(terms.id[t], dr, ds);
+                    const Dual f = f_lda_gga<EXT>(tid_, dr, ds);
                     fv = f.v; fr = f.r; fs = f.s;
                 }
-                e += terms.c[t] * fv; vr += terms.c[t] * fr; vs += terms.c[t] * fs; vt += terms.c[t] * ft;
+            };
+            constexpr int NFIX = PAIR == 1 ? 1 : (PAIR == 2 ? 2 : 0);
+            if constexpr (NFIX > 0) {
+                double fv, fr, fs, ft;
+                term(DQC_XC_MGGA_X_SCAN, fv, fr, fs, ft);
+                e += terms.c[0] * fv; vr += terms.c[0] * fr; vs += terms.c[0] * fs; vt += terms.c[0] * ft;
+                if constexpr (NFIX > 1) {
+                    term(DQC_XC_MGGA_C_SCAN, fv, fr, fs, ft);
+                    e += terms.c[1] * fv; vr += terms.c[1] * fr; vs += terms.c[1] * fs; vt += terms.c[1] * ft;
+                }
+            } else {
+                for (int t = 0; t < terms.n; t++) {
+                    double fv, fr, fs, ft;
+                    term(terms.id[t], fv, fr, fs, ft);
+                    e += terms.c[t] * fv; vr += terms.c[t] * fr; vs += terms.c[t] * fs; vt += terms.c[t] * ft;
+                }
             }
         }
         if (edens) edens[i] = e;
@@ -685,7 +701,14 @@ extern "C" int dqc_xc_eval_mgga(double *d_edens, double *d_vrho, double *d_vgrad
     if (blocks > 4096) blocks = 4096;
     bool ext = false;
     for (int i = 0; i < nterm; i++) ext = ext || xc_id_is_ext(ids[i]);
-    if (ext) hipLaunchKernelGGL(xc_mgga_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+    static const bool no_pair = getenv("DQC_XC_GENERIC") != nullptr;  // (A/B runs)
+    const int pair = no_pair ? 0 : (nterm == 1 && ids[0] == DQC_XC_MGGA_X_SCAN) ? 1
+                   : (nterm == 2 && ids[0] == DQC_XC_MGGA_X_SCAN && ids[1] == DQC_XC_MGGA_C_SCAN) ? 2 : 0;
+    if (pair == 1) hipLaunchKernelGGL((xc_mgga_kernel<false, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+                                      d_rho, d_grho, d_tau, n, t);
+    else if (pair == 2) hipLaunchKernelGGL((xc_mgga_kernel<false, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
+                                           d_rho, d_grho, d_tau, n, t);
+    else if (ext) hipLaunchKernelGGL(xc_mgga_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
                                 d_rho, d_grho, d_tau, n, t);
     else hipLaunchKernelGGL(xc_mgga_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_edens, d_vrho, d_vgrad, d_vtau,
                             d_rho, d_grho, d_tau, n, t);

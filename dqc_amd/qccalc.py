@@ -348,7 +348,16 @@ class SCF_QCCalc:
                 rhs[m] = -1
                 # (m+1) x (m+1) Pulay system on the host with numpy: torch's CPU lstsq costs ~7 ms per call on a
                 # 256-thread box (thread-pool wake-up), several times the whole Fock build
-                c = np.linalg.lstsq(B, rhs, rcond=None)[0][:m]
+                try:
+                    c = np.linalg.lstsq(B, rhs, rcond=None)[0][:m] if np.isfinite(B).all() else None
+                except np.linalg.LinAlgError:  # (LAPACK's SVD gives up on an ill-scaled or non-finite Gram block)
+                    c = None
+                if c is None or not np.isfinite(c).all():
+                    # a Pulay system that cannot be solved: forget the history and take the plain step from this Fock matrix (the next
+                    # iterations rebuild the history; a non-finite commutator is caught at the top of the loop)
+                    fs, es, gram = [fock], [ev], np.array([[float(grow[-1])]])
+                    c = np.ones(1)
+                    m = 1
                 c = torch.as_tensor(c, dtype=fock.dtype).to(fock.device)
                 fmix = (c.reshape((-1,) + (1,) * fock.dim()) * torch.stack(fs)).sum(0)
             else:
