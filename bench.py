@@ -518,8 +518,10 @@ def main():
             "timed_region_s": elapsed,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C5: batch of %d x 20-atom vitamin-C-like organics (nao 208, 353400 grid pts) RKS PBE/cc-pVDZ "
-                                   "sg3, %d per GPU; a step = %d pass(es) over the batch" % (nmol, len(mine), repeats),
+            "config": {"workload": "C5: batch of %d x 20-atom vitamin-C-like organics (nao 208, 353400 grid pts of which %d carry "
+                                   "non-zero weight and are resident) RKS PBE/cc-pVDZ sg3, %d per GPU; a step = %d pass(es) over the batch"
+                                   % (nmol, ngrid, len(mine), repeats),
+                       "ngrid_full": int(h0.ngrid_full), "ngrid_resident_molecule0": ngrid,
                        "coulomb": ("density-fitted J, auxbasis %s (naux %d)" % (args.df, int(h0.df.j2c.shape[0]))) if args.df
                                   else "exact J from stored ERI tiles",
                        "molecules_per_gpu": len(mine), "global_batch": nmol, "nao": nao, "ngrid": ngrid, "streams_per_gpu": nstreams,

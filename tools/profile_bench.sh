@@ -18,7 +18,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_k1 -- python $repo/bench.py --prof
 python $repo/tools/rocpd_summary.py $(find /tmp/prof_k1 -name '*.db' | head -1) > $out/${tag}_kernel_stats_bench_steps10_streams1.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -- python $repo/bench.py --profile-mode --molecules 4 --steps 3 --warmup 1 --min-seconds 0 > /dev/null 2> /tmp/f.err
 python $repo/tools/pmc_summary.py $(find /tmp/prof_f -name '*.db' | head -1) FETCH_SIZE > $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt 2>&1
-python $repo/tools/make_traffic_json.py $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt $out/${tag}_pmc_traffic.json > /dev/null
+# (the resident grid: points of non-zero weight -- bench.py's config.ngrid; the traffic file is only accepted for that workload)
+ng=$(python -c "import json,sys; print(json.loads(open('$out/${tag}_bench_under_rocprof.json').read().strip().splitlines()[-1])['config']['ngrid'])")
+python $repo/tools/make_traffic_json.py $out/${tag}_pmc_FETCH_SIZE_bench_steps3.txt $out/${tag}_pmc_traffic.json 208 $ng > /dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -- python $repo/bench.py --profile-mode --molecules 4 --steps 3 --warmup 1 --min-seconds 0 > /dev/null 2> /tmp/w.err
 python $repo/tools/pmc_summary.py $(find /tmp/prof_w -name '*.db' | head -1) WRITE_SIZE > $out/${tag}_pmc_WRITE_SIZE_bench_steps3.txt 2>&1
 rocprofv3 --kernel-trace --pmc MfmaUtil -d /tmp/prof_m -- python $repo/bench.py --profile-mode --molecules 4 --steps 3 --warmup 1 --min-seconds 0 > /dev/null 2> /tmp/m.err
