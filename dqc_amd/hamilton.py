@@ -883,7 +883,7 @@ class HamiltonMI355(_Base):
         self._energy_memo = (dm, dm._version, en[0], None if exc is None else exc[0])
         return mat
 
-    def get_elrep_plus_vxc_pol(self, dm: SpinParam):
+    def get_elrep_plus_vxc_pol(self, dm: SpinParam, core=None):
         """J[D_u + D_d] + Vxc_s[D_u, D_d] of an unrestricted pair of density matrices as a stacked (2, nao, nao) tensor in the
         orthogonalised basis -- the sums the polarised `_KSEngine.__dm2fock` forms (ks.py:176-187, hf.py:93-103) -- with ONE batched
         AO -> orthogonal conversion X^T (J_ao + V_s,ao) X of the two sums instead of one per operator (three), the AO-basis total
@@ -893,6 +893,9 @@ class HamiltonMI355(_Base):
         assert self.xc is not None and dm.u.dim() == 2 and self._df is None and not self._direct and self._tile_slice is None
         n = self._nao_ao
         fu, fd = self._factor_of(dm.u), self._factor_of(dm.d)
+        if (self._fused_fock_ok(dm.u) and fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1
+                and not (_COULOMB_SIDE and not torch.cuda.is_current_stream_capturing())):
+            return self._elrep_plus_vxc_pol_fused(dm, fu[0], fd[0], core)
 
         def coulomb():  # (the AO-basis total density and its Coulomb matrix: nothing the grid pass waits for)
             if fu is not None and fd is not None and len(fu) == 1 and len(fd) == 1:
@@ -921,7 +924,37 @@ class HamiltonMI355(_Base):
             jao.record_stream(main)  # (allocated on the side stream, read and later freed on this one)
         x = self._orthozer
         mat = x.transpose(-2, -1) @ torch.stack([jao + vu, jao + vd]) @ x
-        return (mat + mat.transpose(-2, -1)) * 0.5
+        mat = (mat + mat.transpose(-2, -1)) * 0.5
+        return mat if core is None else core + mat
+
+    def _elrep_plus_vxc_pol_fused(self, dm, fu, fd, core=None):
+        """get_elrep_plus_vxc_pol through the fused build ends (csrc/fock.hip): the total AO density L L^T of the stacked factor
+        [L_u | L_d] in one launch, the Coulomb stream beside the two-spin grid pass (second stream, as in the torch form), then per
+        spin M_s = J + V_s, X^T M_s X, the symmetrisation and the core Hamiltonian in three launches"""
+        n, x, work = self._nao_ao, self._orthozer, self._jkwork
+        tiles = self._tiles
+        lib.fock_prep(work, x, n, False, orb=torch.cat([fu[0], fd[0]], dim=1))
+        side = None
+        if dm.u.is_cuda and os.environ.get("DQC_AMD_J_OVERLAP", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            side = getattr(self, "_j_stream", None)
+            if side is None:
+                side = self._j_stream = torch.cuda.Stream(device=dm.u.device)
+        if side is not None:
+            main = torch.cuda.current_stream(dm.u.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lib.jk_stream_prepared(tiles, n, work, False)
+        else:
+            lib.jk_stream_prepared(tiles, n, work, False)
+        potinfo = self.xc.get_vxc(self._dm2densinfo_pol(dm))
+        vu = self._vxc_ao_from_potinfo(potinfo.u)
+        vd = self._vxc_ao_from_potinfo(potinfo.d)
+        if side is not None:
+            main.wait_stream(side)
+        # (the two finishes share the scratch regions of the work buffer: stream order keeps them apart)
+        f_u, _, _ = lib.fock_finish(work, x, n, False, vxc_ao=vu, core=core)
+        f_d, _, _ = lib.fock_finish(work, x, n, False, vxc_ao=vd, core=core)
+        return torch.stack([f_u, f_d])
 
     def _memo_energy(self, dm, k):
         c = getattr(self, "_energy_memo", None)

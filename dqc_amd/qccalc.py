@@ -93,7 +93,7 @@ class _Engine:
             if (self.is_ks and dm.u.dim() == 2 and h.df is None and hasattr(h, "get_elrep_plus_vxc_pol") and not getattr(h, "_direct", False)
                     and not getattr(h, "sharded", False) and getattr(h, "_tile_slice", None) is None):
                 # J + Vxc_s with one batched AO -> orthogonal conversion, the Coulomb stream beside the grid pass (hamilton.py)
-                return self.knvext.fullmatrix() + h.get_elrep_plus_vxc_pol(dm)
+                return h.get_elrep_plus_vxc_pol(dm, core=self._core_matrix())
             core = self.knvext + h.get_elrep(dm.u + dm.d)
             v = h.get_vxc(dm) if self.is_ks else h.get_exchange(dm)
             return torch.stack([(core + v.u).fullmatrix(), (core + v.d).fullmatrix()])

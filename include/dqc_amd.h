@@ -91,7 +91,7 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
  * Around its tile pass and grid pass the reference's Fock build runs, per density matrix, a dozen nao^3 / nao^2 torch calls:
  * D_ao = X D X^T (orbconverter.py:126-163 unconvert_dm), the symmetrisation of J and K, the energy traces (hcgto.py:302-328),
  * X^T (J - K / 2 + V_xc) X (convert2, hcgto.py:204-241, ks.py:176-187) and the sum with the core Hamiltonian (hf.py:182-201).
- * Three entry points replace them around dqc's own kernels:
+ * Four entry points replace them around dqc's own kernels (six tile-parallel launches: one 4-wave block per 16 x 16 output tile):
  *   dqc_fock_prep           d_work <- symmetric AO density (zero padded) + zeroed J / K accumulators.  Either from the orthogonal-
  *                           basis density d_dm (north, north) [its symmetric part] and the orthogonaliser d_x (nao, north), or
  *                           (d_orb != NULL) from the AO-basis orbital factor of ao_orb2dm, d_orb (>= nao rows, rp columns,
