@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-UBENCH_READ_GBS = 6450.0  # bare-process streaming read, non-temporal 16-byte loads (profiles/r02a_read_bw_ubench.txt)
+UBENCH_READ_GBS = 6450.0  # asymptotic streaming-read rate (large buffers; profiles/r02a_read_bw_ubench.txt, r06a_hbm_ceiling_bisect.txt)
 F64_MFMA_PEAK_TF = 78.6  # MI355X dense fp64 matrix peak (vendor figure; the guide lists no fp64 row)
 XC = "gga_x_pbe+gga_c_pbe"
 
@@ -543,12 +543,13 @@ def main():
             "kernel_ms_per_molecule": ktime,
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom] + [whole_iteration],
-            "measured_ceilings_note": "measured_hbm_read_ceiling_gbs = dqc_probe_stream_read: contiguous 32 KB tiles per block, 16-byte "
-                                      "non-temporal loads, four tiles in flight (the fastest shape of tools/ubench/read_bw.hip; the "
-                                      "grid-stride cached-load probe of rounds 1-4 read 5.2-5.3 TB/s).  Inside THIS process -- 141 GB of the "
-                                      "288 resident -- the new shape reads no faster than the old one (5.3 TB/s); the same kernel in a bare "
-                                      "process reads 6.45 TB/s (profiles/r02a_read_bw_ubench.txt, tile U=4 nt=1): standalone_read_ceiling_gbs "
-                                      "is that figure, the stricter of the two yardsticks",
+            "measured_ceilings_note": "measured_hbm_read_ceiling_gbs = dqc_probe_stream_read on a 2 GB buffer (contiguous 32 KB tiles per block, "
+                                      "16-byte non-temporal loads, four tiles in flight).  Round 6 (profiles/r06a_hbm_ceiling_bisect.txt): the same "
+                                      "kernel reads 5.2 TB/s on 2 GB and 6.1 TB/s on 8 GB in ANY process state (bare, 145 GB resident, touched or "
+                                      "not, after MFMA work): a launch pays ~80 us of ramp and drain, t = 0.082 ms + bytes / 6.5 TB/s.  "
+                                      "standalone_read_ceiling_gbs = 6450 is that asymptote (what rounds 2-5 called the standalone figure came "
+                                      "from a larger buffer, not from a cleaner process); kernels that stream 1.9-2.3 GB per launch are priced "
+                                      "against the 2 GB figure",
             "traffic_note": traffic_note,
             "sources": source_sha16(),
         }

@@ -227,6 +227,21 @@ struct SideStreams {
         return DQC_OK;
     }
 };
+// joins the side streams back into `st` on EVERY exit after a successful fork: an early error return would otherwise hand the
+// stream-ordered scratch of the call (DevPool) back while launches queued on the side streams may still read it, and leave the
+// caller's stream unordered behind them.  done(): the normal join, with its return code.  (One set of streams per device and process,
+// round-robin counter unsynchronised: the entry points that use them are meant for one host thread per device.)
+struct SideJoin {
+    SideStreams *s = nullptr;
+    hipStream_t st = nullptr;
+    void arm(SideStreams *s_, hipStream_t st_) { s = s_; st = st_; }
+    int done() {
+        SideStreams *t = s;
+        s = nullptr;
+        return t ? t->join(st) : DQC_OK;
+    }
+    ~SideJoin() { if (s) (void)s->join(st); }
+};
 inline SideStreams *side_streams() {  // nullptr: switched off, or the streams could not be created
     constexpr int MAXDEV = 16;
     static SideStreams pool[MAXDEV];

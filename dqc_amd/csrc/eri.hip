@@ -737,6 +737,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     const int nao = c.b.nao, nsh = (int)c.bg.shells.size();  // (groups: the kernels' "shells")
     hipLaunchKernelGGL(jk_direct_prep_kernel, dim3(256), dim3(256), 0, st, c.d_sym, c.d_a, d_K ? c.d_b : nullptr, d_dm, nao);
     DQC_CHECK_LAUNCH();
+    SideJoin sj;  // joins the side streams on every exit after the fork below
     EriOut og{nao, 0, 0, 0};
     og.dmat = c.d_sym;
     og.jacc = c.d_a;
@@ -765,6 +766,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
         c.stat_dmax = dmx[0];
         plan_screen_begin(c, sp, 0.0, dmx + 1, tau, d_K != nullptr, true, st);  // (the class pairs are planned one by one in front of their launches)
         if ((sp.side = side_streams()) != nullptr && (rc = sp.side->fork(st))) { set_error("dqc_direct_jk: stream fork failed"); return rc; }
+        sj.arm(sp.side, st);
         sp.d_toff = c.d_toff;
         sp.d_bins = c.d_bins;
         spp = &sp;
@@ -779,7 +781,7 @@ int dqc_direct_jk_part(void *ctx, double *d_J, double *d_K, const double *d_dm, 
     constexpr int NCLS = (ERI_LMAX + 1) * (ERI_LMAX + 2) / 2;
     if ((rc = ClassLoopJK<NCLS - 1, NCLS - 1>::run(c.ds, c.dp, c.hp, og, st, spp))) return rc;
     if ((rc = run_generic_classes<ERI_OUT_JK>(nullptr, c.ds, c.dp, c.hp, og, st, spp))) return rc;
-    if (spp && sp.side && (rc = sp.side->join(st))) { set_error("dqc_direct_jk: stream join failed"); return rc; }
+    if ((rc = sj.done())) { set_error("dqc_direct_jk: stream join failed"); return rc; }
     hipLaunchKernelGGL(jk_direct_finish_kernel, dim3(256), dim3(256), 0, st, d_J, d_K, c.d_a, c.d_b, nao);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
@@ -820,6 +822,7 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     HostPairs hp;
     build_pairs(bu, hp);
     DevPool pool(st);  // stream-ordered scratch: this call only enqueues
+    SideJoin sj;       // (after the pool: destroyed -- i.e. the side streams joined -- before the scratch is released)
     DevShells ds;
     if ((rc = upload_shells(ds, bu, pool, st))) { set_error("dqc_eri_fill_tiles: device upload failed"); return rc; }
     int *d_sh = nullptr, *d_off = nullptr;
@@ -845,6 +848,7 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
     if (tile_begin == 0 && tile_end == nt_all) {
         const FillTables ft{&dp, &dp, &hp, &hp, FILL_SAME_TABLE};
         if (wm.side && (rc = wm.side->fork(st))) { set_error("dqc_eri_fill_tiles: stream fork failed"); return rc; }
+        sj.arm(wm.side, st);
         rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, ft, st, og, wmp);
         if (rc) return rc;
     } else {
@@ -913,12 +917,13 @@ int dqc_eri_fill_tiles_part(double *d_tiles_part, const int *atm, int natm, cons
         if ((rc = up(h1, d1)) || (rc = up(h0, d0))) { set_error("dqc_eri_fill_tiles_part: device upload failed"); return rc; }
         const FillTables f11{&d1, &d1, &h1, &h1, FILL_SAME_TABLE}, f10{&d1, &d0, &h1, &h0, FILL_CROSS}, f01{&d0, &d1, &h0, &h1, FILL_CROSS_OFFDIAG};
         if (wm.side && (rc = wm.side->fork(st))) { set_error("dqc_eri_fill_tiles_part: stream fork failed"); return rc; }
+        sj.arm(wm.side, st);
         if ((rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f11, st, og, wmp)) || (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f10, st, og, wmp)) ||
             (rc = ClassLoop<NCLS - 1, NCLS - 1>::run(d_tiles, ds, f01, st, og, wmp)))
             return rc;
     }
     if ((rc = run_generic_classes<ERI_OUT_TILES>(d_tiles, ds, dp, hp, og, st))) return rc;
-    if (wm.side && (rc = wm.side->join(st))) { set_error("dqc_eri_fill_tiles: stream join failed"); return rc; }
+    if ((rc = sj.done())) { set_error("dqc_eri_fill_tiles: stream join failed"); return rc; }
     return DQC_OK;
 }
 

@@ -439,12 +439,14 @@ int dqc_eri_grad(double *d_grad, const double *d_dcart, double jscale, double ks
     c.og = EriOut{0, 0, 0, 0};
     c.og.dcart = d_dcart; c.og.ncart = ncart; c.og.cao = d_cao; c.og.sh_atom = d_atom; c.og.gpart = d_part;
     c.og.nslot = nslot; c.og.natm = natm; c.og.norig = N; c.og.jscale = jscale; c.og.kscale = kscale;
+    SideJoin sj;  // (declared after the scratch pools of this call: destroyed, i.e. joined, before they are released)
     if ((c.side = side_streams()) != nullptr && (rc = c.side->fork(st))) { set_error("dqc_eri_grad: stream fork failed"); return rc; }
+    sj.arm(c.side, st);
     c.dbra = dup; c.hbra = &hup; c.og.dirn = +1;
     if ((rc = launch_grad_all(c, st))) return rc;
     c.dbra = ddown; c.hbra = &hdown; c.og.dirn = -1;
     if ((rc = launch_grad_all(c, st))) return rc;
-    if (c.side && (rc = c.side->join(st))) { set_error("dqc_eri_grad: stream join failed"); return rc; }
+    if ((rc = sj.done())) { set_error("dqc_eri_grad: stream join failed"); return rc; }
     // fold the slots into d_grad on the host side of the stream: tiny
     std::vector<double> part((size_t)nslot * natm * 3), g((size_t)natm * 3);
     DQC_HIP(hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));

@@ -152,6 +152,9 @@ int parse_basis(Basis &b, const int *atm, int natm, const int *bas, int nbas, co
         if (s[3] != 1) { set_error("bas: nctr must be 1 (general contractions are split upstream)"); return DQC_EINVAL; }
         if (h.l < 0 || h.l > DQC_LMAX) { set_error("bas: angular momentum above g is not supported"); return DQC_EINVAL; }
         if (h.atom < 0 || h.atom >= natm) { set_error("bas: atom index out of range"); return DQC_EINVAL; }
+        // the integral kernels split a primitive-quartet index through a float reciprocal that is exact below 2^22 (eri_core.hpp):
+        // (nprim_a nprim_b)(nprim_c nprim_d) < 2^22 holds for nprim <= 45 on every shell
+        if (h.nprim < 1 || h.nprim > 45) { set_error("bas: a shell must have 1 ... 45 primitives"); return DQC_EINVAL; }
         if (s[5] < 0 || s[5] + h.nprim > nenv || s[6] < 0 || s[6] + h.nprim > nenv) {
             set_error("bas: exponent/coefficient pointer outside env"); return DQC_EINVAL;
         }

@@ -53,7 +53,13 @@ def nuclear_gradient(qc) -> torch.Tensor:
     norbs = [eng.norb.u, eng.norb.d] if pol else [eng.norb]
     d_aos, w_ao = [], 0.0
     for dm, fock, w, n in zip(dms, focks, weights, norbs):
-        uniform = w.numel() > 0 and getattr(eng, "_sinvh", None) is None and bool((w == w[0]).all())
+        # (the shortcut below needs D = w0 P with P commuting with F: an ACCEPTED fixed point with equal, non-zero occupations --
+        # a run that only warned keeps the energy-weighted density of the final Fock matrix's own orbitals; the flag is cached on
+        # the engine: it reads the device)
+        cache = eng.__dict__.setdefault("_uniform_occ_cache", {})
+        if id(w) not in cache:  # (the occupation tensors live as long as the engine)
+            cache[id(w)] = bool(w.numel() > 0 and bool((w == w[0]).all()) and float(w[0]) > 0.0)
+        uniform = cache[id(w)] and getattr(eng, "_sinvh", None) is None and bool(getattr(qc, "accepted", False))
         if uniform:
             # equal occupations w0 in an orthonormal basis: D = w0 P with P the projector on the occupied space, and at the fixed
             # point sum_i w0 eps_i c_i c_i^T = w0 P F P = D F D / w0 -- no diagonalisation (a 208 x 208 eigh was 3 ms of the gradient)
