@@ -89,6 +89,64 @@ __global__ __launch_bounds__(FT_NT) void fock_factor_kernel(double *__restrict__
     }
 }
 
+// ao_orb2dm and its factor in ONE launch (hcgto.py:272-281): the first nfac blocks are the tiles of L = X (C sqrt(w)) (as
+// fock_factor_kernel), the others the tiles on and right of the diagonal of D = C diag(w) C^T (north x north, orthogonal basis),
+// written with their mirror images.
+__global__ __launch_bounds__(FT_NT) void fock_orb2dm_kernel(double *__restrict__ dm, double *__restrict__ orb, double *__restrict__ orbt,
+                                                            const double *__restrict__ x, const double *__restrict__ c, int ldc,
+                                                            const double *__restrict__ w, int nao, int north, int r, int ld, int rp) {
+    __shared__ double sred[4 * 256];
+    __shared__ double sd[16 * 17];
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int nfx = ld / 16, nfac = nfx * (rp / 16);
+    if ((int)blockIdx.x < nfac) {
+        const int i0 = 16 * ((int)blockIdx.x % nfx), c0 = 16 * ((int)blockIdx.x / nfx);
+        const int col = c0 + lr;
+        const double sw = col < r ? sqrt(w[min(col, r - 1)]) : 0.0;
+        const v4d t = ft_tile((north + 3) & ~3,
+            [&](int m, int k) { const double v = x[(size_t)min(i0 + m, nao - 1) * north + min(k, north - 1)]; return (i0 + m < nao && k < north) ? v : 0.0; },
+            [&](int k, int n) { const double v = c[(size_t)min(k, north - 1) * ldc + min(c0 + n, r - 1)]; return k < north ? v * sw : 0.0; }, sred);
+        if (tid < 64) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = i0 + kq + 4 * q;
+                orb[(size_t)i * rp + col] = t[q];
+                orbt[(size_t)col * ld + i] = t[q];
+            }
+        }
+        return;
+    }
+    const int T = (north + 15) / 16;
+    int ti, tj;
+    ft_upper((int)blockIdx.x - nfac, T, ti, tj);
+    const int a0 = 16 * ti, b0 = 16 * tj;
+    const v4d t = ft_tile((r + 3) & ~3,
+        [&](int m, int k) { const int kc = min(k, r - 1); const double v = c[(size_t)min(a0 + m, north - 1) * ldc + kc] * w[kc]; return (a0 + m < north && k < r) ? v : 0.0; },
+        [&](int k, int n) { const double v = c[(size_t)min(b0 + n, north - 1) * ldc + min(k, r - 1)]; return (b0 + n < north && k < r) ? v : 0.0; }, sred);
+    if (ti != tj) {
+        if (tid < 64) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int a = a0 + kq + 4 * q, b = b0 + lr;
+                if (a < north && b < north) {
+                    dm[(size_t)a * north + b] = t[q];
+                    dm[(size_t)b * north + a] = t[q];
+                }
+            }
+        }
+        return;
+    }
+    if (tid < 64) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) sd[(kq + 4 * q) * 17 + lr] = t[q];
+    }
+    __syncthreads();
+    {
+        const int p = tid >> 4, q = tid & 15, a = a0 + p, b = a0 + q;
+        if (a < north && b < north) dm[(size_t)a * north + b] = 0.5 * (sd[p * 17 + q] + sd[q * 17 + p]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // AO density into the work buffer of the tile pass: work[0 : n2] <- D_ao (npad x npad, zero padded, BITWISE symmetric: the tiles on
 // and right of the diagonal are computed and written with their mirror images), work[n2 : (2 | 3) n2] <- 0 (J / K accumulators).
@@ -323,6 +381,21 @@ int dqc_fock_factor(double *d_orb, double *d_orbt, const double *d_x, const doub
     }
     hipLaunchKernelGGL(fock_factor_kernel, dim3(ld / 16, rp / 16), dim3(FT_NT), 0, (hipStream_t)stream, d_orb, d_orbt, d_x, d_c, ldc, d_w, nao,
                        north, r, ld, rp);
+    DQC_CHECK_LAUNCH();
+    return DQC_OK;
+}
+
+int dqc_fock_orb2dm(double *d_dm, double *d_orb, double *d_orbt, const double *d_x, const double *d_c, int ldc, const double *d_w, int nao,
+                    int north, int r, int ld, int rp, void *stream) {
+    using namespace dqc;
+    if (nao <= 0) return DQC_OK;
+    if (nao > dqc_fock_max_nao() || north > nao || north <= 0 || r <= 0 || r > rp || rp % 16 || ld < nao || ld % 16 || ldc < r) {
+        set_error("dqc_fock_orb2dm: needs 0 < north <= nao <= 1024, 0 < r <= rp (a multiple of 16), ld >= nao (a multiple of 16), ldc >= r");
+        return DQC_EINVAL;
+    }
+    const int T = (north + 15) / 16;
+    hipLaunchKernelGGL(fock_orb2dm_kernel, dim3((ld / 16) * (rp / 16) + T * (T + 1) / 2), dim3(FT_NT), 0, (hipStream_t)stream, d_dm, d_orb, d_orbt,
+                       d_x, d_c, ldc, d_w, nao, north, r, ld, rp);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -611,6 +611,16 @@ class HamiltonMI355(_Base):
     def ao_orb2dm(self, orb, orb_weight):
         """hcgto.py:272-281.  The factor L = orb sqrt(w) of the returned matrix is remembered (keyed on the identity
         + in-place version of the result) so that the grid pass can use the rank-n_occ density kernel."""
+        if (orb.dim() == 2 and orb_weight.dim() == 1 and self._lowrank_density and orb.is_cuda and orb.dtype == torch.float64
+                and (orb.shape[1] == 1 or orb.stride(1) == 1) and orb_weight.is_contiguous() and 0 < orb.shape[1] <= 128 and self._X is not None
+                and self._X.is_contiguous() and orb.shape[0] == self._X.shape[1] and self._nao_ao <= lib.fock_max_nao()
+                and os.environ.get("DQC_AMD_FUSED_FOCK", "1") != "0"):
+            # D and its AO-basis factor L = X C sqrt(w) from ONE launch (csrc/fock.hip) instead of multiply + GEMM here and
+            # sqrt + multiply + GEMM + padding copies at the factor's first use; the factor is only USED after the occupations were
+            # checked to be >= 0 (_factor_of), as before
+            dm, pair = lib.fock_orb2dm(self._X, orb, orb_weight, self._nao_ao, self._ld)
+            self._dm_factor = ([[dm, dm._version, orb, orb_weight, pair]] + (self._dm_factor or []))[:2]
+            return dm
         orb_w = orb * orb_weight.unsqueeze(-2)
         dm = torch.matmul(orb, orb_w.transpose(-2, -1))
         if orb.dim() == 2 and self._lowrank_density:
@@ -633,13 +643,16 @@ class HamiltonMI355(_Base):
         """list of padded AO-basis factor pairs (column panels of L) of `dm` if it came out of ao_orb2dm unmodified, else None"""
         for c in self._dm_factor or []:
             if c[0] is dm and c[1] == dm._version:
-                if len(c) == 4:  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
+                if len(c) >= 4 and not isinstance(c[2], list):  # first use: orthogonal basis -> AO basis (X . orb sqrt(w)), padded for the kernel
                     orb, w = c[2], c[3]
                     if not self._weights_nonneg(w):
                         self._dm_factor.remove(c)
                         return None
+                    if len(c) == 5:  # (ao_orb2dm's launch has formed the padded pair already)
+                        c[2:] = [[c[4]]]
+                        return c[2]
                     x = self._orthozer
-                    if (orb.dim() == 2 and w.dim() == 1 and orb.is_cuda and orb.stride(1) == 1 and w.is_contiguous() and x.is_contiguous()
+                    if (orb.dim() == 2 and w.dim() == 1 and orb.is_cuda and (orb.shape[1] == 1 or orb.stride(1) == 1) and w.is_contiguous() and x.is_contiguous()
                             and 0 < orb.shape[1] <= 128 and self._nao_ao <= lib.fock_max_nao() and os.environ.get("DQC_AMD_FUSED_FOCK", "1") != "0"):
                         c[2:] = [[lib.fock_factor(x, orb, w, self._nao_ao, self._ld)]]  # (one launch: csrc/fock.hip)
                         return c[2]

@@ -112,6 +112,7 @@ def load():
     lib.dqc_stream_cus.argtypes = [c_vp]
     lib.dqc_set_vxc_cus.argtypes = [c_int]
     lib.dqc_fock_factor.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.dqc_fock_orb2dm.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_fock_prep.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_jk_stream_prepared.argtypes = [c_dp, c_int, c_dp, c_int, c_vp]
     lib.dqc_fock_finish.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_dp, c_int, c_int, c_int, c_vp]
@@ -523,13 +524,31 @@ def fock_factor(x, c, w, nao, ld):
     rp = padded_norb(r)
     if rp == 0:
         return None
-    assert c.stride(1) == 1 and c.dtype == torch.float64 and w.is_contiguous()
+    assert (c.shape[1] == 1 or c.stride(1) == 1) and c.dtype == torch.float64 and w.is_contiguous()  # (rows c.stride(0) apart)
     orb = torch.empty((ld, rp), dtype=torch.float64, device=x.device)
     orbt = torch.empty((rp, ld), dtype=torch.float64, device=x.device)
     with _on(x.device) as st_:
         _check(load().dqc_fock_factor(_ptr(orb), _ptr(orbt), _ptr(x), ctypes.c_void_p(c.data_ptr()), int(c.stride(0)), _ptr(w), int(nao),
                                       int(x.shape[1]), int(r), int(ld), int(rp), st_), "dqc_fock_factor")
     return orb, orbt
+
+
+def fock_orb2dm(x, c, w, nao, ld):
+    """ao_orb2dm and its AO-basis factor in one launch -> dm (north, north) = C diag(w) C^T and the padded factor pair (orb, orbt) of
+    L = X (C sqrt(w)); None when the factor is wider than the density kernel's widest instantiation"""
+    r = c.shape[1]
+    rp = padded_norb(r)
+    if rp == 0:
+        return None
+    assert (c.shape[1] == 1 or c.stride(1) == 1) and c.dtype == torch.float64 and w.is_contiguous()  # (rows c.stride(0) apart)
+    north = x.shape[1]
+    dm = torch.empty((north, north), dtype=torch.float64, device=x.device)
+    orb = torch.empty((ld, rp), dtype=torch.float64, device=x.device)
+    orbt = torch.empty((rp, ld), dtype=torch.float64, device=x.device)
+    with _on(x.device) as st_:
+        _check(load().dqc_fock_orb2dm(_ptr(dm), _ptr(orb), _ptr(orbt), _ptr(x), ctypes.c_void_p(c.data_ptr()), int(c.stride(0)), _ptr(w),
+                                      int(nao), int(north), int(r), int(ld), int(rp), st_), "dqc_fock_orb2dm")
+    return dm, (orb, orbt)
 
 
 def fock_prep(work, x, nao, with_k, dm=None, orb=None):

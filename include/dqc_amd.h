@@ -109,6 +109,10 @@ int dqc_jk_from_tiles(double *d_J, double *d_K, const double *d_tiles, const dou
 int dqc_fock_max_nao(void);
 int dqc_fock_factor(double *d_orb, double *d_orbt, const double *d_x, const double *d_c, int ldc, const double *d_w, int nao, int north,
                     int r, int ld, int rp, void *stream);
+/* ao_orb2dm (hcgto.py:272-281) and its factor in one launch: d_dm (north, north) <- C diag(w) C^T, bitwise symmetric, and the padded
+ * factor pair of dqc_fock_factor */
+int dqc_fock_orb2dm(double *d_dm, double *d_orb, double *d_orbt, const double *d_x, const double *d_c, int ldc, const double *d_w, int nao,
+                    int north, int r, int ld, int rp, void *stream);
 int dqc_fock_prep(double *d_work, const double *d_dm, const double *d_x, const double *d_orb, int rp, int nao, int north, int with_k,
                   void *stream);
 int dqc_jk_stream_prepared(const double *d_tiles, int nao, double *d_work, int with_k, void *stream);
