@@ -229,11 +229,13 @@ __global__ __launch_bounds__(FT_NT) void fock_xd_kernel(double *__restrict__ t_o
 // ---------------------------------------------------------------------------------------------
 constexpr int FC_NB = 64;  // blocks
 
-template <bool DET, bool WITH_K, bool HAS_V>
+// HAS_V: 0 no V, 1 a symmetric AO matrix, 2 the RAW cross-block sums of dqc_grid_vxc_raw (V = (M + M^T) / 2; fixed-point integers of
+// scale vscale in deterministic mode)
+template <bool DET, bool WITH_K, int HAS_V>
 __global__ __launch_bounds__(FT_NT) void fock_combine_kernel(double *__restrict__ m, double *__restrict__ en, double *__restrict__ jout,
                                                              const double *__restrict__ work, const double *__restrict__ v, int ldv, int nao,
                                                              int npad, const double *__restrict__ dscp, double *__restrict__ part,
-                                                             unsigned *__restrict__ ticket) {
+                                                             unsigned *__restrict__ ticket, double vscale) {
     __shared__ double red[2][FT_WAVES];
     __shared__ bool last;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(FT_NT) void fock_combine_kernel(double *__restrict_
     constexpr int U = 4;
     double sj = 0.0, sk = 0.0;
     for (int e0 = blockIdx.x * FT_NT + tid; e0 < tot; e0 += FC_NB * FT_NT * U) {
-        double d[U], ja[U], jb[U], ka[U], kb[U], vv[U];
+        double d[U], ja[U], jb[U], ka[U], kb[U], vv[U], vt[U];
+        const double vinv = (HAS_V == 2 && DET) ? 1.0 / vscale : 0.0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = min(e0 + u * FC_NB * FT_NT, tot - 1), i = e / nao, j = e - i * nao;
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(FT_NT) void fock_combine_kernel(double *__restrict_
             ka[u] = WITH_K ? wk[(size_t)i * npad + j] : 0.0;
             kb[u] = WITH_K ? wk[(size_t)j * npad + i] : 0.0;
             vv[u] = HAS_V ? v[(size_t)i * ldv + j] : 0.0;
+            vt[u] = HAS_V == 2 ? v[(size_t)j * ldv + i] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -271,7 +275,12 @@ __global__ __launch_bounds__(FT_NT) void fock_combine_kernel(double *__restrict_
                     mv -= 0.5 * (k1 + dval(kb[u]));
                     sk += d[u] * k1;
                 }
-                if (HAS_V) mv += vv[u];
+                if (HAS_V == 1) mv += vv[u];
+                if (HAS_V == 2) {
+                    const double va = DET ? (double)__double_as_longlong(vv[u]) * vinv : vv[u];
+                    const double vb = DET ? (double)__double_as_longlong(vt[u]) * vinv : vt[u];
+                    mv += 0.5 * (va + vb);
+                }
                 m[(size_t)i * npad + j] = mv;
                 if (jout) jout[e] = jv;
             }
@@ -424,8 +433,23 @@ int dqc_fock_prep(double *d_work, const double *d_dm, const double *d_x, const d
     return DQC_OK;
 }
 
+static int fock_finish_impl(double *d_fock, double *d_energies, double *d_j_ao, double *d_work, const double *d_vxc_ao, int ldv,
+                            const double *d_core, const double *d_x, int nao, int north, int with_k, int vraw, double vscale, void *stream);
+
 int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, double *d_work, const double *d_vxc_ao, int ldv,
                     const double *d_core, const double *d_x, int nao, int north, int with_k, void *stream) {
+    return fock_finish_impl(d_fock, d_energies, d_j_ao, d_work, d_vxc_ao, ldv, d_core, d_x, nao, north, with_k, 0, 0.0, stream);
+}
+
+int dqc_fock_finish_vraw(double *d_fock, double *d_energies, double *d_work, const double *d_vxc_raw, int ldv, double vscale,
+                         const double *d_core, const double *d_x, int nao, int north, void *stream) {
+    // the Kohn-Sham finish on the raw sums of dqc_grid_vxc_raw (vscale: what that call returned)
+    if (!d_vxc_raw) { dqc::set_error("dqc_fock_finish_vraw: null matrix"); return DQC_EINVAL; }
+    return fock_finish_impl(d_fock, d_energies, nullptr, d_work, d_vxc_raw, ldv, d_core, d_x, nao, north, 0, 1, vscale, stream);
+}
+
+static int fock_finish_impl(double *d_fock, double *d_energies, double *d_j_ao, double *d_work, const double *d_vxc_ao, int ldv,
+                            const double *d_core, const double *d_x, int nao, int north, int with_k, int vraw, double vscale, void *stream) {
     using namespace dqc;
     if (nao <= 0) return DQC_OK;
     if (nao > dqc_fock_max_nao() || north > nao || north <= 0) { set_error("dqc_fock_finish: needs 0 < north <= nao <= 1024"); return DQC_EINVAL; }
@@ -439,14 +463,17 @@ int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, double *
     double *d_m = d_work + 3 * n2 + 8, *d_t = d_work + 4 * n2 + 8, *d_part = d_work + 5 * n2 + 8;
     // (the ticket is zero when the kernel starts: dqc_fock_prep, which every build runs first on this buffer, resets it)
 #define DQC_FK_COMBINE(D, K, V) \
-    hipLaunchKernelGGL((fock_combine_kernel<D, K, V>), dim3(FC_NB), dim3(FT_NT), 0, st, d_m, d_energies, d_j_ao, d_work, d_vxc_ao, ldv, nao, npad, dscp, d_part, ticket);
+    hipLaunchKernelGGL((fock_combine_kernel<D, K, V>), dim3(FC_NB), dim3(FT_NT), 0, st, d_m, d_energies, d_j_ao, d_work, d_vxc_ao, ldv, nao, npad, dscp, d_part, ticket, vscale);
     const bool det = dscp != nullptr, wk_ = with_k != 0, hv = d_vxc_ao != nullptr;
-    if (det) {
-        if (wk_) { if (hv) DQC_FK_COMBINE(true, true, true) else DQC_FK_COMBINE(true, true, false) }
-        else { if (hv) DQC_FK_COMBINE(true, false, true) else DQC_FK_COMBINE(true, false, false) }
+    if (vraw && (vscale != 0.0) != det) { set_error("dqc_fock_finish_vraw: the scale does not match the deterministic mode"); return DQC_EINVAL; }
+    if (vraw) {
+        if (det) DQC_FK_COMBINE(true, false, 2) else DQC_FK_COMBINE(false, false, 2)
+    } else if (det) {
+        if (wk_) { if (hv) DQC_FK_COMBINE(true, true, 1) else DQC_FK_COMBINE(true, true, 0) }
+        else { if (hv) DQC_FK_COMBINE(true, false, 1) else DQC_FK_COMBINE(true, false, 0) }
     } else {
-        if (wk_) { if (hv) DQC_FK_COMBINE(false, true, true) else DQC_FK_COMBINE(false, true, false) }
-        else { if (hv) DQC_FK_COMBINE(false, false, true) else DQC_FK_COMBINE(false, false, false) }
+        if (wk_) { if (hv) DQC_FK_COMBINE(false, true, 1) else DQC_FK_COMBINE(false, true, 0) }
+        else { if (hv) DQC_FK_COMBINE(false, false, 1) else DQC_FK_COMBINE(false, false, 0) }
     }
 #undef DQC_FK_COMBINE
     DQC_CHECK_LAUNCH();

@@ -1098,7 +1098,9 @@ static int launch_vxc(int maxt, int nl, int kch, dim3 grid, size_t shmem, hipStr
 extern "C" {
 
 static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob, int ncomp, int ngrid, int nao,
-                         const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream) {
+                         const double *d_w, const double *d_vrho, const double *d_vgrad, void *stream, bool raw = false) {
+    // raw: the cross-block sums M are left as the kernels wrote them (V = (M + M^T) / 2 restricted to the first nao rows / columns is
+    // formed by the consumer: dqc_fock_finish with vxc_raw) -- one launch less per build
     using namespace dqc;
     hipStream_t st = (hipStream_t)stream;
     const bool gga = d_vgrad != nullptr;
@@ -1154,7 +1156,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
                          : launch_vxc_ws2<false>(maxt2, nla, nlb, grid2, shmem2, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, NR, NC, LSA, LSB, d_aob, lda);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
+            if (!raw) hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
@@ -1182,7 +1184,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
             }
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
+            if (!raw) hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
@@ -1220,7 +1222,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
                          : launch_vxc_ws<false>(maxt, nlp, kch, grid, shmem_ws, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, sym ? 1 : 0, lda, LS);
             if (rc) return rc;
             DQC_CHECK_LAUNCH();
-            hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
+            if (!raw) hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
             DQC_CHECK_LAUNCH();
             return DQC_OK;
         }
@@ -1228,7 +1230,7 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
                      : launch_vxc<false>(maxt, nl, kch, grid, shmem, st, d_vmat, d_ao, ngrid, ld, d_w, d_vrho, d_vgrad, slab, nsplit, tps, d_aob, lda, LS);
         if (rc) return rc;
         DQC_CHECK_LAUNCH();
-        hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
+        if (!raw) hipLaunchKernelGGL(symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, st, d_vmat, ld, nao);
         DQC_CHECK_LAUNCH();
     }
     return DQC_OK;
@@ -1237,6 +1239,14 @@ static int grid_vxc_impl(double *d_vmat, const double *d_ao, const double *d_aob
 int dqc_grid_vxc(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao, const double *d_w,
                  const double *d_vrho, const double *d_vgrad, void *stream) {
     return grid_vxc_impl(d_vmat, d_ao, d_ao, ncomp, ngrid, nao, d_w, d_vrho, d_vgrad, stream);
+}
+
+int dqc_grid_vxc_raw(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao, const double *d_w, const double *d_vrho,
+                     const double *d_vgrad, double *h_scale, void *stream) {
+    // dqc_grid_vxc without its closing symmetrisation launch: d_vmat <- the raw cross-block sums M (fixed-point integers in
+    // deterministic mode; *h_scale <- their scale, 0: plain doubles), V = (M + M^T) / 2 on the first nao rows / columns
+    if (h_scale) *h_scale = dqc::deterministic_mode() ? 140737488355328.0 : 0.0;
+    return grid_vxc_impl(d_vmat, d_ao, d_ao, ncomp, ngrid, nao, d_w, d_vrho, d_vgrad, stream, true);
 }
 
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao, const double *d_w,

@@ -891,8 +891,15 @@ class HamiltonMI355(_Base):
                 exc = exc[:1]
         else:
             potinfo, exc = self.xc.get_vxc(densinfo), None
-        vm = self._vxc_ao_from_potinfo(potinfo)
-        mat, en, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm, core=core)  # (core: the one-electron part, added in the same launch)
+        if self.xcfamily != 4 and self._pworld == 1:
+            # LDA / GGA: the Vxc kernel's raw cross-block sums go straight into the finish (their symmetrisation is part of its
+            # combine kernel: one launch less)
+            vg = potinfo.grad if self.xcfamily == 2 else None
+            vraw, vsc = lib.grid_vxc_raw(self._ao, n, self.dvolume, potinfo.value.contiguous(), None if vg is None else vg.contiguous())
+            mat, en = lib.fock_finish_vraw(work, x, n, vraw, vsc, core=core)
+        else:
+            vm = self._vxc_ao_from_potinfo(potinfo)
+            mat, en, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm, core=core)  # (core: the one-electron part, added in the same launch)
         self._energy_memo = (dm, dm._version, en[0], None if exc is None else exc[0])
         return mat
 
@@ -1037,9 +1044,9 @@ class HamiltonMI355(_Base):
             mark()
             _, v, vg = lib.xc_eval(self.xc.terms, rho, grho, want_e=False, want_v=True)
             mark()
-            vm = lib.grid_vxc(self._ao, n, self.dvolume, v, vg)
+            vraw, vsc = lib.grid_vxc_raw(self._ao, n, self.dvolume, v, vg)
             mark()
-            fock, _, _ = lib.fock_finish(work, x, n, False, vxc_ao=vm, core=core.contiguous())  # noqa: F841
+            fock, _ = lib.fock_finish_vraw(work, x, n, vraw, vsc, core=core.contiguous())  # noqa: F841
             mark()
             return ["orth_transforms", "jk_tiles", "grid_density", "xc_eval", "grid_vxc", "fock_assemble"], ev
         dao_n = self._unconvert_dm((dm + dm.transpose(-2, -1)) * 0.5).contiguous()

@@ -113,6 +113,8 @@ def load():
     lib.dqc_set_vxc_cus.argtypes = [c_int]
     lib.dqc_fock_factor.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_fock_orb2dm.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.dqc_grid_vxc_raw.argtypes = [c_dp, c_dp, c_int, c_int, c_int, c_dp, c_dp, c_dp, dp, c_vp]
+    lib.dqc_fock_finish_vraw.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, ctypes.c_double, c_dp, c_dp, c_int, c_int, c_vp]
     lib.dqc_fock_prep.argtypes = [c_dp, c_dp, c_dp, c_dp, c_int, c_int, c_int, c_int, c_vp]
     lib.dqc_jk_stream_prepared.argtypes = [c_dp, c_int, c_dp, c_int, c_vp]
     lib.dqc_fock_finish.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp, c_int, c_dp, c_dp, c_int, c_int, c_int, c_vp]
@@ -987,6 +989,31 @@ def set_vxc_cus(ncu):
 def device_cu_count(device=None):
     with torch.cuda.device(device):
         return int(load().dqc_device_cu_count())
+
+
+def grid_vxc_raw(ao, nao, w, vrho, vgrad):
+    """dqc_grid_vxc without the closing symmetrisation launch -> (raw (ld, ld) cross-block sums, their fixed-point scale or 0.0);
+    for fock_finish_vraw"""
+    ncomp = 1 if ao.dim() == 2 else ao.shape[0]
+    ngrid = ao.shape[-2]
+    ld = padded_nao(nao)
+    vm = torch.empty((ld, ld), dtype=torch.float64, device=ao.device)
+    sc = ctypes.c_double(0.0)
+    with _on(ao.device) as st_:
+        _check(load().dqc_grid_vxc_raw(_ptr(vm), _ptr(ao), ncomp, ngrid, nao, _ptr(w), _ptr(vrho), _ptr(vgrad), ctypes.byref(sc), st_),
+               "dqc_grid_vxc" if vgrad is not None else "dqc_grid_vxc[no gradient term]")
+    return vm, float(sc.value)
+
+
+def fock_finish_vraw(work, x, nao, vxc_raw, vscale, core=None):
+    """the Kohn-Sham finish on the raw sums of grid_vxc_raw -> fock (north, north), energies (2,)"""
+    north = x.shape[1]
+    fock = torch.empty((north, north), dtype=torch.float64, device=work.device)
+    en = torch.empty(2, dtype=torch.float64, device=work.device)
+    with _on(work.device) as st_:
+        _check(load().dqc_fock_finish_vraw(_ptr(fock), _ptr(en), _ptr(work), _ptr(vxc_raw), int(vxc_raw.shape[-1]), float(vscale), _ptr(core),
+                                           _ptr(x), int(nao), int(north), st_), "dqc_fock_finish")
+    return fock, en
 
 
 def probe_stream_read(buf):

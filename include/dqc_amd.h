@@ -116,6 +116,10 @@ int dqc_fock_orb2dm(double *d_dm, double *d_orb, double *d_orbt, const double *d
 int dqc_fock_prep(double *d_work, const double *d_dm, const double *d_x, const double *d_orb, int rp, int nao, int north, int with_k,
                   void *stream);
 int dqc_jk_stream_prepared(const double *d_tiles, int nao, double *d_work, int with_k, void *stream);
+/* the Kohn-Sham finish straight on the raw cross-block sums of dqc_grid_vxc_raw (no symmetrisation launch in between): vscale = the
+ * scale that call returned (0: plain doubles) */
+int dqc_fock_finish_vraw(double *d_fock, double *d_energies, double *d_work, const double *d_vxc_raw, int ldv, double vscale,
+                         const double *d_core, const double *d_x, int nao, int north, void *stream);
 int dqc_fock_finish(double *d_fock, double *d_energies, double *d_j_ao, double *d_work, const double *d_vxc_ao, int ldv,
                     const double *d_core, const double *d_x, int nao, int north, int with_k, void *stream);
 
@@ -358,6 +362,11 @@ int dqc_grid_density_pair(double *d_out, const double *d_ao_a, const double *d_a
                           const double *d_dm, void *stream);
 int dqc_grid_vxc_pair(double *d_vmat, const double *d_ao_a, const double *d_ao_b, int ngrid, int nao,
                       const double *d_w, const double *d_v, void *stream);
+
+/* dqc_grid_vxc without its closing symmetrisation: d_vmat (ld, ld) <- the raw sums M; V = (M + M^T) / 2 on the first nao rows / columns
+ * (fixed-point integers of scale *h_scale in deterministic mode, *h_scale = 0 otherwise) -- consumed by dqc_fock_finish_vraw */
+int dqc_grid_vxc_raw(double *d_vmat, const double *d_ao, int ncomp, int ngrid, int nao, const double *d_w, const double *d_vrho,
+                     const double *d_vgrad, double *h_scale, void *stream);
 
 /* ---- the tile store spread over several GPUs (one molecule on N ranks: 8 x 288 GB hold the tiles of ~1200 basis functions) ----
  * Tiles follow each other in the order (IJ, KL <= IJ); a rank keeps the tiles [tile_begin, tile_end) in a buffer of
