@@ -544,12 +544,12 @@ def main():
             "roofline": roof(dom),
             "roofline_other_kernels": [roof(k) for k in alg_bytes if k != dom] + [whole_iteration],
             "measured_ceilings_note": "measured_hbm_read_ceiling_gbs = dqc_probe_stream_read on a 2 GB buffer (contiguous 32 KB tiles per block, "
-                                      "16-byte non-temporal loads, four tiles in flight).  Round 6 (profiles/r06a_hbm_ceiling_bisect.txt): the same "
-                                      "kernel reads 5.2 TB/s on 2 GB and 6.1 TB/s on 8 GB in ANY process state (bare, 145 GB resident, touched or "
-                                      "not, after MFMA work): a launch pays ~80 us of ramp and drain, t = 0.082 ms + bytes / 6.5 TB/s.  "
-                                      "standalone_read_ceiling_gbs = 6450 is that asymptote (what rounds 2-5 called the standalone figure came "
-                                      "from a larger buffer, not from a cleaner process); kernels that stream 1.9-2.3 GB per launch are priced "
-                                      "against the 2 GB figure",
+                                      "16-byte non-temporal loads, four tiles in flight, two blocks per CU).  Until round 6 the probe ended in 16384 "
+                                      "fp64 atomicAdds of its checksum on one address (~75 us per launch) and read 5.2-5.3 TB/s on 2 GB -- the "
+                                      "'in-process ceiling' of rounds 2-5, which profiles/r06a_hbm_ceiling_bisect.txt showed to be independent of "
+                                      "the process state and profiles/r06c_read_shape.txt traced to those atomics; with one atomic per block it "
+                                      "reads 6.15-6.25 TB/s, like plain read kernels in any access shape the grid kernels use.  "
+                                      "standalone_read_ceiling_gbs = 6450 is the large-buffer asymptote (tools/ubench/read_bw.hip)",
             "traffic_note": traffic_note,
             "sources": source_sha16(),
         }

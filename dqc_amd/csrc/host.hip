@@ -354,8 +354,7 @@ size_t dqc_eri_tile_count(int nao) {
 
 // streaming-read probe used by bench.py as the MEASURED HBM read ceiling.  Round 5: the access shape of tools/ubench/read_bw.hip
 // that reads fastest on this chip -- contiguous 32 KB tiles per 256-thread block, 16-byte NON-TEMPORAL loads, four tiles' worth of
-// loads in flight before the first use (6.5 TB/s; the grid-stride loop of cached 16-byte loads used until round 4 stops at 5.2-5.3
-// and made the J and density kernels look like 0.95 of "the ceiling")
+// loads in flight before the first use, two blocks per CU (6.3-6.4 TB/s on 2 GB, 6.5 on large buffers)
 typedef double probe_v2d __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void probe_read_kernel(const probe_v2d *__restrict__ buf, long long ntile, size_t n2, double *out) {
     constexpr int U = 4;
@@ -382,8 +381,14 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const probe_v2d *__rest
     }
     // (the tail that does not fill a tile)
     for (size_t i = (size_t)ntile * 2048 + (size_t)blockIdx.x * blockDim.x + t; i < n2; i += (size_t)gridDim.x * blockDim.x) s += buf[i].x + buf[i].y;
+    // ONE atomic per block (round 6): the 16384 per-wave fp64 atomicAdds of rounds 1-5 to the one address serialise at ~4.6 ns each --
+    // 75-80 us per launch, which is what made this probe read 5.2 TB/s on 2 GB and 6.1 on 8 GB and was mistaken for a launch ramp
+    // of the chip (tools/ubench/read_shape.hip: the same loop without the atomics reads 6.2-6.4 TB/s on 2 GB)
+    __shared__ double part[4];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // fp64 MFMA issue-rate probe: 8 independent 16x16x4 accumulators per wave, `iters` rounds.
@@ -414,7 +419,7 @@ int dqc_probe_mfma_f64(double *d_out, int iters, void *stream) {
 int dqc_probe_stream_read(const double *d_buf, size_t n, double *d_out, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     DQC_HIP(hipMemsetAsync(d_out, 0, sizeof(double), st));
-    hipLaunchKernelGGL(probe_read_kernel, dim3(4096), dim3(256), 0, st, (const probe_v2d *)d_buf, (long long)(n / 4096), n / 2, d_out);
+    hipLaunchKernelGGL(probe_read_kernel, dim3(2 * dqc::stream_cus(st)), dim3(256), 0, st, (const probe_v2d *)d_buf, (long long)(n / 4096), n / 2, d_out);
     DQC_CHECK_LAUNCH();
     return DQC_OK;
 }

@@ -1,6 +1,6 @@
 // timeline of the rank-r density kernel: which blocks share a CU and how their MFMA / epilogue segments overlap
 #define DEN_TRACE 1
-#include "../../dqc_amd/csrc/grid.hip"
+#include "../../dqc_amd/csrc/grid_density.hip"
 #include <cstdio>
 #include <vector>
 #include <map>
