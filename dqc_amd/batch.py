@@ -50,7 +50,7 @@ def reserve_device_memory(nbytes: int, device) -> float:
 class CuPartition:
     """The chip split in two for a batch of restricted Kohn-Sham builds (round 6): `grid_streams` -- HIP streams confined to the
     first 32 - k compute units of every XCD, on which the caller runs its Fock builds (density, functional and Vxc kernels: bound
-    by the matrix cores, every VGPR of their CUs taken) -- and ONE Coulomb stream on the other k CUs per XCD, to which
+    by the matrix cores, most registers and LDS of their CUs taken) -- and ONE Coulomb stream on the other k CUs per XCD, to which
     `HamiltonMI355.get_elrep_plus_vxc` sends the pass over the ERI tiles (HBM-bound, no matrix-core work) of every build that runs
     on one of the grid streams.  The tile stream of molecule m then rides in the HBM bandwidth the grid pass of molecule m leaves;
     with two or more grid streams the next molecule's Coulomb pass starts while this one's build still waits for its own.

@@ -71,8 +71,8 @@ static int device_cus() {
     }
     return cached[dev];
 }
-// Cap on the CUs the one-block-per-CU Vxc kernels occupy (0: none).  Those blocks hold every VGPR of their CU for the whole launch, so
-// while a Vxc kernel runs nothing else is resident anywhere; with a cap of e.g. 208 the launch leaves 48 CUs to the kernels other
+// Cap on the CUs the one-block-per-CU Vxc kernels occupy (0: none).  Those blocks hold 408 of 512 VGPRs per SIMD and 128 of 160 KB of LDS for the whole launch, so
+// while a Vxc kernel runs no block of the other hot kernels is resident anywhere; with a cap of e.g. 208 the launch leaves 48 CUs to the kernels other
 // streams have queued (the HBM-bound Coulomb / density passes of other molecules of a batch).  dqc_set_vxc_cus / DQC_VXC_CUS.
 static std::atomic<int> g_vxc_cus{-1};
 int vxc_cus_cap() {

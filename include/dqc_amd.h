@@ -441,8 +441,8 @@ int dqc_set_generic_eri(int on);
 /* ---- compute-unit partitions (round 6) --------------------------------------------------------
  * The restricted Kohn-Sham build has two independent halves per density matrix: the Coulomb stream over the ERI tiles (HBM-bound,
  * no matrix-core work; reference: the J einsum of hcgto.py:204-227) and the grid pass (density, functional, Vxc; matrix-core-bound;
- * hcgto.py:371-495).  The Vxc kernel holds every VGPR of the CUs it runs on, so two launches on ordinary streams never share
- * the chip.  dqc_stream_create_partition makes a HIP stream whose kernels run only on CUs [cu_begin, cu_end) of every XCD
+ * hcgto.py:371-495).  The Vxc kernel holds 408 of the 512 VGPRs of every SIMD and 128 of the 160 KB of LDS of the CUs it runs on; the other hot kernels'
+ * blocks do not fit beside it, so two launches on ordinary streams never share the chip.  dqc_stream_create_partition makes a HIP stream whose kernels run only on CUs [cu_begin, cu_end) of every XCD
  * (hipExtStreamCreateWithCUMask): the host layer gives the grid pass most of each XCD and the Coulomb streams of OTHER molecules
  * the rest, so the tile stream rides in the HBM bandwidth the matrix-core-bound kernels leave.  Kernels that size their launch by
  * the CU count (one block per CU) ask dqc_stream_cus(stream).  priority is reserved (0). */
@@ -450,7 +450,7 @@ int dqc_device_cu_count(void);
 int dqc_stream_create_partition(void **stream_out, int cu_begin, int cu_end, int priority);
 int dqc_stream_destroy(void *stream);
 int dqc_stream_cus(void *stream);
-/* Cap on the compute units the one-block-per-CU Vxc kernels occupy (0: none; environment DQC_VXC_CUS).  Their blocks hold every VGPR
+/* Cap on the compute units the one-block-per-CU Vxc kernels occupy (0: none; environment DQC_VXC_CUS).  Their blocks hold most of the VGPRs and LDS
  * of a CU for the whole launch; a cap below the CU count leaves the rest of the chip to what other streams have queued (the
  * HBM-bound Coulomb and density passes of other molecules of a batch).  Process-wide, returns the previous setting. */
 int dqc_set_vxc_cus(int ncu);

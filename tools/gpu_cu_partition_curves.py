@@ -1,5 +1,5 @@
 """Round 6, VERDICT r5 item 1(b): does the Coulomb stream hide beside the grid pass when each gets its own compute units?
-The Vxc kernel holds every VGPR of a CU, so two launches on ordinary streams never share the chip (8 streams: 724 it/s against 741 for
+The Vxc kernel holds most of the VGPRs and LDS of a CU, so two launches on ordinary streams never share the chip (8 streams: 724 it/s against 741 for
 the serial sum of the three hot kernels).  Here: J on CUs [32 - k, 32) of every XCD, the grid pass (density, functional, Vxc) of
 ANOTHER molecule on CUs [0, 32 - k); each alone on its partition, then both at once.  One C5 molecule's arrays serve both roles
 (different buffers are touched: tiles vs AO matrix), a second molecule's tile store is used when --two is given.
