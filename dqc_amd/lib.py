@@ -1041,11 +1041,12 @@ def probe_mfma_f64_tflops(device, iters=4000):
 def probe_hbm_read_gbs(device, nbytes=2 << 30):
     """measured streaming-read bandwidth (GB/s) over a buffer larger than the Infinity Cache"""
     buf = torch.empty(nbytes // 8, dtype=torch.float64, device=device).normal_()
-    probe_stream_read(buf)
+    for _ in range(5):  # (the first launches after an idle spell run at a lower clock: 6.05 then 6.25 TB/s)
+        probe_stream_read(buf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(3):
+    for _ in range(10):
         probe_stream_read(buf)
     e1.record()
     torch.cuda.synchronize()
-    return 3.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return 10.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
