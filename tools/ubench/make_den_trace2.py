@@ -1,7 +1,9 @@
 """Per-block phase timeline of density_lr_kernel WITHOUT disturbing its register allocation (tools/ubench/den_trace.hip's -DDEN_TRACE
 build spills 273 VGPRs): a patched copy of csrc/grid_density.hip keeps four s_memrealtime stamps in SGPRs (start, end of phase 1, end
 of the last panel's phase 2, end) and thread 0 writes them with the CU id when the block is done.
-usage: python tools/ubench/make_den_trace2.py  -> tools/ubench/_den_trace2_kernel.hip (included by den_trace2.hip)"""
+usage: python tools/ubench/make_den_trace2.py  -> tools/ubench/_den_trace2_kernel.hip (included by den_trace2.hip)
+(DEN_TRACE_STEPS=1 adds per-step stamps to the experimental direct-operand phase 1 of docs/LOG_r06.md section 4; that code path is not in
+the product kernel, so the option only applies to a tree that carries it.  den_trace2 <us> delays the first blocks in odd wave slots.)"""
 import os
 here = os.path.dirname(os.path.abspath(__file__))
 src = open(os.path.join(here, "../../dqc_amd/csrc/grid_density.hip")).read()
